@@ -1,0 +1,126 @@
+"""ctypes binding of the CPU oracle (oracle/libpv_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+The oracle is the checker the HIP path is compared against; nothing under phaze_amd/ imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(ROOT, "oracle")
+_SO = os.path.join(_ORACLE_DIR, "libpv_oracle.so")
+_lib = None
+
+
+def build_oracle(force: bool = False) -> str:
+    src = os.path.join(_ORACLE_DIR, "pv_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-B", "libpv_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build_oracle())
+        fp = C.POINTER(C.c_float)
+        L.pvo_create.restype = C.c_void_p
+        L.pvo_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.pvo_destroy.argtypes = [C.c_void_p]
+        L.pvo_process.restype = C.c_int
+        L.pvo_process.argtypes = [C.c_void_p, C.POINTER(fp), C.POINTER(fp), C.c_int, C.c_int, C.c_float]
+        L.pvo_process_planar.restype = C.c_int
+        L.pvo_process_planar.argtypes = [C.c_void_p, fp, fp, C.c_int, C.c_int, C.c_long, fp]
+        for name, rt in (("pvo_debug_X", C.POINTER(C.c_double)), ("pvo_debug_Y", C.POINTER(C.c_double)),
+                         ("pvo_debug_mag", fp), ("pvo_debug_peaks", C.POINTER(C.c_int32))):
+            getattr(L, name).restype = rt
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.pvo_debug_npeaks.restype = C.c_int
+        L.pvo_debug_npeaks.argtypes = [C.c_void_p]
+        L.pvo_time_cursor.restype = C.c_double
+        L.pvo_time_cursor.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Oracle:
+    """One reference processor instance (one input / one output, `nch` channels)."""
+
+    def __init__(self, fft_size: int, hop: int, nch: int = 1):
+        self.h = lib().pvo_create(fft_size, hop, nch)
+        if not self.h:
+            raise ValueError("FFT size must be a power of two and bigger than 1")
+        self.N, self.hop = fft_size, hop
+
+    def close(self):
+        if self.h:
+            lib().pvo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def process(self, blocks, pitch: float, paused: bool = False):
+        """blocks: list of float32[hop] per channel -> list of float32[hop] outputs."""
+        nch = len(blocks)
+        ins = [np.ascontiguousarray(b, dtype=np.float32) for b in blocks]
+        outs = [np.zeros(self.hop, dtype=np.float32) for _ in range(nch)]
+        fp = C.POINTER(C.c_float)
+        ip = (fp * max(nch, 1))(*[_fptr(a) for a in ins])
+        op = (fp * max(nch, 1))(*[_fptr(a) for a in outs])
+        lib().pvo_process(self.h, ip, op, nch, 1 if paused else 0, C.c_float(float(pitch)))
+        return outs
+
+    def process_planar(self, x: np.ndarray, pitch: np.ndarray) -> np.ndarray:
+        """x: [nch, nhops*hop] float32, pitch: [nhops] float32 -> same shape output."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        nch, n = x.shape
+        nhops = n // self.hop
+        pitch = np.ascontiguousarray(pitch, dtype=np.float32)
+        assert pitch.shape[0] >= nhops
+        y = np.zeros_like(x)
+        lib().pvo_process_planar(self.h, _fptr(x), _fptr(y), nch, nhops, n, _fptr(pitch))
+        return y
+
+    def debug(self) -> dict:
+        L, N = lib(), self.N
+        H = N // 2 + 1
+        npk = L.pvo_debug_npeaks(self.h)
+        return {
+            "X": np.ctypeslib.as_array(L.pvo_debug_X(self.h), shape=(2 * N,)).copy(),
+            "Y": np.ctypeslib.as_array(L.pvo_debug_Y(self.h), shape=(2 * N,)).copy(),
+            "mag": np.ctypeslib.as_array(L.pvo_debug_mag(self.h), shape=(H,)).copy(),
+            "peaks": np.ctypeslib.as_array(L.pvo_debug_peaks(self.h), shape=(H,))[:npk].copy(),
+        }
+
+
+def run_case(case: dict, signals, pitch, collect_dumps=False):
+    """Drive one golden case (incl. pause / channel-change events) through the oracle.
+    Returns (out[maxch, nhops*hop], dumps{hop: debug dict})."""
+    N, h, T = case["fft"], case["hop"], case["nhops"]
+    nch = case["nch"]
+    o = Oracle(N, h, nch)
+    out = np.zeros((len(signals), T * h), dtype=np.float32)
+    dumps = {}
+    for m in range(T):
+        paused = False
+        for e in case.get("events", []):
+            if e["hop"] == m:
+                if e["type"] == "pause":
+                    paused = True
+                if e["type"] == "channels":
+                    nch = e["nch"]
+        blocks = [signals[c][m * h:(m + 1) * h] for c in range(nch)]
+        res = o.process(blocks, pitch[m], paused)
+        for c in range(nch):
+            out[c, m * h:(m + 1) * h] = res[c]
+        if collect_dumps and m in case.get("dump_hops", []):
+            dumps[m] = o.debug()
+    o.close()
+    return out, dumps
