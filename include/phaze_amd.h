@@ -1,0 +1,131 @@
+/*
+ * phaze_amd.h -- C ABI of the MI355X-native phase-vocoder pitch shifter (drop-in boundary).
+ *
+ * This library replaces ONE path of olvb/phaze: the AudioWorkletProcessor call
+ *     process(inputs, outputs, {pitchFactor}) -> true
+ * of OLAProcessor.process                (/root/reference/src/ola-processor.js:159-171) with
+ *    PhaseVocoderProcessor.processOLA    (/root/reference/src/phase-vocoder.js:45-72) and the fft.js
+ *    arithmetic it calls                 (/root/reference/www/phase-vocoder.js:2-508).
+ * The reference has no FFI (it is JavaScript in a browser audio thread); the functions below are what a
+ * Node.js N-API addon (phaze_amd/node/phaze_napi.c) or any other FFI (ctypes, cgo, JNI) binds.
+ * See INTEGRATION.md for the reference-side binding.
+ *
+ * Conventions: plain C types only; the caller owns every I/O buffer; the library owns all device state;
+ * every function returns an int status (PV_OK == 0) and never throws or aborts across the boundary.
+ * A handle is NOT thread-safe (the reference runs on one audio thread: one caller per handle).
+ */
+#ifndef PHAZE_AMD_H
+#define PHAZE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define PV_API __attribute__((visibility("default")))
+#else
+#define PV_API
+#endif
+
+/* ---- status codes ---- */
+enum {
+    PV_OK = 0,
+    PV_ERR_FFT_SIZE = 1,     /* 'FFT size must be a power of two and bigger than 1' (bundle:6-7)        */
+    PV_ERR_ARGUMENT = 2,     /* NULL pointer, negative count, hop does not divide fft_size, ...          */
+    PV_ERR_UNSUPPORTED = 3,  /* valid for the reference but outside this build's kernel range (64..8192)  */
+    PV_ERR_CAPACITY = 4,     /* more channels / hops than the handle was created for                     */
+    PV_ERR_DEVICE = 5,       /* HIP runtime error (no GPU, launch failure, out of memory)                */
+    PV_ERR_DESTROYED = 6     /* handle already destroyed                                                  */
+};
+
+typedef struct pv_handle pv_handle;
+
+/* Construction options.  Replaces `new PhaseVocoderProcessor(options)` (phase-vocoder.js:24-43,
+ * ola-processor.js:7-34).  The reference hard-codes fft_size 2048 (phase-vocoder.js:6) and hop 128
+ * (ola-processor.js:3); both are options here, defaults (0) select the reference's values. */
+typedef struct pv_config {
+    int32_t fft_size;        /* N, power of two; 0 => 2048                                              */
+    int32_t hop_size;        /* h, divides N; 0 => 128.  nbOverlaps R = N / h (ola-processor.js:17)     */
+    int32_t max_channels;    /* channel slots owned by this handle (streams x channels); 0 => 2         */
+    int32_t max_hops;        /* largest nhops of a host-buffer batch call (staging size); 0 => 1        */
+    int32_t device_id;       /* HIP device ordinal                                                       */
+    int32_t frames_per_chunk;/* batch kernel: output hops per workgroup (0 => auto)                      */
+} pv_config;
+
+typedef struct pv_info {
+    int32_t fft_size, hop_size, overlaps, max_channels, max_hops;
+    int32_t threads_per_workgroup, lds_bytes_per_workgroup, frames_per_chunk;
+    int32_t compute_units, device_id;
+    char device_name[64];
+} pv_info;
+
+/* ---- lifetime ---------------------------------------------------------------------------------- */
+/* Allocates device state (zeroed input history + overlap-add accumulators, timeCursor = 0) and the
+ * FFT/Hann tables.  Replaces the constructor chain phase-vocoder.js:24-43 -> ola-processor.js:7-34.  */
+PV_API int pv_create(const pv_config *cfg, pv_handle **out);
+PV_API int pv_destroy(pv_handle *h);
+
+/* Human-readable text of the last failure on this handle (h == NULL: of the last failed pv_create). */
+PV_API const char *pv_last_error(const pv_handle *h);
+PV_API const char *pv_status_string(int status);
+PV_API int pv_get_info(const pv_handle *h, pv_info *out);
+
+/* ---- state ------------------------------------------------------------------------------------- */
+/* Zero history + accumulators of ALL channels and set timeCursor = 0 (a freshly constructed processor). */
+PV_API int pv_reset(pv_handle *h);
+/* Zero history + accumulator of channel slots [first, first+count): what allocateInputChannels /
+ * allocateOutputChannels do when a channel count changes (ola-processor.js:38-52,54-88).  timeCursor kept. */
+PV_API int pv_reset_channels(pv_handle *h, int32_t first, int32_t count);
+/* timeCursor (phase-vocoder.js:31,71): samples consumed so far = hops * hop_size. */
+PV_API int pv_get_time_cursor(const pv_handle *h, int64_t *out);
+PV_API int pv_set_time_cursor(pv_handle *h, int64_t value);
+
+/* ---- the hot call, streaming form (one render quantum) ------------------------------------------- */
+/* Replaces OLAProcessor.process(inputs, outputs, parameters) (ola-processor.js:159-171) for ONE input /
+ * ONE output with nch channels:  in[c] -> nsamples (== hop_size) host floats, valid only during the call;
+ * out[c] <- hop_size floats.  pitch_factor = parameters.pitchFactor[last] (phase-vocoder.js:47).
+ * nsamples == 0 (or in == NULL) reproduces the paused branch (ola-processor.js:93-100): the newest hop
+ * is treated as zeros, timeCursor still advances.  A change of nch against the previous call resets all
+ * channel state first (ola-processor.js:38-52).  Synchronous: outputs are valid on return.  PV_OK <=> the
+ * reference's `return true`. */
+PV_API int pv_process(pv_handle *h, const float *const *in, float *const *out, int32_t nch,
+                      int32_t nsamples, float pitch_factor);
+
+/* ---- the hot call, batch (throughput) form ------------------------------------------------------- */
+/* nhops consecutive process() calls for nch channel slots in one launch.  Planar layout: channel c
+ * occupies in[c*ch_stride .. c*ch_stride + nhops*hop_size), same for out.  pitch[m] is the k-rate
+ * pitchFactor of hop m; with pitch_stride != 0 channel c uses the row of its stream,
+ * pitch[(c / channels_per_stream) * pitch_stride + m] (independent processors batched together).
+ * State (history, accumulator tail, timeCursor) carries across calls exactly as if process() had been
+ * called hop by hop.  Host-pointer variant: synchronous, stages through device memory. */
+PV_API int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int32_t nhops,
+                            int64_t ch_stride, const float *pitch, int32_t pitch_stride,
+                            int32_t channels_per_stream);
+
+/* Device-pointer variant: in/out/pitch are DEVICE pointers (HBM-resident), the launch is asynchronous on
+ * the handle's stream (pv_set_stream / pv_synchronize).  This is the form bench.py times. */
+PV_API int pv_process_batch_device(pv_handle *h, const float *d_in, float *d_out, int32_t nch,
+                                   int32_t nhops, int64_t ch_stride, const float *d_pitch,
+                                   int32_t pitch_stride, int32_t channels_per_stream);
+
+/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL => the
+ * handle's own stream. */
+PV_API int pv_set_stream(pv_handle *h, void *hip_stream);
+PV_API int pv_synchronize(pv_handle *h);
+
+/* ---- test taps ----------------------------------------------------------------------------------- */
+/* Runs ONE frame of channel `ch` through the kernels from the CURRENT state without changing it and
+ * returns the intermediates the reference keeps in freqComplexBuffer / magnitudes / peakIndexes /
+ * freqComplexBufferShifted (phase-vocoder.js:37-42): X[2N] doubles (bins 0..N/2 and, when the frame reads
+ * it, the above-Nyquist residue), mag[N/2+1], peak_flags[N/2+1] (0/1), Y[2*(N/2+1)] floats.
+ * block: hop_size host floats (the newest hop).  Any output pointer may be NULL. */
+PV_API int pv_debug_frame(pv_handle *h, int32_t ch, const float *block, float pitch_factor, double *X,
+                          float *mag, int32_t *peak_flags, float *Y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHAZE_AMD_H */

@@ -1,0 +1,208 @@
+"""ctypes binding of include/phaze_amd.h (the same entry points the N-API addon binds).
+
+Mirrors the reference surface: `PhaseVocoder.process(inputs, outputs, parameters)` has the argument
+meaning of OLAProcessor.process (/root/reference/src/ola-processor.js:159-171).  There is NO fallback:
+if libphaze_amd.so cannot be loaded, or no HIP device exists, construction raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libphaze_amd.so")
+_lib = None
+
+PV_OK, PV_ERR_FFT_SIZE, PV_ERR_ARGUMENT, PV_ERR_UNSUPPORTED, PV_ERR_CAPACITY, PV_ERR_DEVICE, PV_ERR_DESTROYED = range(7)
+
+EXPORTS = [
+    "pv_create", "pv_destroy", "pv_last_error", "pv_status_string", "pv_get_info", "pv_reset", "pv_reset_channels",
+    "pv_get_time_cursor", "pv_set_time_cursor", "pv_process", "pv_process_batch", "pv_process_batch_device",
+    "pv_set_stream", "pv_synchronize", "pv_debug_frame",
+]
+
+
+class PvError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+class _Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("fft_size", "hop_size", "max_channels", "max_hops", "device_id", "frames_per_chunk")]
+
+
+class _Info(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("fft_size", "hop_size", "overlaps", "max_channels", "max_hops", "threads_per_workgroup",
+                                          "lds_bytes_per_workgroup", "frames_per_chunk", "compute_units", "device_id")] + [("device_name", C.c_char * 64)]
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the gfx950 library in-tree with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", csrc]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise PvError(PV_ERR_DEVICE, f"{_LIB_PATH} is missing: build it with phaze_amd.build_library() / __graft_entry__.build(); "
+                                     "there is no CPU fallback")
+    L = C.CDLL(_LIB_PATH)
+    fp, vp = C.POINTER(C.c_float), C.c_void_p
+    L.pv_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
+    L.pv_destroy.argtypes = [vp]
+    L.pv_last_error.argtypes = [vp]
+    L.pv_last_error.restype = C.c_char_p
+    L.pv_status_string.argtypes = [C.c_int]
+    L.pv_status_string.restype = C.c_char_p
+    L.pv_get_info.argtypes = [vp, C.POINTER(_Info)]
+    L.pv_reset.argtypes = [vp]
+    L.pv_reset_channels.argtypes = [vp, C.c_int32, C.c_int32]
+    L.pv_get_time_cursor.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.pv_set_time_cursor.argtypes = [vp, C.c_int64]
+    L.pv_process.argtypes = [vp, C.POINTER(fp), C.POINTER(fp), C.c_int32, C.c_int32, C.c_float]
+    L.pv_process_batch.argtypes = [vp, fp, fp, C.c_int32, C.c_int32, C.c_int64, fp, C.c_int32, C.c_int32]
+    L.pv_process_batch_device.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int32, C.c_int32]
+    L.pv_set_stream.argtypes = [vp, vp]
+    L.pv_synchronize.argtypes = [vp]
+    L.pv_debug_frame.argtypes = [vp, C.c_int32, fp, C.c_float, C.POINTER(C.c_double), fp, C.POINTER(C.c_int32), fp]
+    for n in EXPORTS:
+        if n not in ("pv_last_error", "pv_status_string"):
+            getattr(L, n).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class PhaseVocoder:
+    """One processor instance = one `new PhaseVocoderProcessor(options)` (phase-vocoder.js:24-43)."""
+
+    parameter_descriptors = [{"name": "pitchFactor", "defaultValue": 1.0}]   # phase-vocoder.js:17-22
+
+    def __init__(self, fft_size=2048, hop_size=128, max_channels=2, max_hops=1, device_id=0, frames_per_chunk=0):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        cfg = _Config(fft_size, hop_size, max_channels, max_hops, device_id, frames_per_chunk)
+        rc = self._L.pv_create(C.byref(cfg), C.byref(self._h))
+        if rc != PV_OK:
+            msg = self._L.pv_last_error(None).decode()
+            self._h = C.c_void_p()
+            if rc == PV_ERR_FFT_SIZE:
+                raise ValueError(msg)           # the reference throws Error('FFT size must be ...') (bundle:6-7)
+            raise PvError(rc, msg)
+        self.fft_size, self.hop_size = fft_size, hop_size
+        self.max_channels, self.max_hops = max_channels, max_hops
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.pv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != PV_OK:
+            raise PvError(rc, self._L.pv_last_error(self._h).decode())
+
+    # -- state --
+    def reset(self):
+        self._check(self._L.pv_reset(self._h))
+
+    def reset_channels(self, first, count):
+        self._check(self._L.pv_reset_channels(self._h, first, count))
+
+    @property
+    def time_cursor(self):
+        v = C.c_int64()
+        self._check(self._L.pv_get_time_cursor(self._h, C.byref(v)))
+        return v.value
+
+    @time_cursor.setter
+    def time_cursor(self, value):
+        self._check(self._L.pv_set_time_cursor(self._h, int(value)))
+
+    def info(self):
+        i = _Info()
+        self._check(self._L.pv_get_info(self._h, C.byref(i)))
+        d = {n: getattr(i, n) for n, _ in _Info._fields_}
+        d["device_name"] = i.device_name.decode()
+        return d
+
+    # -- the hot call, AudioWorklet form --
+    def process(self, inputs, outputs, parameters):
+        """inputs[0][c]: float32[hop] (or length 0 when paused); outputs[0][c]: float32[hop], filled.
+        parameters['pitchFactor']: float32 array, last element used (phase-vocoder.js:47).  Returns True."""
+        chans = inputs[0]
+        nch = len(chans)
+        pf = np.asarray(parameters["pitchFactor"], dtype=np.float32)
+        pitch = float(pf[-1])
+        paused = nch > 0 and len(chans[0]) == 0                                 # ola-processor.js:93
+        outs = outputs[0]
+        fpt = C.POINTER(C.c_float)
+        keep = [np.ascontiguousarray(c, dtype=np.float32) for c in chans]
+        ip = (fpt * max(nch, 1))(*[_fp(a) if a.size else None for a in keep])
+        tmp = [np.zeros(self.hop_size, dtype=np.float32) for _ in range(nch)]
+        op = (fpt * max(nch, 1))(*[_fp(a) for a in tmp])
+        self._check(self._L.pv_process(self._h, ip, op, nch, 0 if paused else self.hop_size, C.c_float(pitch)))
+        for c in range(min(nch, len(outs))):
+            outs[c][:] = tmp[c]
+        return True
+
+    # -- the hot call, batch forms --
+    def process_batch(self, x, pitch, channels_per_stream=0):
+        """x: float32[nch, nhops*hop] (host); pitch: float32[nhops] or [nstreams, nhops]. Returns y like x."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        nch, n = x.shape
+        nhops = n // self.hop_size
+        assert nhops * self.hop_size == n
+        pitch = np.ascontiguousarray(pitch, dtype=np.float32)
+        stride = 0
+        if pitch.ndim == 2:
+            stride = pitch.shape[1]
+        y = np.empty_like(x)
+        self._check(self._L.pv_process_batch(self._h, _fp(x), _fp(y), nch, nhops, n, _fp(pitch), stride, channels_per_stream or 1))
+        return y
+
+    def process_batch_device(self, d_in, d_out, nch, nhops, ch_stride, d_pitch, pitch_stride=0, channels_per_stream=1):
+        """Raw device pointers (ints).  Asynchronous on the handle's stream."""
+        self._check(self._L.pv_process_batch_device(self._h, C.c_void_p(d_in), C.c_void_p(d_out), nch, nhops, ch_stride,
+                                                    C.c_void_p(d_pitch), pitch_stride, channels_per_stream))
+
+    def set_stream(self, hip_stream):
+        self._check(self._L.pv_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        self._check(self._L.pv_synchronize(self._h))
+
+    # -- test tap --
+    def debug_frame(self, ch, block, pitch):
+        N = self.fft_size
+        H = N // 2 + 1
+        block = np.ascontiguousarray(block, dtype=np.float32)
+        X = np.zeros(2 * N, dtype=np.float64)
+        mag = np.zeros(H, dtype=np.float32)
+        flags = np.zeros(H, dtype=np.int32)
+        Y = np.zeros(2 * H, dtype=np.float32)
+        self._check(self._L.pv_debug_frame(self._h, ch, _fp(block), C.c_float(float(pitch)), X.ctypes.data_as(C.POINTER(C.c_double)),
+                                           _fp(mag), flags.ctypes.data_as(C.POINTER(C.c_int32)), _fp(Y)))
+        return {"X": X, "mag": mag, "flags": flags, "Y": Y}

@@ -1,0 +1,400 @@
+// pv_capi.hip -- host side of the C ABI declared in include/phaze_amd.h.
+//
+// Owns the device state of one processor instance (what OLAProcessor / PhaseVocoderProcessor keep in
+// typed arrays: ola-processor.js:20-33,54-88 and phase-vocoder.js:30-42) and turns process() calls into
+// launches of the chain kernel (pv_kernels.hip).  No CPU compute path exists here: without a HIP device
+// pv_create fails with PV_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/phaze_amd.h"
+#include "pv_kernels.h"
+
+namespace {
+constexpr uint32_t kMagic = 0x50564d49u;   // 'PVMI'
+constexpr int kHdrFloats = 16;             // pinned staging header: [0] = pitchFactor
+thread_local char g_create_err[256] = "";
+}  // namespace
+
+struct pv_handle {
+    uint32_t magic;
+    int N, hop, L, R, log2n;
+    int max_channels, max_hops, device, cus;
+    int frames_per_chunk_cfg;
+    int last_frames_per_chunk;
+    hipStream_t own_stream, stream;
+    double2 *d_tw64;
+    float2 *d_tw32;
+    float *d_hann;
+    float *d_hist[2], *d_acc[2];
+    int cur;
+    float *d_stage_in, *d_stage_out, *d_pitch;   // host-buffer batch staging
+    float *h_pin;                                // pinned: [hdr | max_channels*hop in | max_channels*hop out]
+    float *d_quantum;                            // device twin of h_pin
+    double *d_dbgX; float *d_dbgMag; int *d_dbgFlags; float *d_dbgY;
+    int64_t time_cursor;
+    int active_nch;
+    char devname[64];
+    char err[256];
+};
+
+namespace {
+
+int fail(pv_handle *h, int code, const char *msg)
+{
+    if (h) snprintf(h->err, sizeof h->err, "%s", msg);
+    else snprintf(g_create_err, sizeof g_create_err, "%s", msg);
+    return code;
+}
+
+int fail_hip(pv_handle *h, hipError_t e, const char *what)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    return fail(h, PV_ERR_DEVICE, buf);
+}
+
+#define HIPCHK(h, call)                                            \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ != hipSuccess) return fail_hip((h), e_, #call);     \
+    } while (0)
+
+bool live(const pv_handle *h) { return h && h->magic == kMagic; }
+
+int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
+{
+    if (h->frames_per_chunk_cfg > 0) return h->frames_per_chunk_cfg;
+    int F = 12 * h->R;                       // halo overhead (R-1)/F ~ 8 %
+    const long want = 8L * h->cus;           // enough workgroups to fill every CU several times
+    while (F > h->R && (long)nch * ((nhops + F - 1) / F) < want) F >>= 1;
+    if (F < 1) F = 1;
+    return F;
+}
+
+// One launch over [nch] channel slots x [nhops] hops; flips the state ping-pong and advances timeCursor.
+int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops, long ch_stride, const float *d_pitch,
+              int pitch_stride, int ch_per_stream, bool commit, int dbg_ch)
+{
+    PvKernelParams p;
+    memset(&p, 0, sizeof p);
+    p.in = d_in; p.out = d_out; p.ch_stride = ch_stride;
+    p.nhops = nhops; p.hop = h->hop;
+    p.frames_per_chunk = commit ? pick_frames_per_chunk(h, nch, nhops) : nhops;
+    p.pitch = d_pitch; p.pitch_stride = pitch_stride; p.ch_per_stream = ch_per_stream > 0 ? ch_per_stream : 1;
+    p.hist_in = h->d_hist[h->cur]; p.hist_out = h->d_hist[h->cur ^ 1];
+    p.acc_in = h->d_acc[h->cur];   p.acc_out = h->d_acc[h->cur ^ 1];
+    p.t0_mod_n = (int)(h->time_cursor & (int64_t)(h->N - 1));
+    p.tw64 = h->d_tw64; p.tw32 = h->d_tw32; p.hann = h->d_hann;
+    p.dbg_ch = -1; p.dbg_frame = -1;
+    if (dbg_ch >= 0) { p.dbg_X = h->d_dbgX; p.dbg_mag = h->d_dbgMag; p.dbg_flags = h->d_dbgFlags; p.dbg_Y = h->d_dbgY; p.dbg_ch = dbg_ch; p.dbg_frame = 0; }
+    const int nchunks = (nhops + p.frames_per_chunk - 1) / p.frames_per_chunk;
+    h->last_frames_per_chunk = p.frames_per_chunk;
+    hipError_t e = pv_launch_chain(h->log2n, p, nch, nchunks, h->stream);
+    if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
+    if (commit) {
+        // channels outside [0, nch) keep their state: copy them across the ping-pong flip
+        if (nch < h->max_channels && h->L > 0) {
+            const size_t off = (size_t)nch * h->L, cnt = (size_t)(h->max_channels - nch) * h->L * sizeof(float);
+            HIPCHK(h, hipMemcpyAsync(h->d_hist[h->cur ^ 1] + off, h->d_hist[h->cur] + off, cnt, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->d_acc[h->cur ^ 1] + off, h->d_acc[h->cur] + off, cnt, hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->cur ^= 1;
+        h->time_cursor += (int64_t)nhops * h->hop;
+    }
+    return PV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pv_status_string(int status)
+{
+    switch (status) {
+    case PV_OK: return "ok";
+    case PV_ERR_FFT_SIZE: return "FFT size must be a power of two and bigger than 1";
+    case PV_ERR_ARGUMENT: return "invalid argument";
+    case PV_ERR_UNSUPPORTED: return "configuration outside the supported kernel range";
+    case PV_ERR_CAPACITY: return "channel or hop count exceeds the handle's capacity";
+    case PV_ERR_DEVICE: return "HIP device error";
+    case PV_ERR_DESTROYED: return "handle destroyed";
+    default: return "unknown status";
+    }
+}
+
+const char *pv_last_error(const pv_handle *h) { return live(h) ? h->err : g_create_err; }
+
+int pv_create(const pv_config *cfg, pv_handle **out)
+{
+    if (!cfg || !out) return fail(nullptr, PV_ERR_ARGUMENT, "pv_create: null argument");
+    *out = nullptr;
+    const int N = cfg->fft_size ? cfg->fft_size : 2048;          // phase-vocoder.js:6
+    const int hop = cfg->hop_size ? cfg->hop_size : 128;         // ola-processor.js:3
+    if (N <= 1 || (N & (N - 1)) != 0)                            // bundle:6-7
+        return fail(nullptr, PV_ERR_FFT_SIZE, "FFT size must be a power of two and bigger than 1");
+    if (hop <= 0 || N % hop != 0) return fail(nullptr, PV_ERR_ARGUMENT, "hop_size must be positive and divide fft_size");
+    int log2n = 0;
+    while ((1 << log2n) < N) log2n++;
+    if (log2n < 6 || log2n > 13) return fail(nullptr, PV_ERR_UNSUPPORTED, "fft_size must be within 64..8192 for the gfx950 kernels");
+    if (hop < 2 && N != hop) return fail(nullptr, PV_ERR_UNSUPPORTED, "hop_size must be >= 2");
+    if (pv_kernel_lds_bytes(log2n, hop) > 160 * 1024)
+        return fail(nullptr, PV_ERR_UNSUPPORTED, "fft_size/hop_size combination exceeds the 160 KiB LDS of a CU");
+    const int maxch = cfg->max_channels > 0 ? cfg->max_channels : 2;
+    const int maxhops = cfg->max_hops > 0 ? cfg->max_hops : 1;
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, PV_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, PV_ERR_ARGUMENT, "device_id out of range");
+
+    pv_handle *h = (pv_handle *)calloc(1, sizeof(pv_handle));
+    h->magic = kMagic;
+    h->N = N; h->hop = hop; h->L = N - hop; h->R = N / hop; h->log2n = log2n;
+    h->max_channels = maxch; h->max_hops = maxhops; h->device = cfg->device_id;
+    h->frames_per_chunk_cfg = cfg->frames_per_chunk;
+    h->active_nch = -1;
+#define CHK(call)                                                          \
+    do {                                                                   \
+        hipError_t e2_ = (call);                                           \
+        if (e2_ != hipSuccess) {                                           \
+            int rc_ = fail_hip(nullptr, e2_, #call);                       \
+            pv_destroy(h);                                                 \
+            return rc_;                                                    \
+        }                                                                  \
+    } while (0)
+    CHK(hipSetDevice(h->device));
+    hipDeviceProp_t prop;
+    CHK(hipGetDeviceProperties(&prop, h->device));
+    h->cus = prop.multiProcessorCount;
+    snprintf(h->devname, sizeof h->devname, "%s", prop.name);
+    CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+
+    // tables: twiddles exp(-2 pi j k/N) (role of bundle:12-18) and the periodic Hann window (pv:8-14), fp64 on host
+    std::vector<double2> tw64(N);
+    std::vector<float2> tw32(N);
+    std::vector<float> hann(N);
+    for (int k = 0; k < N; k++) {
+        const double ang = 2.0 * M_PI * (double)k / (double)N;
+        tw64[k] = double2{cos(ang), -sin(ang)};
+        tw32[k] = float2{(float)tw64[k].x, (float)tw64[k].y};
+        hann[k] = (float)(0.5 * (1.0 - cos(ang)));
+    }
+    // exact values on the axes (libm returns ~1e-16 residues)
+    tw64[0] = double2{1, 0}; tw32[0] = float2{1, 0};
+    if (N >= 4) { tw64[N / 4] = double2{0, -1}; tw32[N / 4] = float2{0, -1}; tw64[3 * N / 4] = double2{0, 1}; tw32[3 * N / 4] = float2{0, 1}; }
+    tw64[N / 2] = double2{-1, 0}; tw32[N / 2] = float2{-1, 0};
+    CHK(hipMalloc(&h->d_tw64, sizeof(double2) * N));
+    CHK(hipMalloc(&h->d_tw32, sizeof(float2) * N));
+    CHK(hipMalloc(&h->d_hann, sizeof(float) * N));
+    CHK(hipMemcpy(h->d_tw64, tw64.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(h->d_tw32, tw32.data(), sizeof(float2) * N, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(h->d_hann, hann.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+
+    const size_t state = sizeof(float) * (size_t)maxch * (size_t)(h->L > 0 ? h->L : 1);
+    for (int i = 0; i < 2; i++) {
+        CHK(hipMalloc(&h->d_hist[i], state));
+        CHK(hipMalloc(&h->d_acc[i], state));
+        CHK(hipMemset(h->d_hist[i], 0, state));
+        CHK(hipMemset(h->d_acc[i], 0, state));
+    }
+    const size_t stage = sizeof(float) * (size_t)maxch * (size_t)maxhops * (size_t)hop;
+    CHK(hipMalloc(&h->d_stage_in, stage));
+    CHK(hipMalloc(&h->d_stage_out, stage));
+    CHK(hipMalloc(&h->d_pitch, sizeof(float) * (size_t)maxch * (size_t)maxhops));
+    const size_t quantum = sizeof(float) * (kHdrFloats + 2 * (size_t)maxch * hop);
+    CHK(hipHostMalloc((void **)&h->h_pin, quantum, hipHostMallocDefault));
+    CHK(hipMalloc(&h->d_quantum, quantum));
+    CHK(hipMalloc(&h->d_dbgX, sizeof(double) * 2 * N));
+    CHK(hipMalloc(&h->d_dbgMag, sizeof(float) * (N / 2 + 1)));
+    CHK(hipMalloc(&h->d_dbgFlags, sizeof(int) * (N / 2 + 1)));
+    CHK(hipMalloc(&h->d_dbgY, sizeof(float) * 2 * (N / 2 + 1)));
+#undef CHK
+    *out = h;
+    return PV_OK;
+}
+
+int pv_destroy(pv_handle *h)
+{
+    if (!h) return PV_OK;
+    if (h->magic != kMagic) return PV_ERR_DESTROYED;
+    hipSetDevice(h->device);
+    if (h->own_stream) hipStreamSynchronize(h->own_stream);
+    hipFree(h->d_tw64); hipFree(h->d_tw32); hipFree(h->d_hann);
+    for (int i = 0; i < 2; i++) { hipFree(h->d_hist[i]); hipFree(h->d_acc[i]); }
+    hipFree(h->d_stage_in); hipFree(h->d_stage_out); hipFree(h->d_pitch);
+    if (h->h_pin) hipHostFree(h->h_pin);
+    hipFree(h->d_quantum);
+    hipFree(h->d_dbgX); hipFree(h->d_dbgMag); hipFree(h->d_dbgFlags); hipFree(h->d_dbgY);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    h->magic = 0;
+    free(h);
+    return PV_OK;
+}
+
+int pv_get_info(const pv_handle *h, pv_info *out)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    if (!out) return PV_ERR_ARGUMENT;
+    memset(out, 0, sizeof *out);
+    out->fft_size = h->N; out->hop_size = h->hop; out->overlaps = h->R;
+    out->max_channels = h->max_channels; out->max_hops = h->max_hops;
+    out->threads_per_workgroup = pv_kernel_threads(h->log2n);
+    out->lds_bytes_per_workgroup = (int32_t)pv_kernel_lds_bytes(h->log2n, h->hop);
+    out->frames_per_chunk = h->last_frames_per_chunk;
+    out->compute_units = h->cus; out->device_id = h->device;
+    snprintf(out->device_name, sizeof out->device_name, "%s", h->devname);
+    return PV_OK;
+}
+
+int pv_reset_channels(pv_handle *h, int32_t first, int32_t count)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    if (first < 0 || count < 0 || first + count > h->max_channels) return fail(h, PV_ERR_ARGUMENT, "pv_reset_channels: range out of bounds");
+    if (count == 0 || h->L == 0) return PV_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t off = (size_t)first * h->L, bytes = sizeof(float) * (size_t)count * h->L;
+    HIPCHK(h, hipMemsetAsync(h->d_hist[h->cur] + off, 0, bytes, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_acc[h->cur] + off, 0, bytes, h->stream));
+    return PV_OK;
+}
+
+int pv_reset(pv_handle *h)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    const int rc = pv_reset_channels(h, 0, h->max_channels);
+    if (rc != PV_OK) return rc;
+    h->time_cursor = 0;
+    h->active_nch = -1;
+    return PV_OK;
+}
+
+int pv_get_time_cursor(const pv_handle *h, int64_t *out)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    if (!out) return PV_ERR_ARGUMENT;
+    *out = h->time_cursor;
+    return PV_OK;
+}
+
+int pv_set_time_cursor(pv_handle *h, int64_t value)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    if (value < 0) return fail(h, PV_ERR_ARGUMENT, "pv_set_time_cursor: negative");
+    h->time_cursor = value;
+    return PV_OK;
+}
+
+int pv_set_stream(pv_handle *h, void *hip_stream)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return PV_OK;
+}
+
+int pv_synchronize(pv_handle *h)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PV_OK;
+}
+
+int pv_process(pv_handle *h, const float *const *in, float *const *out, int32_t nch, int32_t nsamples, float pitch_factor)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    if (nch < 0 || (nch > 0 && !out)) return fail(h, PV_ERR_ARGUMENT, "pv_process: bad channel arguments");
+    if (nch > h->max_channels) return fail(h, PV_ERR_CAPACITY, "pv_process: nch exceeds max_channels");
+    const bool paused = (nsamples == 0 || in == nullptr);                       // ola-processor.js:93-100
+    if (!paused && nsamples != h->hop) return fail(h, PV_ERR_ARGUMENT, "pv_process: nsamples must equal hop_size (or 0 when paused)");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->active_nch >= 0 && nch != h->active_nch) {                           // ola-processor.js:38-52
+        const int rc = pv_reset_channels(h, 0, h->max_channels);
+        if (rc != PV_OK) return rc;
+    }
+    h->active_nch = nch;
+    if (nch == 0) { h->time_cursor += h->hop; return PV_OK; }                   // pv:71 still advances
+    const int hop = h->hop;
+    float *pin_in = h->h_pin + kHdrFloats, *pin_out = pin_in + (size_t)h->max_channels * hop;
+    h->h_pin[0] = pitch_factor;
+    for (int c = 0; c < nch; c++) {
+        if (paused || !in[c]) memset(pin_in + (size_t)c * hop, 0, sizeof(float) * hop);
+        else memcpy(pin_in + (size_t)c * hop, in[c], sizeof(float) * hop);       // host block is only valid during the call (ola:64)
+    }
+    float *dq_in = h->d_quantum + kHdrFloats, *dq_out = dq_in + (size_t)h->max_channels * hop;
+    HIPCHK(h, hipMemcpyAsync(h->d_quantum, h->h_pin, sizeof(float) * (kHdrFloats + (size_t)nch * hop), hipMemcpyHostToDevice, h->stream));
+    const int rc = run_chain(h, dq_in, dq_out, nch, 1, hop, h->d_quantum, 0, 1, true, -1);
+    if (rc != PV_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(pin_out, dq_out, sizeof(float) * (size_t)nch * hop, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int c = 0; c < nch; c++)
+        if (out[c]) memcpy(out[c], pin_out + (size_t)c * hop, sizeof(float) * hop);
+    return PV_OK;                                                                // ola-processor.js:170: return true
+}
+
+int pv_process_batch_device(pv_handle *h, const float *d_in, float *d_out, int32_t nch, int32_t nhops, int64_t ch_stride,
+                            const float *d_pitch, int32_t pitch_stride, int32_t channels_per_stream)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    if (!d_in || !d_out || !d_pitch || nch <= 0 || nhops <= 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: bad arguments");
+    if (nch > h->max_channels) return fail(h, PV_ERR_CAPACITY, "pv_process_batch_device: nch exceeds max_channels");
+    if (ch_stride < (int64_t)nhops * h->hop && nch > 1) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: ch_stride smaller than nhops*hop");
+    HIPCHK(h, hipSetDevice(h->device));
+    return run_chain(h, d_in, d_out, nch, nhops, (long)ch_stride, d_pitch, pitch_stride, channels_per_stream, true, -1);
+}
+
+int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int32_t nhops, int64_t ch_stride, const float *pitch,
+                     int32_t pitch_stride, int32_t channels_per_stream)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    if (!in || !out || !pitch || nch <= 0 || nhops <= 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: bad arguments");
+    if (nch > h->max_channels || nhops > h->max_hops) return fail(h, PV_ERR_CAPACITY, "pv_process_batch: nch/nhops exceed the handle's capacity");
+    const size_t row = (size_t)nhops * h->hop;
+    if (ch_stride < (int64_t)row && nch > 1) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: ch_stride smaller than nhops*hop");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int cps = channels_per_stream > 0 ? channels_per_stream : 1;
+    const int nrows = pitch_stride ? (nch + cps - 1) / cps : 1;
+    if (pitch_stride && pitch_stride < nhops) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: pitch_stride smaller than nhops");
+    HIPCHK(h, hipMemcpy2DAsync(h->d_stage_in, row * sizeof(float), in, (size_t)ch_stride * sizeof(float), row * sizeof(float), nch,
+                               hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->d_pitch, (size_t)nhops * sizeof(float), pitch, (size_t)(pitch_stride ? pitch_stride : nhops) * sizeof(float),
+                               (size_t)nhops * sizeof(float), nrows, hipMemcpyHostToDevice, h->stream));
+    const int rc = run_chain(h, h->d_stage_in, h->d_stage_out, nch, nhops, (long)row, h->d_pitch, pitch_stride ? nhops : 0, cps, true, -1);
+    if (rc != PV_OK) return rc;
+    HIPCHK(h, hipMemcpy2DAsync(out, (size_t)ch_stride * sizeof(float), h->d_stage_out, row * sizeof(float), row * sizeof(float), nch,
+                               hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PV_OK;
+}
+
+int pv_debug_frame(pv_handle *h, int32_t ch, const float *block, float pitch_factor, double *X, float *mag, int32_t *peak_flags, float *Y)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    if (ch < 0 || ch >= h->max_channels || !block) return fail(h, PV_ERR_ARGUMENT, "pv_debug_frame: bad arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int hop = h->hop, N = h->N, H = N / 2 + 1;
+    // place the block at slot `ch` of the quantum buffer so that channel indexing matches the state arrays
+    float *pin_in = h->h_pin + kHdrFloats;
+    h->h_pin[0] = pitch_factor;
+    memset(pin_in, 0, sizeof(float) * (size_t)(ch + 1) * hop);
+    memcpy(pin_in + (size_t)ch * hop, block, sizeof(float) * hop);
+    float *dq_in = h->d_quantum + kHdrFloats, *dq_out = dq_in + (size_t)h->max_channels * hop;
+    HIPCHK(h, hipMemcpyAsync(h->d_quantum, h->h_pin, sizeof(float) * (kHdrFloats + (size_t)(ch + 1) * hop), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_dbgX, 0, sizeof(double) * 2 * N, h->stream));
+    const int rc = run_chain(h, dq_in, dq_out, ch + 1, 1, hop, h->d_quantum, 0, 1, false, ch);   // commit=false: state untouched
+    if (rc != PV_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (X) HIPCHK(h, hipMemcpy(X, h->d_dbgX, sizeof(double) * 2 * N, hipMemcpyDeviceToHost));
+    if (mag) HIPCHK(h, hipMemcpy(mag, h->d_dbgMag, sizeof(float) * H, hipMemcpyDeviceToHost));
+    if (peak_flags) HIPCHK(h, hipMemcpy(peak_flags, h->d_dbgFlags, sizeof(int) * H, hipMemcpyDeviceToHost));
+    if (Y) HIPCHK(h, hipMemcpy(Y, h->d_dbgY, sizeof(float) * 2 * H, hipMemcpyDeviceToHost));
+    return PV_OK;
+}
+
+}  // extern "C"

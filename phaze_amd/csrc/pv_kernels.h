@@ -1,0 +1,34 @@
+// pv_kernels.h -- host-visible launch interface of the CDNA4 kernels (internal; the public ABI is include/phaze_amd.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct PvKernelParams {
+    const float *in;          // planar input, channel c at in + c*ch_stride, nhops*hop samples
+    float *out;               // planar output, same layout
+    long ch_stride;
+    int nhops;                // hops (= process() calls) in this launch
+    int hop;
+    int frames_per_chunk;     // output hops per workgroup
+    const float *pitch;       // pitchFactor per hop (k-rate, phase-vocoder.js:47)
+    int pitch_stride;         // 0: one row shared by all channels; else row = (c / ch_per_stream)
+    int ch_per_stream;
+    const float *hist_in;     // [ch][N-hop] input history carried in   (ola-processor.js:59,121-127)
+    float *hist_out;          // [ch][N-hop] carried out (other half of the ping-pong)
+    const float *acc_in;      // [ch][N-hop] overlap-add accumulator tail carried in (ola-processor.js:77,130-137)
+    float *acc_out;
+    int t0_mod_n;             // timeCursor at the first hop of the launch, mod N (phase-vocoder.js:31,71)
+    const double2 *tw64;      // exp(-2 pi j k / N), k in [0, N), fp64
+    const float2 *tw32;       // same, rounded to fp32
+    const float *hann;        // periodic Hann, fp32 (phase-vocoder.js:8-14)
+    // test taps (all null in production)
+    double *dbg_X;
+    float *dbg_mag;
+    int *dbg_flags;
+    float *dbg_Y;
+    int dbg_ch, dbg_frame;
+};
+
+int pv_kernel_threads(int log2n);
+size_t pv_kernel_lds_bytes(int log2n, int hop);
+hipError_t pv_launch_chain(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
