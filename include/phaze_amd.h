@@ -45,10 +45,10 @@ typedef struct pv_handle pv_handle;
 
 /* Construction options.  Replaces `new PhaseVocoderProcessor(options)` (phase-vocoder.js:24-43,
  * ola-processor.js:7-34).  The reference hard-codes fft_size 2048 (phase-vocoder.js:6) and hop 128
- * (ola-processor.js:3); both are options here, defaults (0) select the reference's values. */
+ * (ola-processor.js:3); both are options here; the host layer (phaze_amd/node/phase-vocoder.js) supplies the reference's values when omitted. */
 typedef struct pv_config {
-    int32_t fft_size;        /* N, power of two; 0 => 2048                                              */
-    int32_t hop_size;        /* h, divides N; 0 => 128.  nbOverlaps R = N / h (ola-processor.js:17)     */
+    int32_t fft_size;        /* N, power of two > 1 (else PV_ERR_FFT_SIZE); kernels cover 64..8192        */
+    int32_t hop_size;        /* h >= 2, divides N.  nbOverlaps R = N / h (ola-processor.js:17)           */
     int32_t max_channels;    /* channel slots owned by this handle (streams x channels); 0 => 2         */
     int32_t max_hops;        /* largest nhops of a host-buffer batch call (staging size); 0 => 1        */
     int32_t device_id;       /* HIP device ordinal                                                       */

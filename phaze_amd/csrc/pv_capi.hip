@@ -134,15 +134,15 @@ int pv_create(const pv_config *cfg, pv_handle **out)
 {
     if (!cfg || !out) return fail(nullptr, PV_ERR_ARGUMENT, "pv_create: null argument");
     *out = nullptr;
-    const int N = cfg->fft_size ? cfg->fft_size : 2048;          // phase-vocoder.js:6
-    const int hop = cfg->hop_size ? cfg->hop_size : 128;         // ola-processor.js:3
+    const int N = cfg->fft_size;                                 // the host passes 2048 for the reference default (phase-vocoder.js:6)
+    const int hop = cfg->hop_size;                               // ... and 128 (ola-processor.js:3)
     if (N <= 1 || (N & (N - 1)) != 0)                            // bundle:6-7
         return fail(nullptr, PV_ERR_FFT_SIZE, "FFT size must be a power of two and bigger than 1");
     if (hop <= 0 || N % hop != 0) return fail(nullptr, PV_ERR_ARGUMENT, "hop_size must be positive and divide fft_size");
     int log2n = 0;
     while ((1 << log2n) < N) log2n++;
     if (log2n < 6 || log2n > 13) return fail(nullptr, PV_ERR_UNSUPPORTED, "fft_size must be within 64..8192 for the gfx950 kernels");
-    if (hop < 2 && N != hop) return fail(nullptr, PV_ERR_UNSUPPORTED, "hop_size must be >= 2");
+    if (hop < 2) return fail(nullptr, PV_ERR_UNSUPPORTED, "hop_size must be >= 2");
     if (pv_kernel_lds_bytes(log2n, hop) > 160 * 1024)
         return fail(nullptr, PV_ERR_UNSUPPORTED, "fft_size/hop_size combination exceeds the 160 KiB LDS of a CU");
     const int maxch = cfg->max_channels > 0 ? cfg->max_channels : 2;
@@ -172,7 +172,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     hipDeviceProp_t prop;
     CHK(hipGetDeviceProperties(&prop, h->device));
     h->cus = prop.multiProcessorCount;
-    snprintf(h->devname, sizeof h->devname, "%s", prop.name);
+    snprintf(h->devname, sizeof h->devname, "%s (%s)", prop.name[0] ? prop.name : "AMD GPU", prop.gcnArchName);
     CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
 

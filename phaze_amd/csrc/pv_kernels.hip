@@ -192,7 +192,8 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
     int last_out = first_out + p.frames_per_chunk;
     if (last_out > p.nhops) last_out = p.nhops;
     int first_frame = first_out - (R - 1);                                // halo: frames that still overlap first_out
-    if (first_frame < 0 || chunk == 0) first_frame = 0;
+    const bool from_state = (first_frame <= 0);                           // the carried accumulator still reaches first_out
+    if (from_state) first_frame = 0;
 
     const long cbase = (long)ch * p.ch_stride;
     FrameSrc src{p.in + cbase, p.hist_in + (long)ch * L, L};
@@ -200,8 +201,8 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
     const float *pitch_row = p.pitch + (p.pitch_stride ? (long)(ch / p.ch_per_stream) * p.pitch_stride : 0);
     const float invR = 1.0f / (float)R;                                   // exact: R is a power of two
 
-    // accumulator ring: chunk 0 resumes from the carried state, later chunks rebuild it from the halo frames
-    for (int j = tid; j < L; j += THREADS) acc[j] = (chunk == 0) ? p.acc_in[(long)ch * L + j] : 0.f;
+    // accumulator ring: chunks whose halo reaches hop 0 resume from the carried state, later chunks rebuild it from the halo frames
+    for (int j = tid; j < L; j += THREADS) acc[j] = from_state ? p.acc_in[(long)ch * L + j] : 0.f;
     int ring = 0;
     __syncthreads();
 
