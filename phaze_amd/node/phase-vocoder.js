@@ -1,0 +1,125 @@
+"use strict";
+/*
+ * phase-vocoder.js -- Node.js host for the MI355X-native pitch shifter.
+ *
+ * Drop-in for the reference worklet module (/root/reference/src/phase-vocoder.js + src/ola-processor.js):
+ * same registration name, same `parameterDescriptors`, same constructor shape, same
+ * `process(inputs, outputs, parameters) -> true`.  The per-frame work (Hann -> real FFT -> peak picking ->
+ * region shift -> inverse FFT -> Hann -> overlap-add) runs as HIP kernels behind the N-API addon; this file
+ * only keeps the bookkeeping the reference does in JS around that call:
+ *   - one native handle per input (channels of one input share a launch),
+ *   - channel (re)allocation: a changed channel count zeroes that input's state (ola-processor.js:38-52,54-88),
+ *   - the paused branch (ola-processor.js:93-100),
+ *   - k-rate pitchFactor = last element of the parameter array (phase-vocoder.js:47).
+ * There is no JS fallback for the DSP: without the addon / a GPU, construction throws.
+ */
+const path = require("path");
+const native = require(path.join(__dirname, "phaze_napi.node"));
+
+const BUFFERED_BLOCK_SIZE = 2048;   // reference default (phase-vocoder.js:6)
+const WEBAUDIO_BLOCK_SIZE = 128;    // reference default (ola-processor.js:3)
+
+// Host globals of an AudioWorkletGlobalScope; Node has neither, so provide the minimal equivalents.
+const Base = (typeof AudioWorkletProcessor !== "undefined") ? AudioWorkletProcessor : class AudioWorkletProcessor {
+    constructor(options) { this.port = null; }
+};
+const registry = new Map();
+const register = (typeof registerProcessor !== "undefined") ? registerProcessor : function registerProcessor(name, cls) {
+    if (registry.has(name)) throw new Error(`processor '${name}' is already registered`);
+    registry.set(name, cls);
+};
+
+class PhaseVocoderProcessor extends Base {
+    static get parameterDescriptors() {                       // phase-vocoder.js:17-22
+        return [{ name: "pitchFactor", defaultValue: 1.0 }];
+    }
+
+    constructor(options) {
+        super(options);
+        options = options || {};
+        const po = options.processorOptions || {};
+        this.nbInputs = options.numberOfInputs;                // required, as in ola-processor.js:10-11
+        this.nbOutputs = options.numberOfOutputs;
+        this.blockSize = po.fftSize !== undefined ? po.fftSize : BUFFERED_BLOCK_SIZE;
+        this.hopSize = po.hopSize !== undefined ? po.hopSize : WEBAUDIO_BLOCK_SIZE;
+        this.fftSize = this.blockSize;
+        this.nbOverlaps = this.blockSize / this.hopSize;       // ola-processor.js:17
+        this.deviceId = po.deviceId | 0;
+        this._handles = [];
+        this._channels = [];
+        this._capacity = [];
+        for (let i = 0; i < (this.nbInputs | 0); i++) {
+            // "default to 1 channel per input until we know more" (ola-processor.js:24-27); capacity 2 avoids a
+            // re-create for the common mono->stereo switch.  Throws Error('FFT size must be a power of two and
+            // bigger than 1') for bad sizes, as `new FFT(n)` does (bundle:6-7).
+            this._capacity.push(2);
+            this._handles.push(native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: 2, maxHops: 1, deviceId: this.deviceId }));
+            this._channels.push(1);
+        }
+    }
+
+    get timeCursor() { return this._handles.length ? native.timeCursor(this._handles[0]) : 0; }   // phase-vocoder.js:31
+
+    /** Handles dynamic reallocation of input/output channels (ola-processor.js:38-52): state of that input restarts from zero. */
+    reallocateChannelsIfNeeded(inputs, outputs) {
+        for (let i = 0; i < this._handles.length; i++) {
+            const nb = inputs[i].length;
+            if (nb !== this._channels[i]) {
+                if (nb > this._capacity[i]) {
+                    const t = native.timeCursor(this._handles[i]);
+                    native.destroy(this._handles[i]);
+                    this._capacity[i] = Math.max(nb, 2 * this._capacity[i]);
+                    this._handles[i] = native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: this._capacity[i], maxHops: 1, deviceId: this.deviceId });
+                    native.timeCursor(this._handles[i], t);     // timeCursor survives a reallocation (phase-vocoder.js:31,71)
+                } else {
+                    native.reset(this._handles[i], 0, this._capacity[i]);
+                }
+                this._channels[i] = nb;
+            }
+        }
+    }
+
+    process(inputs, outputs, parameters) {
+        this.reallocateChannelsIfNeeded(inputs, outputs);
+        const pf = parameters.pitchFactor;
+        const pitchFactor = pf[pf.length - 1];                  // "no automation, take last value" (phase-vocoder.js:47)
+        // paused: the newest hop of EVERY input is treated as zeros (ola-processor.js:93-100)
+        const paused = inputs.length > 0 && inputs[0].length > 0 && inputs[0][0].length === 0;
+        for (let i = 0; i < this._handles.length; i++) {
+            const ins = paused ? inputs[i].map(() => PhaseVocoderProcessor._EMPTY) : inputs[i];
+            native.process(this._handles[i], ins, outputs[i] || [], pitchFactor);
+        }
+        return true;                                            // ola-processor.js:170
+    }
+
+    /** Throughput form (no reference counterpart): nhops process() calls of input 0 in one launch, planar [ch][nhops*hop]. */
+    processBatch(input, output, nch, nhops, pitchPerHop) {
+        if (nch !== this._channels[0] || nhops > (this._maxHops | 0)) {
+            const t = native.timeCursor(this._handles[0]);
+            const keep = nch === this._channels[0];
+            if (!keep || nhops > (this._maxHops | 0)) {
+                // a larger staging area needs a new handle; state only survives when the channel count is unchanged
+                if (keep) throw new Error("processBatch: nhops exceeds maxHops; construct with processorOptions.maxHops");
+                native.destroy(this._handles[0]);
+                this._maxHops = Math.max(nhops, this._maxHops | 0);
+                this._capacity[0] = Math.max(nch, this._capacity[0]);
+                this._handles[0] = native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: this._capacity[0], maxHops: this._maxHops, deviceId: this.deviceId });
+                native.timeCursor(this._handles[0], t);
+                this._channels[0] = nch;
+            }
+        }
+        return native.processBatch(this._handles[0], input, output, nch, nhops, pitchPerHop, 0, 1);
+    }
+
+    info() { return this._handles.length ? native.info(this._handles[0]) : null; }
+
+    close() {
+        for (const h of this._handles) native.destroy(h);
+        this._handles = [];
+    }
+}
+PhaseVocoderProcessor._EMPTY = new Float32Array(0);
+
+register("phase-vocoder-processor", PhaseVocoderProcessor);      // phase-vocoder.js:176
+
+module.exports = { PhaseVocoderProcessor, registerProcessor: register, getProcessor: (name) => registry.get(name), native };

@@ -1,0 +1,93 @@
+"""The Node.js host + N-API addon (the drop-in surface of src/phase-vocoder.js).
+
+CPU part (`not gpu`): the addon loads, exports every entry point, the processor class has the reference's
+surface and error behaviour.  GPU part: process() driven hop by hop from Node against the golden vectors.
+"""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import signals as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE = shutil.which("node")
+ADDON = os.path.join(ROOT, "phaze_amd", "node", "phaze_napi.node")
+pytestmark = pytest.mark.skipif(NODE is None, reason="node not installed")
+
+
+def _build():
+    if not os.path.exists(ADDON):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "phaze_amd", "csrc")], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "phaze_amd", "node")], stdout=subprocess.DEVNULL)
+
+
+def _node(script):
+    return subprocess.run([NODE, "-e", script], cwd=ROOT, capture_output=True, text=True, timeout=120)
+
+
+def test_addon_loads_and_exports_surface():
+    _build()
+    r = _node("""
+      const m = require('./phaze_amd/node/phase-vocoder.js');
+      const P = m.PhaseVocoderProcessor;
+      console.log(JSON.stringify({
+        native: Object.keys(m.native).sort(),
+        desc: P.parameterDescriptors,
+        registered: m.getProcessor('phase-vocoder-processor') === P,
+        hasProcess: typeof P.prototype.process === 'function',
+      }));""")
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["native"] == sorted(["create", "destroy", "process", "processBatch", "reset", "timeCursor", "info"])
+    assert d["desc"] == [{"name": "pitchFactor", "defaultValue": 1}]          # phase-vocoder.js:17-22
+    assert d["registered"] and d["hasProcess"]
+
+
+def test_bad_fft_size_throws_reference_message():
+    _build()
+    r = _node("""
+      const m = require('./phaze_amd/node/phase-vocoder.js');
+      const out = [];
+      for (const n of [0, 1, 3, 1000]) {
+        try { new m.PhaseVocoderProcessor({numberOfInputs: 1, numberOfOutputs: 1, processorOptions: {fftSize: n, hopSize: 1}}); out.push('no throw'); }
+        catch (e) { out.push(e.message); }
+      }
+      console.log(JSON.stringify(out));""")
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == ["FFT size must be a power of two and bigger than 1"] * 4     # bundle:6-7
+
+
+MAN = S.load_manifest()
+CASES = {c["name"]: c for c in MAN["cases"]}
+NODE_CASES = ["c2_1024_256_mono_pf1.5_tonal", "c3_2048_512_stereo_pf0.8_noise", "native_2048_128_mono_pf1.5_noise",
+              "pause_1024_256_stereo_noise", "chanchange_1024_256_noise", "arate_1024_256_mono_tonal", "weird_pf_1024_256_mono_noise",
+              "c5s_8192_2048_mono_sweep16_tonal"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NODE_CASES)
+def test_node_process_matches_reference_golden(name, tmp_path):
+    _build()
+    case = CASES[name]
+    h, T = case["hop"], case["store_hops"]
+    nmax = S.case_max_channels(case)
+    sig = np.stack([S.make_signal(case["signal"], ch, case["nhops"] * h)[:T * h] for ch in range(nmax)])
+    pitch = S.pitch_schedule(case["pitch"], case["nhops"])[:T]
+    sig.astype("<f4").tofile(tmp_path / "in.f32")
+    pitch.astype("<f4").tofile(tmp_path / "pitch.f32")
+    spec = {"fft": case["fft"], "hop": h, "nhops": T, "nch": case["nch"], "max_ch": nmax, "events": case.get("events", []),
+            "arate": bool(case.get("arate")), "use_defaults": name.startswith("native"),
+            "in_file": str(tmp_path / "in.f32"), "pitch_file": str(tmp_path / "pitch.f32"), "out_file": str(tmp_path / "out.f32")}
+    (tmp_path / "spec.json").write_text(json.dumps(spec))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node", "run_case.js"), str(tmp_path / "spec.json")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = np.fromfile(tmp_path / "out.f32", dtype="<f4").reshape(nmax, T * h)
+    gold = S.load_golden_out(case)
+    err = S.rms(got[:case["store_ch"]].astype(np.float64) - gold)
+    assert np.all(np.isfinite(got))
+    assert err < 2e-6, f"{name}: rms {err:.3e}"
+    print(name, json.loads(r.stdout.strip().splitlines()[-1])["us_per_call"], "us/call")
