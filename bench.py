@@ -146,15 +146,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps            # HIP events on the launch stream: avg launch duration
-    if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+    from phaze_amd import shard
+    elapsed, kernel_ms = shard.reduce_max([elapsed, kernel_ms], dist, dev)      # MAX over ranks
 
     info = pv.info()
     frames_per_step_rank = nch * T
-    total_frames = frames_per_step_rank * args.steps * world
-    value = total_frames / elapsed
+    value = shard.aggregate_rate(frames_per_step_rank * args.steps, world, elapsed)
     alg_bytes_per_launch = frames_per_step_rank * 2 * hop * 4          # 2*hop*4 B per channel-frame
     achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9          # GB/s, per GPU
     traffic = None
