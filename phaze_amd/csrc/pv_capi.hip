@@ -39,6 +39,7 @@ struct pv_handle {
     double *d_dbgX; float *d_dbgMag; int *d_dbgFlags; float *d_dbgY;
     int64_t time_cursor;
     int active_nch;
+    bool use_wave;                               // N = 1024: wave-per-frame kernel (pv_wave_kernel.hip)
     char devname[64];
     char err[256];
 };
@@ -95,7 +96,7 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     if (dbg_ch >= 0) { p.dbg_X = h->d_dbgX; p.dbg_mag = h->d_dbgMag; p.dbg_flags = h->d_dbgFlags; p.dbg_Y = h->d_dbgY; p.dbg_ch = dbg_ch; p.dbg_frame = 0; }
     const int nchunks = (nhops + p.frames_per_chunk - 1) / p.frames_per_chunk;
     h->last_frames_per_chunk = p.frames_per_chunk;
-    hipError_t e = pv_launch_chain(h->log2n, p, nch, nchunks, h->stream);
+    hipError_t e = h->use_wave ? pv_launch_wave(p, nch, nchunks, h->stream) : pv_launch_chain(h->log2n, p, nch, nchunks, h->stream);
     if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
     if (commit) {
         // channels outside [0, nch) keep their state: copy them across the ping-pong flip
@@ -159,6 +160,10 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     h->max_channels = maxch; h->max_hops = maxhops; h->device = cfg->device_id;
     h->frames_per_chunk_cfg = cfg->frames_per_chunk;
     h->active_nch = -1;
+    {
+        const char *g = getenv("PHAZE_GENERIC_KERNEL");      // A/B switch for tests and profiling
+        h->use_wave = pv_wave_supported(log2n, hop) && !(g && g[0] == '1');
+    }
 #define CHK(call)                                                          \
     do {                                                                   \
         hipError_t e2_ = (call);                                           \
@@ -245,8 +250,8 @@ int pv_get_info(const pv_handle *h, pv_info *out)
     memset(out, 0, sizeof *out);
     out->fft_size = h->N; out->hop_size = h->hop; out->overlaps = h->R;
     out->max_channels = h->max_channels; out->max_hops = h->max_hops;
-    out->threads_per_workgroup = pv_kernel_threads(h->log2n);
-    out->lds_bytes_per_workgroup = (int32_t)pv_kernel_lds_bytes(h->log2n, h->hop);
+    out->threads_per_workgroup = h->use_wave ? 64 : pv_kernel_threads(h->log2n);
+    out->lds_bytes_per_workgroup = (int32_t)(h->use_wave ? pv_wave_lds_bytes() : pv_kernel_lds_bytes(h->log2n, h->hop));
     out->frames_per_chunk = h->last_frames_per_chunk;
     out->compute_units = h->cus; out->device_id = h->device;
     snprintf(out->device_name, sizeof out->device_name, "%s", h->devname);

@@ -1,0 +1,464 @@
+// pv_wave_kernel.hip -- wave-per-frame kernel for N = 1024 (BASELINE configs[0..1], the bench workload).
+//
+// One 64-lane wavefront owns one channel and a chain of consecutive frames.  Everything that can stay in
+// registers does; LDS is used only for the two register<->lane transposes of each FFT, the magnitude /
+// peak-mask exchange and the shifted spectrum Y:
+//
+//   lane l, register r  <->  packed complex element z[l + 64 r]   (z[n] = xw[2n] + j xw[2n+1], N/2 = 512 = 8*8*8)
+//
+//   * raw input samples slide in registers (hop = 128*S samples = S register rows): 2*S new loads per frame
+//   * forward 512-pt complex FFT in fp64: three radix-8 butterflies per lane, two conflict-free LDS transposes
+//     (layouts from tools/lds_layout_check.py), per-lane twiddles held in registers for the whole chain
+//   * split pass with the partner bin fetched by ds_bpermute (lane 64-l), |X|^2 -> f32 in registers
+//   * peak flags on 8 consecutive bins per lane -> byte masks; scatter with the source bin taken from registers
+//   * c2r pre-pass + 512-pt inverse FFT in fp32 (same structure), Hann, overlap-add accumulator in registers,
+//     finished hop stored coalesced
+//
+// Semantics are those of pv_chain_kernel (same reference citations); tests run both against the oracle.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pv_kernels.h"
+
+namespace {
+
+template <typename T> struct v2t;
+template <> struct v2t<float> { using type = float2; };
+template <> struct v2t<double> { using type = double2; };
+
+template <typename T2> __device__ __forceinline__ T2 cadd(T2 a, T2 b) { return T2{a.x + b.x, a.y + b.y}; }
+template <typename T2> __device__ __forceinline__ T2 csub(T2 a, T2 b) { return T2{a.x - b.x, a.y - b.y}; }
+template <typename T2> __device__ __forceinline__ T2 cmul(T2 a, T2 b) { return T2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+template <typename T2> __device__ __forceinline__ T2 cconj(T2 a) { return T2{a.x, -a.y}; }
+// multiply by -j (forward) or +j (inverse)
+template <bool INV, typename T2> __device__ __forceinline__ T2 rot90(T2 a) { return INV ? T2{-a.y, a.x} : T2{a.y, -a.x}; }
+
+// In-register 8-point DFT, natural order in and out.  INV selects exp(+2 pi j nk/8).
+template <typename T, bool INV>
+__device__ __forceinline__ void radix8(typename v2t<T>::type (&a)[8])
+{
+    using T2 = typename v2t<T>::type;
+    const T h = (T)0.70710678118654752440;
+    const T2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
+    const T2 b1 = cadd(a[1], a[5]), b5 = csub(a[1], a[5]);
+    const T2 b2 = cadd(a[2], a[6]), b6 = csub(a[2], a[6]);
+    const T2 b3 = cadd(a[3], a[7]), b7 = csub(a[3], a[7]);
+    // odd half: c_n = b_{n+4} * W8^n
+    T2 c1, c3;
+    if (!INV) { c1 = T2{(b5.x + b5.y) * h, (b5.y - b5.x) * h}; c3 = T2{(b7.y - b7.x) * h, -(b7.x + b7.y) * h}; }
+    else      { c1 = T2{(b5.x - b5.y) * h, (b5.x + b5.y) * h}; c3 = T2{-(b7.x + b7.y) * h, (b7.x - b7.y) * h}; }
+    const T2 c0 = b4, c2 = rot90<INV>(b6);
+    // even outputs: 4-pt DFT of b0..b3
+    {
+        const T2 e0 = cadd(b0, b2), e1 = csub(b0, b2), e2 = cadd(b1, b3), e3 = rot90<INV>(csub(b1, b3));
+        a[0] = cadd(e0, e2); a[4] = csub(e0, e2); a[2] = cadd(e1, e3); a[6] = csub(e1, e3);
+    }
+    // odd outputs: 4-pt DFT of c0..c3
+    {
+        const T2 e0 = cadd(c0, c2), e1 = csub(c0, c2), e2 = cadd(c1, c3), e3 = rot90<INV>(csub(c1, c3));
+        a[1] = cadd(e0, e2); a[5] = csub(e0, e2); a[3] = cadd(e1, e3); a[7] = csub(e1, e3);
+    }
+}
+
+constexpr int TP = 72;   // padded row of the transpose scratch (elements); conflict-free with the skew below
+
+// 512-point complex FFT across one wave: in/out layout lane l, reg r <-> element l + 64 r.
+// The per-lane twiddles are kept once, in fp64; the fp32 inverse rounds (and conjugates) them on the fly.
+template <typename T, bool INV>
+__device__ __forceinline__ typename v2t<T>::type twv(double2 w) { return typename v2t<T>::type{(T)w.x, INV ? (T)(-w.y) : (T)w.y}; }
+
+template <typename T, bool INV>
+__device__ __forceinline__ void fft512_wave(typename v2t<T>::type (&a)[8], typename v2t<T>::type *S, const double2 (&tw1)[8],
+                                            const double2 (&tw2)[8], int l)
+{
+    using T2 = typename v2t<T>::type;
+    const int lh = l >> 3, ll = l & 7;
+    // pass 1: DFT over n2 (register index); twiddle W_512^{l*k0}
+    radix8<T, INV>(a);
+#pragma unroll
+    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twv<T, INV>(tw1[k]));
+    // transpose 1: [reg k0][lane (n1,n0)] -> [reg n1][lane (k0,n0)]
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k * TP + l] = a[k];
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 8; n++) a[n] = S[lh * TP + 8 * n + ll];
+    __syncthreads();
+    // pass 2: DFT over n1; twiddle W_64^{n0*k1}
+    radix8<T, INV>(a);
+#pragma unroll
+    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twv<T, INV>(tw2[k]));
+    // transpose 2: [reg k1][lane (k0,n0)] -> [reg n0][lane (k1,k0)], skewed rows
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k * TP + lh * 8 + ((ll + lh) & 7)] = a[k];
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 8; n++) a[n] = S[lh * TP + ll * 8 + ((n + ll) & 7)];
+    __syncthreads();
+    // pass 3: DFT over n0 -> k2; lane l now holds X[l + 64 k2]
+    radix8<T, INV>(a);
+}
+
+struct WaveSrc {
+    const float *in;
+    const float *hist;
+    int hist_len;
+    __device__ __forceinline__ float at(long s) const { return s < 0 ? hist[s + hist_len] : in[s]; }
+};
+
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+
+// S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
+template <int S_ROWS>
+__global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParams p)
+{
+    constexpr int N = 1024, M = 512, H = 513, LOG2N = 10;
+    constexpr int HOP = 128 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;    // LROWS rows of carried accumulator
+    constexpr int BIG = 1 << 30;
+    const int l = threadIdx.x;
+    const int ch = blockIdx.y, chunk = blockIdx.x;
+
+    // ---- LDS carve (all dynamic, 16-byte aligned) ----
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2 *S64 = reinterpret_cast<double2 *>(smem);                    // 8*72*16 = 9216 B: fp64 transposes
+    float2 *S32 = reinterpret_cast<float2 *>(smem);                      // fp32 transposes (first 4608 B)
+    float2 *Y = reinterpret_cast<float2 *>(smem);                        // shifted spectrum Y[0..512] (4104 B), between the FFTs
+    float2 *RES = reinterpret_cast<float2 *>(smem + 4112) - M;           // residue float2 positions [512, 1024) -> smem[4112, 8208)
+    float *MAG = reinterpret_cast<float *>(smem + 9216);                 // MAG[4 + k], k in [-4, 524)
+    unsigned char *MASKB = smem + 9216 + 528 * 4;                        // 64 bytes = 8 x u64 peak masks (bins 0..511) + 1 zero word
+    unsigned long long *MASKW = reinterpret_cast<unsigned long long *>(MASKB);
+
+    const int first_out = chunk * p.frames_per_chunk;
+    int last_out = first_out + p.frames_per_chunk;
+    if (last_out > p.nhops) last_out = p.nhops;
+    int first_frame = first_out - (R - 1);
+    const bool from_state = (first_frame <= 0);
+    if (from_state) first_frame = 0;
+
+    const long cbase = (long)ch * p.ch_stride;
+    const WaveSrc src{p.in + cbase, p.hist_in + (long)ch * (N - HOP), N - HOP};
+    float *outp = p.out + cbase;
+    const float *pitch_row = p.pitch + (p.pitch_stride ? (long)(ch / p.ch_per_stream) * p.pitch_stride : 0);
+    const float invR = 1.0f / (float)R;
+
+    // ---- per-lane constants, loaded once per chain ----
+    double2 tw1[8], tw2[8];               // fp64: W_512^{l k}, W_64^{(l&7) k}
+    const double2 wl = p.tw64[l];          // split pass: W_1024^{l + 64 r} = wl * W_16^r (W_16^r is wave-uniform)
+    const float2 wlf = cconj(p.tw32[l]);
+    float2 hw[8];                          // Hann at samples 2(l+64r), 2(l+64r)+1
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        tw1[k] = p.tw64[(2 * l * k) & (N - 1)];
+        tw2[k] = p.tw64[(16 * (l & 7) * k) & (N - 1)];
+        hw[k] = float2{p.hann[2 * (l + 64 * k)], p.hann[2 * (l + 64 * k) + 1]};
+    }
+
+    // ---- carried overlap-add accumulator in registers: row r <-> samples 2l + 128 r (+1) ----
+    float2 acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) acc[r] = float2{0.f, 0.f};
+    if (from_state) {
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) {
+            const float *a = p.acc_in + (long)ch * (N - HOP) + 2 * l + 128 * r;
+            acc[r] = float2{a[0], a[1]};
+        }
+    }
+
+    // ---- raw input window in registers ----
+    float2 raw[8];
+    {
+        const long s0 = (long)(first_frame + 1) * HOP - N;
+#pragma unroll
+        for (int r = 0; r < 8; r++) raw[r] = float2{src.at(s0 + 2 * l + 128 * r), src.at(s0 + 2 * l + 128 * r + 1)};
+    }
+    if (l < 9) MASKW[l] = 0ull;           // word 8 (bin 512) stays zero
+
+    for (int m = first_frame; m < last_out; ++m) {
+        const double pf = (double)pitch_row[m];
+        const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
+        const bool dbg = (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
+
+        // prefetch the rows the NEXT frame slides in
+        float2 nxt_raw[S_ROWS];
+        {
+            const long s1 = (long)(m + 2) * HOP - N;
+            const bool more = (m + 1 < last_out);
+#pragma unroll
+            for (int r = 0; r < S_ROWS; r++) {
+                const long s = s1 + 2 * l + 128 * (8 - S_ROWS + r);
+                nxt_raw[r] = more ? float2{src.at(s), src.at(s + 1)} : float2{0.f, 0.f};
+            }
+        }
+
+        // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded in here (exact) ----
+        double2 z[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) z[r] = double2{0.5 * (double)(raw[r].x * hw[r].x), 0.5 * (double)(raw[r].y * hw[r].y)};
+
+        fft512_wave<double, false>(z, S64, tw1, tw2, l);
+
+        // ---- split pass: X[k] = E - j W^k O with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved) ----
+        double2 X[8];
+        double x512 = 0.0;
+        {
+            const int pl = (64 - l) & 63;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                double2 zm{shfl_d(z[7 - r].x, pl), shfl_d(z[7 - r].y, pl)};
+                if (l == 0) zm = (r == 0) ? z[0] : z[8 - r > 7 ? 7 : 8 - r];
+                const double2 E{z[r].x + zm.x, z[r].y - zm.y};
+                const double2 O{z[r].x - zm.x, z[r].y + zm.y};
+                const double2 WO = cmul(wl, cmul(p.tw64[64 * r], O));
+                X[r] = double2{E.x + WO.y, E.y - WO.x};
+            }
+            if (l == 0) {
+                // Z[0] is pre-halved: X[0] = 2(zr + zi), X[512] = 2(zr - zi), both real (bundle:447-508 keep Im = 0)
+                X[0] = double2{2.0 * (z[0].x + z[0].y), 0.0};
+                x512 = 2.0 * (z[0].x - z[0].y);
+            }
+        }
+        // ---- |X|^2 -> f32 (pv:82-92), exchanged through LDS for the neighbour tests ----
+#pragma unroll
+        for (int r = 0; r < 8; r++) MAG[4 + l + 64 * r] = (float)(X[r].x * X[r].x + X[r].y * X[r].y);
+        if (l == 0) MAG[4 + 512] = (float)(x512 * x512);
+        __syncthreads();
+        // ---- peak flags (pv:95-116) for bins 8l..8l+7 -> one mask byte per lane ----
+        {
+            float mg[12];
+            const float2 q0 = *reinterpret_cast<const float2 *>(&MAG[4 + 8 * l - 2]);
+            const float4 q1 = *reinterpret_cast<const float4 *>(&MAG[4 + 8 * l]);
+            const float4 q2 = *reinterpret_cast<const float4 *>(&MAG[4 + 8 * l + 4]);
+            const float2 q3 = *reinterpret_cast<const float2 *>(&MAG[4 + 8 * l + 8]);
+            mg[0] = q0.x; mg[1] = q0.y; mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w;
+            mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w; mg[10] = q3.x; mg[11] = q3.y;
+            unsigned bits = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int k = 8 * l + i;
+                const float c = mg[i + 2];
+                const bool f = (k >= 2) && (k < H - 2) && (mg[i + 1] < c) && (mg[i] < c) && (mg[i + 3] < c) && (mg[i + 4] < c);
+                bits |= f ? (1u << i) : 0u;
+            }
+            MASKB[l] = (unsigned char)bits;
+        }
+        __syncthreads();
+        // ---- per-word nearest peaks (uniform) ----
+        unsigned long long mk[8];
+        int wprev[8], wnext[8];
+        {
+            int run = -1;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                {
+                    const unsigned long long v = MASKW[w];
+                    mk[w] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+                }
+                wprev[w] = run;
+                if (mk[w]) run = w * 64 + 63 - __clzll(mk[w]);
+            }
+            const int last_peak_tmp = run;
+            run = BIG;
+#pragma unroll
+            for (int w = 7; w >= 0; w--) {
+                wnext[w] = run;
+                if (mk[w]) run = w * 64 + __ffsll(mk[w]) - 1;
+            }
+            (void)last_peak_tmp;
+        }
+        int last_peak = -1;
+#pragma unroll
+        for (int w = 0; w < 8; w++) if (mk[w]) last_peak = w * 64 + 63 - __clzll(mk[w]);
+
+        int upper_end = H;
+        if (last_peak >= 0) {
+            const double psh = floor((double)last_peak * pf + 0.5);      // Math.round (pv:125); x+0.5 is exact here
+            if (!(psh > (double)H) && psh >= -(double)(2 * N)) {
+                const int d = (int)psh - last_peak;
+                if (d < 0) { upper_end = H - d; if (upper_end > N) upper_end = N; }
+            }
+        }
+        if (dbg) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = l + 64 * r;
+                p.dbg_X[2 * k] = X[r].x; p.dbg_X[2 * k + 1] = X[r].y;
+                p.dbg_mag[k] = MAG[4 + k];
+                p.dbg_flags[k] = (int)((mk[r] >> l) & 1ull);
+            }
+            if (l == 0) { p.dbg_X[2 * 512] = x512; p.dbg_X[2 * 512 + 1] = 0.0; p.dbg_mag[512] = MAG[4 + 512]; p.dbg_flags[512] = 0; }
+        }
+        // ---- zero Y (pv:121); the transposes of the forward FFT are done with the scratch ----
+#pragma unroll
+        for (int r = 0; r < 8; r++) Y[l + 64 * r] = float2{0.f, 0.f};
+        if (l == 0) Y[512] = float2{0.f, 0.f};
+        // ---- residue above Nyquist only when the last region reads it ----
+        const bool need_res = upper_end > H;
+        __syncthreads();
+        if (need_res) {
+            // re-run fft.js's stage structure on [N/2, N) in fp32 (bundle:306-442) -- rare path, LDS/global based
+            const long s0 = (long)(m + 1) * HOP - N;
+            // base stage (radix-4, LOG2N even): blocks t in [N/8, N/4)
+            for (int t = N / 8 + l; t < N / 4; t += 64) {
+                unsigned rv = __brev((unsigned)t) >> (32 - 8);
+                const int off = (int)(((rv & 0x55555555u) << 1) | ((rv >> 1) & 0x55555555u));
+                const float a = src.at(s0 + off) * p.hann[off];
+                const float b = src.at(s0 + off + N / 4) * p.hann[off + N / 4];
+                const float c = src.at(s0 + off + N / 2) * p.hann[off + N / 2];
+                const float d = src.at(s0 + off + 3 * N / 4) * p.hann[off + 3 * N / 4];
+                const float t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+                RES[4 * t] = float2{t0 + t2, 0.f};
+                RES[4 * t + 1] = float2{t1, -t3};
+                RES[4 * t + 2] = float2{t0 - t2, 0.f};
+                RES[4 * t + 3] = float2{t1, t3};
+            }
+            __syncthreads();
+            for (int log2m = 4; log2m <= LOG2N - 2; log2m += 2) {
+                const int Mb = 1 << log2m, q = Mb >> 2, hq = q >> 1;
+                const int nblocks = (N / 2) >> log2m;
+                const int tws = LOG2N - log2m;
+                const int total = nblocks * (hq + 1);
+                for (int it = l; it < total; it += 64) {
+                    int blk, i;
+                    if (it < nblocks * hq) { blk = it / hq; i = it - blk * hq; } else { blk = it - nblocks * hq; i = hq; }
+                    const int o = N / 2 + (blk << log2m);
+                    const float2 A = RES[o + i];
+                    const float2 Bv = cmul(RES[o + q + i], p.tw32[i << tws]);
+                    const float2 C = cmul(RES[o + 2 * q + i], p.tw32[(2 * i) << tws]);
+                    const float2 D = cmul(RES[o + 3 * q + i], p.tw32[(3 * i) << tws]);
+                    const float2 T0 = cadd(A, C), T1 = csub(A, C), T2 = cadd(Bv, D), T3 = csub(Bv, D);
+                    RES[o + i] = cadd(T0, T2);
+                    RES[o + q + i] = float2{T1.x + T3.y, T1.y - T3.x};
+                    if (i == 0) {
+                        RES[o + 2 * q] = csub(T0, T2);
+                    } else if (i != hq) {
+                        RES[o + q - i] = float2{T1.x - T3.y, -(T1.y + T3.x)};
+                        RES[o + 2 * q - i] = float2{T0.x - T2.x, -(T0.y - T2.y)};
+                    }
+                }
+                __syncthreads();
+            }
+            if (dbg) for (int k = H + l; k < N; k += 64) { p.dbg_X[2 * k] = RES[k].x; p.dbg_X[2 * k + 1] = RES[k].y; }
+        }
+        // ---- shiftPeaks (pv:119-173): per-source-bin owner rule, sources straight from registers ----
+        {
+            auto emit = [&](int b, int prv, int nxt, float2 v) {
+                int owner;
+                if (prv < 0) owner = nxt;
+                else if (nxt == BIG) owner = prv;
+                else owner = (b < prv + ((nxt - prv + 1) >> 1)) ? prv : nxt;
+                if (owner == BIG || owner < 0) return;
+                const double psh = floor((double)owner * pf + 0.5);
+                if (!(psh <= (double)H) || psh < -(double)(2 * N)) return;
+                const int delta = (int)psh - owner;
+                const int tgt = b + delta;
+                if (tgt < 0 || tgt >= H) return;
+                const int ridx = ((delta & (N - 1)) * tmod) & (N - 1);
+                float2 y;
+                if (R == 4) {
+                    const int qd = ridx >> (LOG2N - 2);                    // rotation = j^qd exactly
+                    y = (qd == 0) ? v : (qd == 1) ? float2{-v.y, v.x} : (qd == 2) ? float2{-v.x, -v.y} : float2{v.y, -v.x};
+                } else {
+                    y = cmul(v, cconj(p.tw32[ridx]));
+                }
+                atomicAdd(&Y[tgt].x, y.x);
+                atomicAdd(&Y[tgt].y, y.y);
+            };
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const unsigned long long m_r = mk[r];
+                const unsigned long long below = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
+                const unsigned long long lo = m_r & below, hi = m_r & ~below;
+                const int prv = lo ? r * 64 + 63 - __clzll(lo) : wprev[r];
+                const int nxt = hi ? r * 64 + __ffsll(hi) - 1 : wnext[r];
+                emit(l + 64 * r, prv, nxt, float2{(float)X[r].x, (float)X[r].y});
+            }
+            if (l == 0) emit(512, last_peak, BIG, float2{(float)x512, 0.f});
+            if (need_res)
+                for (int b = H + l; b < upper_end; b += 64) emit(b, last_peak, BIG, RES[b]);
+        }
+        __syncthreads();
+        if (dbg) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) { const int k = l + 64 * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
+            if (l == 0) { p.dbg_Y[1024] = Y[512].x; p.dbg_Y[1025] = Y[512].y; }
+        }
+        // ---- c2r pre-pass (bundle:69-76,102-114 folded): Z[k] = ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)) / N ----
+        float2 zi[8];
+        {
+            const float sc = 1.0f / (float)N;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = l + 64 * r;
+                float2 yk = Y[k], ym = Y[M - k];
+                if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
+                const float2 E{yk.x + ym.x, yk.y - ym.y};
+                const float2 O{yk.x - ym.x, yk.y + ym.y};
+                const float2 c = cmul(wlf, cmul(cconj(p.tw32[64 * r]), O));
+                zi[r] = float2{(E.x - c.y) * sc, (E.y + c.x) * sc};
+            }
+        }
+        __syncthreads();
+        fft512_wave<float, true>(zi, S32, tw1, tw2, l);
+        // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
+        {
+            const bool emit_out = (m >= first_out);
+            float2 fr[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) fr[r] = float2{zi[r].x * hw[r].x * invR, zi[r].y * hw[r].y * invR};
+#pragma unroll
+            for (int r = 0; r < S_ROWS; r++) {
+                const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
+                if (emit_out) {
+                    float *dst = outp + (long)m * HOP + 2 * l + 128 * r;
+                    dst[0] = o.x; dst[1] = o.y;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < LROWS; r++) {
+                const int s = r + S_ROWS;
+                acc[r] = (s < LROWS) ? float2{acc[s].x + fr[s].x, acc[s].y + fr[s].y} : fr[s];
+            }
+        }
+        // ---- slide the raw window ----
+#pragma unroll
+        for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
+#pragma unroll
+        for (int r = 0; r < S_ROWS; r++) raw[8 - S_ROWS + r] = nxt_raw[r];
+    }
+
+    if (chunk == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) {
+            float *a = p.acc_out + (long)ch * (N - HOP) + 2 * l + 128 * r;
+            a[0] = acc[r].x; a[1] = acc[r].y;
+            float *hs = p.hist_out + (long)ch * (N - HOP) + 2 * l + 128 * r;
+            const long s = (long)p.nhops * HOP - (N - HOP) + 2 * l + 128 * r;
+            hs[0] = src.at(s); hs[1] = src.at(s + 1);
+        }
+    }
+}
+
+template <int S_ROWS>
+hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+{
+    hipLaunchKernelGGL(pv_wave_kernel_1024<S_ROWS>, dim3(nchunks, nch, 1), dim3(64, 1, 1), pv_wave_lds_bytes(), st, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t pv_wave_lds_bytes() { return 9216 + 528 * 4 + 80; }
+
+bool pv_wave_supported(int log2n, int hop) { return log2n == 10 && (hop == 128 || hop == 256 || hop == 512 || hop == 1024); }
+
+hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+{
+    switch (p.hop) {
+    case 128: return launch_wave<1>(p, nch, nchunks, st);
+    case 256: return launch_wave<2>(p, nch, nchunks, st);
+    case 512: return launch_wave<4>(p, nch, nchunks, st);
+    case 1024: return launch_wave<8>(p, nch, nchunks, st);
+    default: return hipErrorInvalidValue;
+    }
+}
