@@ -342,6 +342,9 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
         }
         // ---- shiftPeaks (pv:119-173): per-source-bin owner rule, sources straight from registers ----
         {
+            // For f >= 1, delta_i = round(p_i f) - p_i is non-decreasing in i, so the shifted regions stay disjoint and a plain
+            // store replaces the LDS float atomic (which serialises: it was 2/3 of all LDS cycles).
+            const bool disjoint = (pf >= 1.0);
             auto emit = [&](int b, int prv, int nxt, float2 v) {
                 int owner;
                 if (prv < 0) owner = nxt;
@@ -361,8 +364,12 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
                 } else {
                     y = cmul(v, cconj(p.tw32[ridx]));
                 }
-                atomicAdd(&Y[tgt].x, y.x);
-                atomicAdd(&Y[tgt].y, y.y);
+                if (disjoint) {
+                    Y[tgt] = y;                                            // f >= 1: shifted regions never overlap
+                } else {
+                    atomicAdd(&Y[tgt].x, y.x);                             // f < 1: regions compress, += collisions (pv:169-170)
+                    atomicAdd(&Y[tgt].y, y.y);
+                }
             };
 #pragma unroll
             for (int r = 0; r < 8; r++) {
