@@ -60,6 +60,27 @@ __device__ __forceinline__ void radix8(typename v2t<T>::type (&a)[8])
     }
 }
 
+// o * exp(-+2 pi j r / 16): the wave-uniform part of the split-pass twiddle (INV = conjugate)
+template <typename T, bool INV>
+__device__ __forceinline__ typename v2t<T>::type mul_w16(typename v2t<T>::type o, int r)
+{
+    using T2 = typename v2t<T>::type;
+    const T c = (T)0.92387953251128675613, s = (T)0.38268343236508977173, h = (T)0.70710678118654752440;
+    T2 w;
+    switch (r) {               // r is a compile-time constant at every call site (unrolled loops)
+    case 0: return o;
+    case 4: return rot90<INV>(o);
+    case 1: w = T2{c, -s}; break;
+    case 2: w = T2{h, -h}; break;
+    case 3: w = T2{s, -c}; break;
+    case 5: w = T2{-s, -c}; break;
+    case 6: w = T2{-h, -h}; break;
+    default: w = T2{-c, -s}; break;
+    }
+    if (INV) w.y = -w.y;
+    return cmul(o, w);
+}
+
 constexpr int TP = 72;   // padded row of the transpose scratch (elements); conflict-free with the skew below
 
 // 512-point complex FFT across one wave: in/out layout lane l, reg r <-> element l + 64 r.
@@ -125,8 +146,9 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
     float2 *Y = reinterpret_cast<float2 *>(smem);                        // shifted spectrum Y[0..512] (4104 B), between the FFTs
     float2 *RES = reinterpret_cast<float2 *>(smem + 4112) - M;           // residue float2 positions [512, 1024) -> smem[4112, 8208)
     float *MAG = reinterpret_cast<float *>(smem + 9216);                 // MAG[4 + k], k in [-4, 524)
-    unsigned char *MASKB = smem + 9216 + 528 * 4;                        // 64 bytes = 8 x u64 peak masks (bins 0..511) + 1 zero word
-    unsigned long long *MASKW = reinterpret_cast<unsigned long long *>(MASKB);
+    unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + 9216);         // aliases MAG once the flags are taken: route of source bin b
+    short *PSH = reinterpret_cast<short *>(smem + 9216 + 528 * 4);       // Math.round(p * f) per candidate peak bin p (0x7FFF: dropped)
+    unsigned psh_key = 0x7FC12345u;                                      // bit pattern of the f the table was built for (starts invalid)
 
     const int first_out = chunk * p.frames_per_chunk;
     int last_out = first_out + p.frames_per_chunk;
@@ -172,7 +194,6 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
 #pragma unroll
         for (int r = 0; r < 8; r++) raw[r] = float2{src.at(s0 + 2 * l + 128 * r), src.at(s0 + 2 * l + 128 * r + 1)};
     }
-    if (l < 9) MASKW[l] = 0ull;           // word 8 (bin 512) stays zero
 
     for (int m = first_frame; m < last_out; ++m) {
         const double pf = (double)pitch_row[m];
@@ -199,9 +220,11 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
         fft512_wave<double, false>(z, S64, tw1, tw2, l);
 
         // ---- split pass: X[k] = E - j W^k O with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved) ----
-        double2 X[8];
-        double x512 = 0.0;
+        float2 X32[8];                     // fp32 copy of the spectrum: the only thing the shift needs after the decisions
+        float x512f;
         {
+            double2 X[8];
+            double x512 = 0.0;
             const int pl = (64 - l) & 63;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -209,7 +232,7 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
                 if (l == 0) zm = (r == 0) ? z[0] : z[8 - r > 7 ? 7 : 8 - r];
                 const double2 E{z[r].x + zm.x, z[r].y - zm.y};
                 const double2 O{z[r].x - zm.x, z[r].y + zm.y};
-                const double2 WO = cmul(wl, cmul(p.tw64[64 * r], O));
+                const double2 WO = cmul(wl, mul_w16<double, false>(O, r));     // W_1024^{l+64r} = W^l * W_16^r
                 X[r] = double2{E.x + WO.y, E.y - WO.x};
             }
             if (l == 0) {
@@ -217,13 +240,37 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
                 X[0] = double2{2.0 * (z[0].x + z[0].y), 0.0};
                 x512 = 2.0 * (z[0].x - z[0].y);
             }
-        }
-        // ---- |X|^2 -> f32 (pv:82-92), exchanged through LDS for the neighbour tests ----
+            // ---- |X|^2 -> f32 (pv:82-92), exchanged through LDS for the neighbour tests ----
 #pragma unroll
-        for (int r = 0; r < 8; r++) MAG[4 + l + 64 * r] = (float)(X[r].x * X[r].x + X[r].y * X[r].y);
-        if (l == 0) MAG[4 + 512] = (float)(x512 * x512);
+            for (int r = 0; r < 8; r++) {
+                MAG[4 + l + 64 * r] = (float)(X[r].x * X[r].x + X[r].y * X[r].y);
+                X32[r] = float2{(float)X[r].x, (float)X[r].y};
+            }
+            if (l == 0) MAG[4 + 512] = (float)(x512 * x512);
+            x512f = (float)x512;
+            if (dbg) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) { const int k = l + 64 * r; p.dbg_X[2 * k] = X[r].x; p.dbg_X[2 * k + 1] = X[r].y; }
+                if (l == 0) { p.dbg_X[2 * 512] = x512; p.dbg_X[2 * 512 + 1] = 0.0; }
+            }
+        }
+        // ---- Math.round(peak * f) (pv:125) for every possible peak bin, cached while f does not change ----
+        {
+            const unsigned pfb = __float_as_uint(pitch_row[m]);
+            if (pfb != psh_key) {
+                psh_key = pfb;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int pk = l + 64 * r;
+                    const double ps = floor((double)pk * pf + 0.5);                 // x + 0.5 is exact here (<= 37 significant bits)
+                    const bool ok = (ps <= (double)H) && (ps >= -(double)(2 * N));   // pv:127-129; NaN -> not ok
+                    PSH[pk] = ok ? (short)(int)ps : (short)0x7FFF;
+                }
+            }
+        }
         __syncthreads();
-        // ---- peak flags (pv:95-116) for bins 8l..8l+7 -> one mask byte per lane ----
+        // ---- peak flags (pv:95-116) for bins 8l..8l+7, nearest peaks by wave scans, then one ROUTE word per source bin ----
+        int last_peak;
         {
             float mg[12];
             const float2 q0 = *reinterpret_cast<const float2 *>(&MAG[4 + 8 * l - 2]);
@@ -240,53 +287,61 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
                 const bool f = (k >= 2) && (k < H - 2) && (mg[i + 1] < c) && (mg[i] < c) && (mg[i + 3] < c) && (mg[i + 4] < c);
                 bits |= f ? (1u << i) : 0u;
             }
-            MASKB[l] = (unsigned char)bits;
-        }
-        __syncthreads();
-        // ---- per-word nearest peaks (uniform) ----
-        unsigned long long mk[8];
-        int wprev[8], wnext[8];
-        {
-            int run = -1;
-#pragma unroll
-            for (int w = 0; w < 8; w++) {
-                {
-                    const unsigned long long v = MASKW[w];
-                    mk[w] = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
-                }
-                wprev[w] = run;
-                if (mk[w]) run = w * 64 + 63 - __clzll(mk[w]);
+            if (dbg) {
+                p.dbg_flags[8 * l + 0] = bits & 1; p.dbg_flags[8 * l + 1] = (bits >> 1) & 1; p.dbg_flags[8 * l + 2] = (bits >> 2) & 1;
+                p.dbg_flags[8 * l + 3] = (bits >> 3) & 1; p.dbg_flags[8 * l + 4] = (bits >> 4) & 1; p.dbg_flags[8 * l + 5] = (bits >> 5) & 1;
+                p.dbg_flags[8 * l + 6] = (bits >> 6) & 1; p.dbg_flags[8 * l + 7] = (bits >> 7) & 1;
+                for (int i = 0; i < 8; i++) p.dbg_mag[8 * l + i] = mg[i + 2];
+                if (l == 63) { p.dbg_flags[512] = 0; p.dbg_mag[512] = mg[10]; }
             }
-            const int last_peak_tmp = run;
-            run = BIG;
+            // nearest peak at-or-below / above this lane's byte: inclusive prefix-max / suffix-min over lanes
+            int pm = bits ? 8 * l + 31 - __clz((int)bits) : -1;
+            int nm = bits ? 8 * l + __ffs((int)bits) - 1 : BIG;
 #pragma unroll
-            for (int w = 7; w >= 0; w--) {
-                wnext[w] = run;
-                if (mk[w]) run = w * 64 + __ffsll(mk[w]) - 1;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(pm, d, 64), u = __shfl_down(nm, d, 64);
+                if (l >= d) pm = max(pm, t);
+                if (l + d < 64) nm = min(nm, u);
             }
-            (void)last_peak_tmp;
-        }
-        int last_peak = -1;
+            int cprev = __shfl_up(pm, 1, 64), cnext = __shfl_down(nm, 1, 64);
+            if (l == 0) cprev = -1;
+            if (l == 63) cnext = BIG;
+            last_peak = __builtin_amdgcn_readlane(pm, 63);
+            // owner rule (pv:132-141) + shift (pv:147-152) per source bin -> ROUTE = (rotation index << 16) | target, or ~0
+            auto route_of = [&](int b, int prv, int nxt) -> unsigned {
+                int owner;
+                if (prv < 0) owner = nxt;
+                else if (nxt == BIG) owner = prv;
+                else owner = (b < prv + ((nxt - prv + 1) >> 1)) ? prv : nxt;
+                const bool has = (owner != BIG) && (owner >= 0);
+                const int ps = (int)PSH[has ? owner : 0];
+                const int delta = ps - owner;
+                const int tgt = b + delta;
+                const bool ok = has && (ps != 0x7FFF) && (tgt >= 0) && (tgt < H);
+                const unsigned ridx = (unsigned)((delta & (N - 1)) * tmod) & (N - 1);
+                return ok ? ((ridx << 16) | (unsigned)tgt) : 0xFFFFFFFFu;
+            };
+            unsigned rt[8];
 #pragma unroll
-        for (int w = 0; w < 8; w++) if (mk[w]) last_peak = w * 64 + 63 - __clzll(mk[w]);
-
+            for (int i = 0; i < 8; i++) {
+                const unsigned lowm = bits & ((2u << i) - 1u), highm = bits >> (i + 1);
+                const int prv = lowm ? 8 * l + 31 - __clz((int)lowm) : cprev;
+                const int nxt = highm ? 8 * l + i + __ffs((int)highm) : cnext;
+                rt[i] = route_of(8 * l + i, prv, nxt);
+            }
+            // MAG is dead now (every lane has its 12 magnitudes in registers): ROUTE aliases it
+            __syncthreads();
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * l]) = uint4{rt[0], rt[1], rt[2], rt[3]};
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * l + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
+            if (l == 63) ROUTE[512] = route_of(512, pm, BIG);               // source bin N/2: owner is the last peak
+        }
         int upper_end = H;
         if (last_peak >= 0) {
-            const double psh = floor((double)last_peak * pf + 0.5);      // Math.round (pv:125); x+0.5 is exact here
-            if (!(psh > (double)H) && psh >= -(double)(2 * N)) {
-                const int d = (int)psh - last_peak;
+            const int ps = (int)PSH[last_peak];
+            if (ps != 0x7FFF) {
+                const int d = ps - last_peak;
                 if (d < 0) { upper_end = H - d; if (upper_end > N) upper_end = N; }
             }
-        }
-        if (dbg) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int k = l + 64 * r;
-                p.dbg_X[2 * k] = X[r].x; p.dbg_X[2 * k + 1] = X[r].y;
-                p.dbg_mag[k] = MAG[4 + k];
-                p.dbg_flags[k] = (int)((mk[r] >> l) & 1ull);
-            }
-            if (l == 0) { p.dbg_X[2 * 512] = x512; p.dbg_X[2 * 512 + 1] = 0.0; p.dbg_mag[512] = MAG[4 + 512]; p.dbg_flags[512] = 0; }
         }
         // ---- zero Y (pv:121); the transposes of the forward FFT are done with the scratch ----
 #pragma unroll
@@ -340,49 +395,45 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
             }
             if (dbg) for (int k = H + l; k < N; k += 64) { p.dbg_X[2 * k] = RES[k].x; p.dbg_X[2 * k + 1] = RES[k].y; }
         }
-        // ---- shiftPeaks (pv:119-173): per-source-bin owner rule, sources straight from registers ----
+        // ---- shiftPeaks (pv:119-173): each lane moves its own source bins (registers) along the precomputed routes ----
         {
             // For f >= 1, delta_i = round(p_i f) - p_i is non-decreasing in i, so the shifted regions stay disjoint and a plain
             // store replaces the LDS float atomic (which serialises: it was 2/3 of all LDS cycles).
             const bool disjoint = (pf >= 1.0);
-            auto emit = [&](int b, int prv, int nxt, float2 v) {
-                int owner;
-                if (prv < 0) owner = nxt;
-                else if (nxt == BIG) owner = prv;
-                else owner = (b < prv + ((nxt - prv + 1) >> 1)) ? prv : nxt;
-                if (owner == BIG || owner < 0) return;
-                const double psh = floor((double)owner * pf + 0.5);
-                if (!(psh <= (double)H) || psh < -(double)(2 * N)) return;
-                const int delta = (int)psh - owner;
-                const int tgt = b + delta;
-                if (tgt < 0 || tgt >= H) return;
-                const int ridx = ((delta & (N - 1)) * tmod) & (N - 1);
+            auto emit = [&](unsigned route, float2 v) {
+                const unsigned ridx = route >> 16;
+                const int tgt = (int)(route & 0xFFFFu);
                 float2 y;
                 if (R == 4) {
-                    const int qd = ridx >> (LOG2N - 2);                    // rotation = j^qd exactly
-                    y = (qd == 0) ? v : (qd == 1) ? float2{-v.y, v.x} : (qd == 2) ? float2{-v.x, -v.y} : float2{v.y, -v.x};
+                    const unsigned qd = ridx >> (LOG2N - 2);               // (delta*t) mod N is a multiple of N/4: rotation = j^qd
+                    const bool sw = (qd & 1u) != 0u;                       // j^1 = (-y, x), j^2 = (-x, -y), j^3 = (y, -x)
+                    const float a = sw ? v.y : v.x, b = sw ? v.x : v.y;
+                    y.x = __uint_as_float(__float_as_uint(a) ^ ((((qd + 1u) >> 1) & 1u) << 31));
+                    y.y = __uint_as_float(__float_as_uint(b) ^ ((qd >> 1) << 31));
                 } else {
-                    y = cmul(v, cconj(p.tw32[ridx]));
+                    y = cmul(v, cconj(p.tw32[ridx & (N - 1)]));
                 }
-                if (disjoint) {
-                    Y[tgt] = y;                                            // f >= 1: shifted regions never overlap
-                } else {
-                    atomicAdd(&Y[tgt].x, y.x);                             // f < 1: regions compress, += collisions (pv:169-170)
-                    atomicAdd(&Y[tgt].y, y.y);
+                if (route != 0xFFFFFFFFu) {
+                    if (disjoint) {
+                        Y[tgt] = y;
+                    } else {
+                        atomicAdd(&Y[tgt].x, y.x);                         // f < 1: regions compress, += collisions (pv:169-170)
+                        atomicAdd(&Y[tgt].y, y.y);
+                    }
                 }
             };
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const unsigned long long m_r = mk[r];
-                const unsigned long long below = (l == 63) ? ~0ull : ((2ull << l) - 1ull);
-                const unsigned long long lo = m_r & below, hi = m_r & ~below;
-                const int prv = lo ? r * 64 + 63 - __clzll(lo) : wprev[r];
-                const int nxt = hi ? r * 64 + __ffsll(hi) - 1 : wnext[r];
-                emit(l + 64 * r, prv, nxt, float2{(float)X[r].x, (float)X[r].y});
+            for (int r = 0; r < 8; r++) emit(ROUTE[l + 64 * r], X32[r]);
+            if (l == 0) emit(ROUTE[512], float2{x512f, 0.f});
+            if (need_res) {
+                const int ps = (int)PSH[last_peak < 0 ? 0 : last_peak];
+                const int delta = ps - last_peak;
+                const unsigned ridx = (unsigned)((delta & (N - 1)) * tmod) & (N - 1);
+                for (int b = H + l; b < upper_end; b += 64) {
+                    const int tgt = b + delta;
+                    emit((tgt >= 0 && tgt < H) ? ((ridx << 16) | (unsigned)tgt) : 0xFFFFFFFFu, RES[b]);
+                }
             }
-            if (l == 0) emit(512, last_peak, BIG, float2{(float)x512, 0.f});
-            if (need_res)
-                for (int b = H + l; b < upper_end; b += 64) emit(b, last_peak, BIG, RES[b]);
         }
         __syncthreads();
         if (dbg) {
@@ -401,7 +452,7 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
                 if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
                 const float2 E{yk.x + ym.x, yk.y - ym.y};
                 const float2 O{yk.x - ym.x, yk.y + ym.y};
-                const float2 c = cmul(wlf, cmul(cconj(p.tw32[64 * r]), O));
+                const float2 c = cmul(wlf, mul_w16<float, true>(O, r));
                 zi[r] = float2{(E.x - c.y) * sc, (E.y + c.x) * sc};
             }
         }
@@ -455,7 +506,7 @@ hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_
 
 }  // namespace
 
-size_t pv_wave_lds_bytes() { return 9216 + 528 * 4 + 80; }
+size_t pv_wave_lds_bytes() { return 9216 + 528 * 4 + 1024; }
 
 bool pv_wave_supported(int log2n, int hop) { return log2n == 10 && (hop == 128 || hop == 256 || hop == 512 || hop == 1024); }
 
