@@ -83,39 +83,44 @@ __device__ __forceinline__ typename v2t<T>::type mul_w16(typename v2t<T>::type o
 
 constexpr int TP = 72;   // padded row of the transpose scratch (elements); conflict-free with the skew below
 
-// 512-point complex FFT across one wave: in/out layout lane l, reg r <-> element l + 64 r.
-// The per-lane twiddles are kept once, in fp64; the fp32 inverse rounds (and conjugates) them on the fly.
-template <typename T, bool INV>
-__device__ __forceinline__ typename v2t<T>::type twv(double2 w) { return typename v2t<T>::type{(T)w.x, INV ? (T)(-w.y) : (T)w.y}; }
-
-template <typename T, bool INV>
-__device__ __forceinline__ void fft512_wave(typename v2t<T>::type (&a)[8], typename v2t<T>::type *S, const double2 (&tw1)[8],
-                                            const double2 (&tw2)[8], int l)
+// Wave-local ordering of LDS traffic: LDS instructions of one wave execute in order, so only the compiler must be fenced.
+__device__ __forceinline__ void wave_sync()
 {
-    using T2 = typename v2t<T>::type;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 512-point complex FFT across one wave: in/out layout lane l, reg r <-> element l + 64 r.
+// TW1[k*64 + l] = W_512^{l k}, TW2[k*8 + n0] = W_64^{n0 k} (k = 1..7) live in LDS, shared by the waves of the workgroup,
+// already conjugated / rounded for the inverse fp32 instance.
+template <typename T, bool INV>
+__device__ __forceinline__ void fft512_wave(typename v2t<T>::type (&a)[8], typename v2t<T>::type *S, const typename v2t<T>::type *TW1,
+                                            const typename v2t<T>::type *TW2, int l)
+{
     const int lh = l >> 3, ll = l & 7;
     // pass 1: DFT over n2 (register index); twiddle W_512^{l*k0}
     radix8<T, INV>(a);
 #pragma unroll
-    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twv<T, INV>(tw1[k]));
+    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], TW1[k * 64 + l]);
     // transpose 1: [reg k0][lane (n1,n0)] -> [reg n1][lane (k0,n0)]
 #pragma unroll
     for (int k = 0; k < 8; k++) S[k * TP + l] = a[k];
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int n = 0; n < 8; n++) a[n] = S[lh * TP + 8 * n + ll];
-    __syncthreads();
+    wave_sync();
     // pass 2: DFT over n1; twiddle W_64^{n0*k1}
     radix8<T, INV>(a);
 #pragma unroll
-    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twv<T, INV>(tw2[k]));
+    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], TW2[k * 8 + ll]);
     // transpose 2: [reg k1][lane (k0,n0)] -> [reg n0][lane (k1,k0)], skewed rows
 #pragma unroll
     for (int k = 0; k < 8; k++) S[k * TP + lh * 8 + ((ll + lh) & 7)] = a[k];
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int n = 0; n < 8; n++) a[n] = S[lh * TP + ll * 8 + ((n + ll) & 7)];
-    __syncthreads();
+    wave_sync();
     // pass 3: DFT over n0 -> k2; lane l now holds X[l + 64 k2]
     radix8<T, INV>(a);
 }
@@ -129,18 +134,56 @@ struct WaveSrc {
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
+constexpr int WAVES = 4;                         // independent frame chains per workgroup (they only share the LDS tables)
+constexpr int TAB_TW1 = 0;                       // double2[8*64]  W_512^{l k}
+constexpr int TAB_TW2 = TAB_TW1 + 8 * 64 * 16;   // double2[8*8]   W_64^{n0 k}
+constexpr int TAB_TW1F = TAB_TW2 + 8 * 8 * 16;   // float2[8*64]   conj, fp32 (inverse)
+constexpr int TAB_TW2F = TAB_TW1F + 8 * 64 * 8;  // float2[8*8]
+constexpr int TAB_HANN = TAB_TW2F + 8 * 8 * 8;   // float2[512]    Hann at samples 2n, 2n+1
+constexpr int TAB_BYTES = TAB_HANN + 512 * 8;    // 17920
+constexpr int WAVE_LDS = 9216 + 528 * 4 + 1024;  // per-wave: transposes/Y/RES | MAG/ROUTE | PSH
+
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
 template <int S_ROWS>
-__global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParams p)
+__global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKernelParams p)
 {
     constexpr int N = 1024, M = 512, H = 513, LOG2N = 10;
     constexpr int HOP = 128 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;    // LROWS rows of carried accumulator
     constexpr int BIG = 1 << 30;
-    const int l = threadIdx.x;
-    const int ch = blockIdx.y, chunk = blockIdx.x;
+    const int l = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ch = blockIdx.y, chunk = blockIdx.x * WAVES + wv;
 
-    // ---- LDS carve (all dynamic, 16-byte aligned) ----
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // ---- LDS carve (all dynamic, 16-byte aligned): shared tables, then one private region per wave ----
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const double2 *TW1 = reinterpret_cast<const double2 *>(smem_all + TAB_TW1);
+    const double2 *TW2 = reinterpret_cast<const double2 *>(smem_all + TAB_TW2);
+    const float2 *TW1F = reinterpret_cast<const float2 *>(smem_all + TAB_TW1F);
+    const float2 *TW2F = reinterpret_cast<const float2 *>(smem_all + TAB_TW2F);
+    const float2 *HW = reinterpret_cast<const float2 *>(smem_all + TAB_HANN);
+    {
+        double2 *t1 = reinterpret_cast<double2 *>(smem_all + TAB_TW1);
+        double2 *t2 = reinterpret_cast<double2 *>(smem_all + TAB_TW2);
+        float2 *t1f = reinterpret_cast<float2 *>(smem_all + TAB_TW1F);
+        float2 *t2f = reinterpret_cast<float2 *>(smem_all + TAB_TW2F);
+        float2 *hh = reinterpret_cast<float2 *>(smem_all + TAB_HANN);
+        for (int i = threadIdx.x; i < 512; i += 64 * WAVES) {
+            const int k = i >> 6, ln = i & 63;
+            const double2 w = p.tw64[(2 * ln * k) & (N - 1)];
+            t1[i] = w;
+            t1f[i] = float2{(float)w.x, -(float)w.y};
+            hh[i] = float2{p.hann[2 * i], p.hann[2 * i + 1]};
+            if (i < 64) {
+                const double2 w2 = p.tw64[(16 * (i & 7) * (i >> 3)) & (N - 1)];
+                t2[i] = w2;
+                t2f[i] = float2{(float)w2.x, -(float)w2.y};
+            }
+        }
+    }
+    __syncthreads();                                                     // the only workgroup-wide barrier
+    if (chunk >= p.nchunks) return;
+
+    unsigned char *smem = smem_all + TAB_BYTES + wv * WAVE_LDS;
     double2 *S64 = reinterpret_cast<double2 *>(smem);                    // 8*72*16 = 9216 B: fp64 transposes
     float2 *S32 = reinterpret_cast<float2 *>(smem);                      // fp32 transposes (first 4608 B)
     float2 *Y = reinterpret_cast<float2 *>(smem);                        // shifted spectrum Y[0..512] (4104 B), between the FFTs
@@ -163,17 +206,8 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
     const float *pitch_row = p.pitch + (p.pitch_stride ? (long)(ch / p.ch_per_stream) * p.pitch_stride : 0);
     const float invR = 1.0f / (float)R;
 
-    // ---- per-lane constants, loaded once per chain ----
-    double2 tw1[8], tw2[8];               // fp64: W_512^{l k}, W_64^{(l&7) k}
     const double2 wl = p.tw64[l];          // split pass: W_1024^{l + 64 r} = wl * W_16^r (W_16^r is wave-uniform)
     const float2 wlf = cconj(p.tw32[l]);
-    float2 hw[8];                          // Hann at samples 2(l+64r), 2(l+64r)+1
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        tw1[k] = p.tw64[(2 * l * k) & (N - 1)];
-        tw2[k] = p.tw64[(16 * (l & 7) * k) & (N - 1)];
-        hw[k] = float2{p.hann[2 * (l + 64 * k)], p.hann[2 * (l + 64 * k) + 1]};
-    }
 
     // ---- carried overlap-add accumulator in registers: row r <-> samples 2l + 128 r (+1) ----
     float2 acc[8];
@@ -215,9 +249,9 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
         // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded in here (exact) ----
         double2 z[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) z[r] = double2{0.5 * (double)(raw[r].x * hw[r].x), 0.5 * (double)(raw[r].y * hw[r].y)};
+        for (int r = 0; r < 8; r++) { const float2 hwr = HW[l + 64 * r]; z[r] = double2{0.5 * (double)(raw[r].x * hwr.x), 0.5 * (double)(raw[r].y * hwr.y)}; }
 
-        fft512_wave<double, false>(z, S64, tw1, tw2, l);
+        fft512_wave<double, false>(z, S64, TW1, TW2, l);
 
         // ---- split pass: X[k] = E - j W^k O with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved) ----
         float2 X32[8];                     // fp32 copy of the spectrum: the only thing the shift needs after the decisions
@@ -268,7 +302,7 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- peak flags (pv:95-116) for bins 8l..8l+7, nearest peaks by wave scans, then one ROUTE word per source bin ----
         int last_peak;
         {
@@ -330,7 +364,7 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
                 rt[i] = route_of(8 * l + i, prv, nxt);
             }
             // MAG is dead now (every lane has its 12 magnitudes in registers): ROUTE aliases it
-            __syncthreads();
+            wave_sync();
             *reinterpret_cast<uint4 *>(&ROUTE[8 * l]) = uint4{rt[0], rt[1], rt[2], rt[3]};
             *reinterpret_cast<uint4 *>(&ROUTE[8 * l + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
             if (l == 63) ROUTE[512] = route_of(512, pm, BIG);               // source bin N/2: owner is the last peak
@@ -349,7 +383,7 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
         if (l == 0) Y[512] = float2{0.f, 0.f};
         // ---- residue above Nyquist only when the last region reads it ----
         const bool need_res = upper_end > H;
-        __syncthreads();
+        wave_sync();
         if (need_res) {
             // re-run fft.js's stage structure on [N/2, N) in fp32 (bundle:306-442) -- rare path, LDS/global based
             const long s0 = (long)(m + 1) * HOP - N;
@@ -367,7 +401,7 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
                 RES[4 * t + 2] = float2{t0 - t2, 0.f};
                 RES[4 * t + 3] = float2{t1, t3};
             }
-            __syncthreads();
+            wave_sync();
             for (int log2m = 4; log2m <= LOG2N - 2; log2m += 2) {
                 const int Mb = 1 << log2m, q = Mb >> 2, hq = q >> 1;
                 const int nblocks = (N / 2) >> log2m;
@@ -391,7 +425,7 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
                         RES[o + 2 * q - i] = float2{T0.x - T2.x, -(T0.y - T2.y)};
                     }
                 }
-                __syncthreads();
+                wave_sync();
             }
             if (dbg) for (int k = H + l; k < N; k += 64) { p.dbg_X[2 * k] = RES[k].x; p.dbg_X[2 * k + 1] = RES[k].y; }
         }
@@ -435,7 +469,7 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         if (dbg) {
 #pragma unroll
             for (int r = 0; r < 8; r++) { const int k = l + 64 * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
@@ -456,14 +490,14 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
                 zi[r] = float2{(E.x - c.y) * sc, (E.y + c.x) * sc};
             }
         }
-        __syncthreads();
-        fft512_wave<float, true>(zi, S32, tw1, tw2, l);
+        wave_sync();
+        fft512_wave<float, true>(zi, S32, TW1F, TW2F, l);
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         {
             const bool emit_out = (m >= first_out);
             float2 fr[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) fr[r] = float2{zi[r].x * hw[r].x * invR, zi[r].y * hw[r].y * invR};
+            for (int r = 0; r < 8; r++) { const float2 hwr = HW[l + 64 * r]; fr[r] = float2{zi[r].x * hwr.x * invR, zi[r].y * hwr.y * invR}; }
 #pragma unroll
             for (int r = 0; r < S_ROWS; r++) {
                 const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
@@ -485,7 +519,7 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
         for (int r = 0; r < S_ROWS; r++) raw[8 - S_ROWS + r] = nxt_raw[r];
     }
 
-    if (chunk == (int)gridDim.x - 1) {
+    if (chunk == p.nchunks - 1) {
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
             float *a = p.acc_out + (long)ch * (N - HOP) + 2 * l + 128 * r;
@@ -500,13 +534,24 @@ __global__ __launch_bounds__(64, 2) void pv_wave_kernel_1024(const PvKernelParam
 template <int S_ROWS>
 hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
-    hipLaunchKernelGGL(pv_wave_kernel_1024<S_ROWS>, dim3(nchunks, nch, 1), dim3(64, 1, 1), pv_wave_lds_bytes(), st, p);
+    static bool attr_done[16] = {};
+    auto k = pv_wave_kernel_1024<S_ROWS>;
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (!attr_done[dev & 15]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_wave_lds_bytes());
+        if (e != hipSuccess) return e;
+        attr_done[dev & 15] = true;
+    }
+    PvKernelParams q = p;
+    q.nchunks = nchunks;
+    hipLaunchKernelGGL(k, dim3((nchunks + WAVES - 1) / WAVES, nch, 1), dim3(64 * WAVES, 1, 1), pv_wave_lds_bytes(), st, q);
     return hipGetLastError();
 }
 
 }  // namespace
 
-size_t pv_wave_lds_bytes() { return 9216 + 528 * 4 + 1024; }
+size_t pv_wave_lds_bytes() { return TAB_BYTES + WAVES * WAVE_LDS; }
 
 bool pv_wave_supported(int log2n, int hop) { return log2n == 10 && (hop == 128 || hop == 256 || hop == 512 || hop == 1024); }
 
