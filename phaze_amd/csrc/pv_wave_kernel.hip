@@ -139,8 +139,9 @@ constexpr int TAB_TW1 = 0;                       // double2[8*64]  W_512^{l k}
 constexpr int TAB_TW2 = TAB_TW1 + 8 * 64 * 16;   // double2[8*8]   W_64^{n0 k}
 constexpr int TAB_TW1F = TAB_TW2 + 8 * 8 * 16;   // float2[8*64]   conj, fp32 (inverse)
 constexpr int TAB_TW2F = TAB_TW1F + 8 * 64 * 8;  // float2[8*8]
-constexpr int TAB_HANN = TAB_TW2F + 8 * 8 * 8;   // float2[512]    Hann at samples 2n, 2n+1
-constexpr int TAB_BYTES = TAB_HANN + 512 * 8;    // 17920
+constexpr int TAB_HANN = TAB_TW2F + 8 * 8 * 8;   // float2[512]    0.5 * Hann at samples 2n, 2n+1 (analysis; 1/2 of the split pass folded in, exact)
+constexpr int TAB_HANNI = TAB_HANN + 512 * 8;    // float2[512]    Hann / R (synthesis; the 1/R of the overlap-add folded in, exact: R = 2^k)
+constexpr int TAB_BYTES = TAB_HANNI + 512 * 8;   // 22016
 constexpr int WAVE_LDS = 9216 + 528 * 4 + 1024;  // per-wave: transposes/Y/RES | MAG/ROUTE | PSH
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
@@ -161,18 +162,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
     const float2 *TW1F = reinterpret_cast<const float2 *>(smem_all + TAB_TW1F);
     const float2 *TW2F = reinterpret_cast<const float2 *>(smem_all + TAB_TW2F);
     const float2 *HW = reinterpret_cast<const float2 *>(smem_all + TAB_HANN);
+    const float2 *HWI = reinterpret_cast<const float2 *>(smem_all + TAB_HANNI);
     {
         double2 *t1 = reinterpret_cast<double2 *>(smem_all + TAB_TW1);
         double2 *t2 = reinterpret_cast<double2 *>(smem_all + TAB_TW2);
         float2 *t1f = reinterpret_cast<float2 *>(smem_all + TAB_TW1F);
         float2 *t2f = reinterpret_cast<float2 *>(smem_all + TAB_TW2F);
         float2 *hh = reinterpret_cast<float2 *>(smem_all + TAB_HANN);
+        float2 *hi = reinterpret_cast<float2 *>(smem_all + TAB_HANNI);
+        const float invRt = 1.0f / (float)R;
         for (int i = threadIdx.x; i < 512; i += 64 * WAVES) {
             const int k = i >> 6, ln = i & 63;
             const double2 w = p.tw64[(2 * ln * k) & (N - 1)];
             t1[i] = w;
             t1f[i] = float2{(float)w.x, -(float)w.y};
-            hh[i] = float2{p.hann[2 * i], p.hann[2 * i + 1]};
+            hh[i] = float2{0.5f * p.hann[2 * i], 0.5f * p.hann[2 * i + 1]};
+            hi[i] = float2{p.hann[2 * i] * invRt, p.hann[2 * i + 1] * invRt};
             if (i < 64) {
                 const double2 w2 = p.tw64[(16 * (i & 7) * (i >> 3)) & (N - 1)];
                 t2[i] = w2;
@@ -204,7 +209,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
     const WaveSrc src{p.in + cbase, p.hist_in + (long)ch * (N - HOP), N - HOP};
     float *outp = p.out + cbase;
     const float *pitch_row = p.pitch + (p.pitch_stride ? (long)(ch / p.ch_per_stream) * p.pitch_stride : 0);
-    const float invR = 1.0f / (float)R;
 
     const double2 wl = p.tw64[l];          // split pass: W_1024^{l + 64 r} = wl * W_16^r (W_16^r is wave-uniform)
     const float2 wlf = cconj(p.tw32[l]);
@@ -246,10 +250,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
             }
         }
 
-        // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded in here (exact) ----
+        // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded into the table (exact) ----
         double2 z[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { const float2 hwr = HW[l + 64 * r]; z[r] = double2{0.5 * (double)(raw[r].x * hwr.x), 0.5 * (double)(raw[r].y * hwr.y)}; }
+        for (int r = 0; r < 8; r++) { const float2 hwr = HW[l + 64 * r]; z[r] = double2{(double)(raw[r].x * hwr.x), (double)(raw[r].y * hwr.y)}; }
 
         fft512_wave<double, false>(z, S64, TW1, TW2, l);
 
@@ -328,19 +332,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
                 for (int i = 0; i < 8; i++) p.dbg_mag[8 * l + i] = mg[i + 2];
                 if (l == 63) { p.dbg_flags[512] = 0; p.dbg_mag[512] = mg[10]; }
             }
-            // nearest peak at-or-below / above this lane's byte: inclusive prefix-max / suffix-min over lanes
-            int pm = bits ? 8 * l + 31 - __clz((int)bits) : -1;
-            int nm = bits ? 8 * l + __ffs((int)bits) - 1 : BIG;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(pm, d, 64), u = __shfl_down(nm, d, 64);
-                if (l >= d) pm = max(pm, t);
-                if (l + d < 64) nm = min(nm, u);
-            }
-            int cprev = __shfl_up(pm, 1, 64), cnext = __shfl_down(nm, 1, 64);
-            if (l == 0) cprev = -1;
-            if (l == 63) cnext = BIG;
-            last_peak = __builtin_amdgcn_readlane(pm, 63);
+            // nearest peak below / above this lane's byte: the 64-bit ballot of non-empty lanes locates the neighbour lane,
+            // one bpermute each fetches its last / first peak (two independent LDS round trips instead of a 6-step scan)
+            const int last_in = bits ? 8 * l + 31 - __clz((int)bits) : -1;
+            const int first_in = bits ? 8 * l + __ffs((int)bits) - 1 : BIG;
+            const unsigned long long occ = __ballot(bits != 0u);
+            const unsigned long long below = occ & ((1ull << l) - 1ull);
+            const unsigned long long above = (l == 63) ? 0ull : (occ >> (l + 1));
+            const int src_lo = below ? 63 - __clzll((long long)below) : 0;
+            const int src_hi = above ? l + __ffsll((long long)above) : 0;
+            int cprev = __shfl(last_in, src_lo, 64), cnext = __shfl(first_in, src_hi, 64);
+            if (!below) cprev = -1;
+            if (!above) cnext = BIG;
+            const int pm = bits ? last_in : cprev;                          // nearest peak at or below the end of this byte
+            last_peak = occ ? __shfl(last_in, 63 - __clzll((long long)occ), 64) : -1;
             // owner rule (pv:132-141) + shift (pv:147-152) per source bin -> ROUTE = (rotation index << 16) | target, or ~0
             auto route_of = [&](int b, int prv, int nxt) -> unsigned {
                 int owner;
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
             const bool emit_out = (m >= first_out);
             float2 fr[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) { const float2 hwr = HW[l + 64 * r]; fr[r] = float2{zi[r].x * hwr.x * invR, zi[r].y * hwr.y * invR}; }
+            for (int r = 0; r < 8; r++) { const float2 hwr = HWI[l + 64 * r]; fr[r] = float2{zi[r].x * hwr.x, zi[r].y * hwr.y}; }
 #pragma unroll
             for (int r = 0; r < S_ROWS; r++) {
                 const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
