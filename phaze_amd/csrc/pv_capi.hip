@@ -93,6 +93,7 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     p.t0_mod_n = (int)(h->time_cursor & (int64_t)(h->N - 1));
     p.tw64 = h->d_tw64; p.tw32 = h->d_tw32; p.hann = h->d_hann;
     p.dbg_ch = -1; p.dbg_frame = -1;
+    { const char *ab = getenv("PHAZE_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
     if (dbg_ch >= 0) { p.dbg_X = h->d_dbgX; p.dbg_mag = h->d_dbgMag; p.dbg_flags = h->d_dbgFlags; p.dbg_Y = h->d_dbgY; p.dbg_ch = dbg_ch; p.dbg_frame = 0; }
     const int nchunks = (nhops + p.frames_per_chunk - 1) / p.frames_per_chunk;
     h->last_frames_per_chunk = p.frames_per_chunk;

@@ -89,6 +89,9 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef PV_SCHED_FENCE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 // 512-point complex FFT across one wave: in/out layout lane l, reg r <-> element l + 64 r.
@@ -145,9 +148,10 @@ constexpr int TAB_BYTES = TAB_HANNI + 512 * 8;   // 22016
 constexpr int WAVE_LDS = 9216 + 528 * 4 + 1024;  // per-wave: transposes/Y/RES | MAG/ROUTE | PSH
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
-template <int S_ROWS>
+template <int S_ROWS, bool ABL>
 __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKernelParams p)
 {
+    const int ablate = ABL ? p.ablate : 0;                                // phase-ablation build (profiling only); folds away otherwise
     constexpr int N = 1024, M = 512, H = 513, LOG2N = 10;
     constexpr int HOP = 128 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;    // LROWS rows of carried accumulator
     constexpr int BIG = 1 << 30;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
 #pragma unroll
         for (int r = 0; r < 8; r++) { const float2 hwr = HW[l + 64 * r]; z[r] = double2{(double)(raw[r].x * hwr.x), (double)(raw[r].y * hwr.y)}; }
 
-        fft512_wave<double, false>(z, S64, TW1, TW2, l);
+        if (!(ablate & 1)) fft512_wave<double, false>(z, S64, TW1, TW2, l);
 
         // ---- split pass: X[k] = E - j W^k O with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved) ----
         float2 X32[8];                     // fp32 copy of the spectrum: the only thing the shift needs after the decisions
@@ -264,6 +268,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
             double2 X[8];
             double x512 = 0.0;
             const int pl = (64 - l) & 63;
+            if (ablate & 2) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) X[r] = z[r];
+            } else
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 double2 zm{shfl_d(z[7 - r].x, pl), shfl_d(z[7 - r].y, pl)};
@@ -308,8 +316,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
         }
         wave_sync();
         // ---- peak flags (pv:95-116) for bins 8l..8l+7, nearest peaks by wave scans, then one ROUTE word per source bin ----
-        int last_peak;
-        {
+        int last_peak = -1;
+        if (ablate & 4) {
+            wave_sync();
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * l]) = uint4{8u * l, 8u * l + 1, 8u * l + 2, 8u * l + 3};
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * l + 4]) = uint4{8u * l + 4, 8u * l + 5, 8u * l + 6, 8u * l + 7};
+            if (l == 63) ROUTE[512] = 512u;
+        } else {
             float mg[12];
             const float2 q0 = *reinterpret_cast<const float2 *>(&MAG[4 + 8 * l - 2]);
             const float4 q1 = *reinterpret_cast<const float4 *>(&MAG[4 + 8 * l]);
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
             }
             // nearest peak below / above this lane's byte: the 64-bit ballot of non-empty lanes locates the neighbour lane,
             // one bpermute each fetches its last / first peak (two independent LDS round trips instead of a 6-step scan)
-            const int last_in = bits ? 8 * l + 31 - __clz((int)bits) : -1;
+            const int last_in = bits ? 8 * l + 31 - __clz((int)bits) : -BIG;
             const int first_in = bits ? 8 * l + __ffs((int)bits) - 1 : BIG;
             const unsigned long long occ = __ballot(bits != 0u);
             const unsigned long long below = occ & ((1ull << l) - 1ull);
@@ -342,22 +355,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
             const int src_lo = below ? 63 - __clzll((long long)below) : 0;
             const int src_hi = above ? l + __ffsll((long long)above) : 0;
             int cprev = __shfl(last_in, src_lo, 64), cnext = __shfl(first_in, src_hi, 64);
-            if (!below) cprev = -1;
+            if (!below) cprev = -BIG;
             if (!above) cnext = BIG;
             const int pm = bits ? last_in : cprev;                          // nearest peak at or below the end of this byte
             last_peak = occ ? __shfl(last_in, 63 - __clzll((long long)occ), 64) : -1;
             // owner rule (pv:132-141) + shift (pv:147-152) per source bin -> ROUTE = (rotation index << 16) | target, or ~0
+            // pv:132-141: regions tile [0, N); a bin belongs to the peak on its left iff it is strictly closer to it
+            // (b < prv + ceil(gap/2)  <=>  b - prv < nxt - b; the midpoint of an even gap goes right).  Sentinels make the
+            // first region start at 0 (pv:132) and the last one end at N (pv:133).
             auto route_of = [&](int b, int prv, int nxt) -> unsigned {
-                int owner;
-                if (prv < 0) owner = nxt;
-                else if (nxt == BIG) owner = prv;
-                else owner = (b < prv + ((nxt - prv + 1) >> 1)) ? prv : nxt;
-                const bool has = (owner != BIG) && (owner >= 0);
+                const int owner = (b - prv < nxt - b) ? prv : nxt;          // prv = -BIG / nxt = +BIG when absent
+                const bool has = (unsigned)owner < (unsigned)H;
                 const int ps = (int)PSH[has ? owner : 0];
                 const int delta = ps - owner;
                 const int tgt = b + delta;
-                const bool ok = has && (ps != 0x7FFF) && (tgt >= 0) && (tgt < H);
-                const unsigned ridx = (unsigned)((delta & (N - 1)) * tmod) & (N - 1);
+                const bool ok = has && (ps != 0x7FFF) && ((unsigned)tgt < (unsigned)H);   // pv:127-129, pv:150-152, negative index
+                const unsigned ridx = (unsigned)((delta & (N - 1)) * tmod) & (N - 1);      // (delta * t) mod N  (pv:155-157)
                 return ok ? ((ridx << 16) | (unsigned)tgt) : 0xFFFFFFFFu;
             };
             unsigned rt[8];
@@ -383,6 +396,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
             }
         }
         // ---- zero Y (pv:121); the transposes of the forward FFT are done with the scratch ----
+        if (!(ablate & 8))
 #pragma unroll
         for (int r = 0; r < 8; r++) Y[l + 64 * r] = float2{0.f, 0.f};
         if (l == 0) Y[512] = float2{0.f, 0.f};
@@ -461,6 +475,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
                     }
                 }
             };
+            if (!(ablate & 8))
 #pragma unroll
             for (int r = 0; r < 8; r++) emit(ROUTE[l + 64 * r], X32[r]);
             if (l == 0) emit(ROUTE[512], float2{x512f, 0.f});
@@ -484,6 +499,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
         float2 zi[8];
         {
             const float sc = 1.0f / (float)N;
+            if (ablate & 8) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) zi[r] = float2{X32[r].x * sc, X32[r].y * sc};
+            } else
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const int k = l + 64 * r;
@@ -496,7 +515,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
             }
         }
         wave_sync();
-        fft512_wave<float, true>(zi, S32, TW1F, TW2F, l);
+        if (!(ablate & 16)) fft512_wave<float, true>(zi, S32, TW1F, TW2F, l);
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         {
             const bool emit_out = (m >= first_out);
@@ -536,11 +555,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
     }
 }
 
-template <int S_ROWS>
+template <int S_ROWS, bool ABL>
 hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
     static bool attr_done[16] = {};
-    auto k = pv_wave_kernel_1024<S_ROWS>;
+    auto k = pv_wave_kernel_1024<S_ROWS, ABL>;
     int dev = 0;
     hipGetDevice(&dev);
     if (!attr_done[dev & 15]) {
@@ -563,10 +582,10 @@ bool pv_wave_supported(int log2n, int hop) { return log2n == 10 && (hop == 128 |
 hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
     switch (p.hop) {
-    case 128: return launch_wave<1>(p, nch, nchunks, st);
-    case 256: return launch_wave<2>(p, nch, nchunks, st);
-    case 512: return launch_wave<4>(p, nch, nchunks, st);
-    case 1024: return launch_wave<8>(p, nch, nchunks, st);
+    case 128: return launch_wave<1, false>(p, nch, nchunks, st);
+    case 256: return p.ablate ? launch_wave<2, true>(p, nch, nchunks, st) : launch_wave<2, false>(p, nch, nchunks, st);
+    case 512: return launch_wave<4, false>(p, nch, nchunks, st);
+    case 1024: return launch_wave<8, false>(p, nch, nchunks, st);
     default: return hipErrorInvalidValue;
     }
 }
