@@ -179,8 +179,9 @@ def main():
                        "lds_bytes_per_workgroup": info["lds_bytes_per_workgroup"], "parallelism": f"streams x{world} (independent, no collective)",
                        "device": info["device_name"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "pv_chain_kernel", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel": info["kernel_name"], "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
                          "note": "algorithmic bytes = 2*hop*4 B per channel-frame; the kernel is LDS/VALU-bound (fp64 FFT), see DESIGN.md"},
             "parity_rms_vs_oracle": parity,
         }

@@ -60,6 +60,7 @@ typedef struct pv_info {
     int32_t threads_per_workgroup, lds_bytes_per_workgroup, frames_per_chunk;
     int32_t compute_units, device_id;
     char device_name[64];
+    char kernel_name[32];    /* "pv_wave_kernel_1024" (N = 1024, hop in {128,256,512,1024}) or "pv_chain_kernel" (generic)  */
 } pv_info;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */

@@ -35,7 +35,8 @@ class _Config(C.Structure):
 
 class _Info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("fft_size", "hop_size", "overlaps", "max_channels", "max_hops", "threads_per_workgroup",
-                                          "lds_bytes_per_workgroup", "frames_per_chunk", "compute_units", "device_id")] + [("device_name", C.c_char * 64)]
+                                          "lds_bytes_per_workgroup", "frames_per_chunk", "compute_units", "device_id")] + [("device_name", C.c_char * 64),
+                                                                                                       ("kernel_name", C.c_char * 32)]
 
 
 def library_path() -> str:
@@ -146,6 +147,7 @@ class PhaseVocoder:
         self._check(self._L.pv_get_info(self._h, C.byref(i)))
         d = {n: getattr(i, n) for n, _ in _Info._fields_}
         d["device_name"] = i.device_name.decode()
+        d["kernel_name"] = i.kernel_name.decode()
         return d
 
     # -- the hot call, AudioWorklet form --

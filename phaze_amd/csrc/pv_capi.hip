@@ -251,7 +251,8 @@ int pv_get_info(const pv_handle *h, pv_info *out)
     memset(out, 0, sizeof *out);
     out->fft_size = h->N; out->hop_size = h->hop; out->overlaps = h->R;
     out->max_channels = h->max_channels; out->max_hops = h->max_hops;
-    out->threads_per_workgroup = h->use_wave ? 64 : pv_kernel_threads(h->log2n);
+    out->threads_per_workgroup = h->use_wave ? pv_wave_threads() : pv_kernel_threads(h->log2n);
+    snprintf(out->kernel_name, sizeof out->kernel_name, "%s", h->use_wave ? "pv_wave_kernel_1024" : "pv_chain_kernel");
     out->lds_bytes_per_workgroup = (int32_t)(h->use_wave ? pv_wave_lds_bytes() : pv_kernel_lds_bytes(h->log2n, h->hop));
     out->frames_per_chunk = h->last_frames_per_chunk;
     out->compute_units = h->cus; out->device_id = h->device;

@@ -37,5 +37,6 @@ hipError_t pv_launch_chain(int log2n, const PvKernelParams &p, int nch, int nchu
 
 // wave-per-frame kernel for N = 1024 (pv_wave_kernel.hip)
 size_t pv_wave_lds_bytes();
+int pv_wave_threads();
 bool pv_wave_supported(int log2n, int hop);
 hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st);

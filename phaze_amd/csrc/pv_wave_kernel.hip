@@ -577,6 +577,8 @@ hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_
 
 size_t pv_wave_lds_bytes() { return TAB_BYTES + WAVES * WAVE_LDS; }
 
+int pv_wave_threads() { return 64 * WAVES; }
+
 bool pv_wave_supported(int log2n, int hop) { return log2n == 10 && (hop == 128 || hop == 256 || hop == 512 || hop == 1024); }
 
 hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)

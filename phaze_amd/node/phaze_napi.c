@@ -268,6 +268,8 @@ static napi_value js_info(napi_env env, napi_callback_info info)
 #undef SETI
     napi_create_string_utf8(env, inf.device_name, NAPI_AUTO_LENGTH, &v);
     napi_set_named_property(env, o, "deviceName", v);
+    napi_create_string_utf8(env, inf.kernel_name, NAPI_AUTO_LENGTH, &v);
+    napi_set_named_property(env, o, "kernelName", v);
     return o;
 }
 
