@@ -1,0 +1,106 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent properties (the oracle cannot run these sizes in seconds).
+
+Everything stays on the device (torch tensors + pv_process_batch_device); only small slices come back to the host.
+  * K1 identity: pitchFactor = 1  =>  y[n] = 0.375 * x[n - (N - hop)]   (any size, any hop with R = 4)
+  * replication: streams fed identical input produce bit-identical output (channel independence, K5)
+  * chunk invariance: different frames_per_chunk => bit-identical output
+  * prefix parity: the first hops of the full-size run equal the oracle on the same prefix
+"""
+import numpy as np
+import pytest
+
+import oracle_lib
+import signals as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(fft, hop, nch, T, fpc=0):
+    import torch
+    import phaze_amd
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, frames_per_chunk=fpc)
+    st = torch.cuda.Stream()
+    pv.set_stream(st.cuda_stream)
+    return torch, pv, st
+
+
+def _noise(torch, nch, n, seed=0):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return (torch.rand((nch, n), device="cuda", generator=g) - 0.5)
+
+
+@pytest.mark.parametrize("fft,hop,nch,T", [(1024, 256, 1, 1 << 20), (2048, 512, 2, 1 << 16), (4096, 1024, 8 * 64, 64), (8192, 2048, 8, 1 << 11)])
+def test_identity_pf1_full_size(fft, hop, nch, T):
+    torch, pv, st = _setup(fft, hop, nch, T)
+    x = _noise(torch, nch, T * hop)
+    y = torch.empty_like(x)
+    p = torch.ones(T, device="cuda")
+    torch.cuda.synchronize()          # inputs are produced on torch's default stream, the library launches on `st`
+    with torch.cuda.stream(st):
+        pv.process_batch_device(x.data_ptr(), y.data_ptr(), nch, T, T * hop, p.data_ptr())
+    pv.synchronize()
+    d = fft - hop
+    err = (y[:, d:] - 0.375 * x[:, :-d]).double().pow(2).mean().sqrt().item()
+    assert err < 1e-7, err
+    assert pv.time_cursor == T * hop
+    pv.close()
+
+
+def test_c4_streams_replicated_and_prefix_parity():
+    """C4 shape: 4096/1024, 8 channels x 128 streams (one GPU's share of 1024 streams), 64 hops, pf 1.25."""
+    fft, hop, nstreams, cps, T = 4096, 1024, 128, 8, 64
+    nch = nstreams * cps
+    torch, pv, st = _setup(fft, hop, nch, T)
+    base = np.stack([S.make_signal("tonal", c, T * hop) for c in range(cps)])
+    x = torch.from_numpy(np.tile(base, (nstreams, 1))).cuda()
+    y = torch.empty_like(x)
+    p = torch.full((T,), 1.25, device="cuda")
+    torch.cuda.synchronize()          # inputs are produced on torch's default stream, the library launches on `st`
+    with torch.cuda.stream(st):
+        pv.process_batch_device(x.data_ptr(), y.data_ptr(), nch, T, T * hop, p.data_ptr())
+    pv.synchronize()
+    y0 = y[:cps]
+    for s in (1, 17, nstreams - 1):
+        assert torch.equal(y[s * cps:(s + 1) * cps], y0)
+    K = 12
+    ref = oracle_lib.Oracle(fft, hop, cps).process_planar(base[:, :K * hop], np.full(K, 1.25, np.float32))
+    assert S.rms(y0[:, :K * hop].cpu().numpy().astype(np.float64) - ref) < 2e-6
+    pv.close()
+
+
+@pytest.mark.parametrize("fft,hop", [(1024, 256), (2048, 512)])
+def test_chunk_invariance_full_size(fft, hop):
+    T = 1 << 16
+    outs = []
+    for fpc in (0, 29, 200):
+        torch, pv, st = _setup(fft, hop, 1, T, fpc)
+        x = _noise(torch, 1, T * hop, seed=5) * 0.5 + 0.25 * torch.sin(torch.arange(T * hop, device="cuda") * 0.05)
+        y = torch.empty_like(x)
+        p = torch.full((T,), 1.5 if fft == 1024 else 0.8, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            pv.process_batch_device(x.data_ptr(), y.data_ptr(), 1, T, T * hop, p.data_ptr())
+        pv.synchronize()
+        outs.append(y)
+        pv.close()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_c5_sweep_prefix_parity_and_finite():
+    """C5 shape: 8192/2048, 8 channels, pitchFactor swept 0.5 -> 2.0 over 256 hops; prefix vs oracle, everything finite."""
+    fft, hop, nch, T = 8192, 2048, 8, 256
+    torch, pv, st = _setup(fft, hop, nch, T)
+    xs = np.stack([S.make_signal("tonal", c, T * hop) for c in range(nch)])
+    pitch = (0.5 + 1.5 * np.arange(T, dtype=np.float64) / (T - 1)).astype(np.float32)
+    x, p = torch.from_numpy(xs).cuda(), torch.from_numpy(pitch).cuda()
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()          # inputs are produced on torch's default stream, the library launches on `st`
+    with torch.cuda.stream(st):
+        pv.process_batch_device(x.data_ptr(), y.data_ptr(), nch, T, T * hop, p.data_ptr())
+    pv.synchronize()
+    assert torch.isfinite(y).all()
+    K = 10
+    ref = oracle_lib.Oracle(fft, hop, 2).process_planar(xs[:2, :K * hop], pitch[:K])
+    assert S.rms(y[:2, :K * hop].cpu().numpy().astype(np.float64) - ref) < 2e-6
+    pv.close()
