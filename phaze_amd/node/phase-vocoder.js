@@ -45,6 +45,7 @@ class PhaseVocoderProcessor extends Base {
         this.fftSize = this.blockSize;
         this.nbOverlaps = this.blockSize / this.hopSize;       // ola-processor.js:17
         this.deviceId = po.deviceId | 0;
+        this._maxHops = Math.max(1, po.maxHops | 0);                   // staging size of the throughput entry point (processBatch)
         this._handles = [];
         this._channels = [];
         this._capacity = [];
@@ -53,7 +54,7 @@ class PhaseVocoderProcessor extends Base {
             // re-create for the common mono->stereo switch.  Throws Error('FFT size must be a power of two and
             // bigger than 1') for bad sizes, as `new FFT(n)` does (bundle:6-7).
             this._capacity.push(2);
-            this._handles.push(native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: 2, maxHops: 1, deviceId: this.deviceId }));
+            this._handles.push(native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: 2, maxHops: this._maxHops, deviceId: this.deviceId }));
             this._channels.push(1);
         }
     }
@@ -69,7 +70,7 @@ class PhaseVocoderProcessor extends Base {
                     const t = native.timeCursor(this._handles[i]);
                     native.destroy(this._handles[i]);
                     this._capacity[i] = Math.max(nb, 2 * this._capacity[i]);
-                    this._handles[i] = native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: this._capacity[i], maxHops: 1, deviceId: this.deviceId });
+                    this._handles[i] = native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: this._capacity[i], maxHops: this._maxHops, deviceId: this.deviceId });
                     native.timeCursor(this._handles[i], t);     // timeCursor survives a reallocation (phase-vocoder.js:31,71)
                 } else {
                     native.reset(this._handles[i], 0, this._capacity[i]);
@@ -92,22 +93,12 @@ class PhaseVocoderProcessor extends Base {
         return true;                                            // ola-processor.js:170
     }
 
-    /** Throughput form (no reference counterpart): nhops process() calls of input 0 in one launch, planar [ch][nhops*hop]. */
+    /** Throughput form (no reference counterpart): nhops process() calls of input 0 in one launch, planar [ch][nhops*hop].
+     *  Needs processorOptions.maxHops >= nhops at construction; a changed channel count restarts the state (ola-processor.js:38-52). */
     processBatch(input, output, nch, nhops, pitchPerHop) {
-        if (nch !== this._channels[0] || nhops > (this._maxHops | 0)) {
-            const t = native.timeCursor(this._handles[0]);
-            const keep = nch === this._channels[0];
-            if (!keep || nhops > (this._maxHops | 0)) {
-                // a larger staging area needs a new handle; state only survives when the channel count is unchanged
-                if (keep) throw new Error("processBatch: nhops exceeds maxHops; construct with processorOptions.maxHops");
-                native.destroy(this._handles[0]);
-                this._maxHops = Math.max(nhops, this._maxHops | 0);
-                this._capacity[0] = Math.max(nch, this._capacity[0]);
-                this._handles[0] = native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: this._capacity[0], maxHops: this._maxHops, deviceId: this.deviceId });
-                native.timeCursor(this._handles[0], t);
-                this._channels[0] = nch;
-            }
-        }
+        if (nhops > this._maxHops) throw new Error("processBatch: nhops exceeds processorOptions.maxHops");
+        const fake = [Array.from({ length: nch })];
+        this.reallocateChannelsIfNeeded(fake.concat(this._handles.slice(1).map((_, i) => ({ length: this._channels[i + 1] }))), null);
         return native.processBatch(this._handles[0], input, output, nch, nhops, pitchPerHop, 0, 1);
     }
 

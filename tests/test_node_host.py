@@ -91,3 +91,33 @@ def test_node_process_matches_reference_golden(name, tmp_path):
     assert np.all(np.isfinite(got))
     assert err < 2e-6, f"{name}: rms {err:.3e}"
     print(name, json.loads(r.stdout.strip().splitlines()[-1])["us_per_call"], "us/call")
+
+
+@pytest.mark.gpu
+def test_wav_cli_shifts_pitch(tmp_path):
+    """Node WAV-in/WAV-out CLI (counterpart of src/main.js): a 440 Hz tone at pitch 1.5 comes out near 660 Hz, same length and level;
+    the streaming (process() per quantum) and batch entry points agree bit for bit."""
+    import struct
+    _build()
+    rate, n = 48000, 48000
+    t = np.arange(n) / rate
+    x = (0.4 * np.sin(2 * np.pi * 440 * t) + S.make_signal("noise", 0, n) * 0.002).astype(np.float32)
+    pcm = (np.clip(x, -1, 1) * 32767).astype("<i2").tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, rate, rate * 2, 2, 16) + b"data" + struct.pack("<I", len(pcm))
+    (tmp_path / "in.wav").write_bytes(hdr + pcm)
+    cli = os.path.join(ROOT, "phaze_amd", "node", "pitch-shift-cli.js")
+    outs = []
+    for mode in ([], ["--batch"]):
+        out = tmp_path / f"out{len(mode)}.wav"
+        r = subprocess.run([NODE, cli, str(tmp_path / "in.wav"), str(out), "--pitch", "1.5", "--fft", "1024", "--hop", "256"] + mode,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        raw = out.read_bytes()
+        y = np.frombuffer(raw[44:], dtype="<f4")
+        assert y.shape[0] == n
+        outs.append(y)
+        spec = np.abs(np.fft.rfft(y[4096:4096 + 32768] * np.hanning(32768)))
+        f_peak = np.argmax(spec) * rate / 32768
+        assert 600 < f_peak < 720, f_peak
+        assert 0.5 < S.rms(y[8192:-8192]) / S.rms(x[8192:-8192]) < 1.5
+    assert np.array_equal(outs[0], outs[1])
