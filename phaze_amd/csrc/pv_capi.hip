@@ -71,7 +71,7 @@ bool live(const pv_handle *h) { return h && h->magic == kMagic; }
 int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
 {
     if (h->frames_per_chunk_cfg > 0) return h->frames_per_chunk_cfg;
-    int F = 12 * h->R;                       // halo overhead (R-1)/F ~ 8 %
+    int F = 24 * h->R;                       // halo overhead (R-1)/F ~ 3 % when the launch is big enough
     const long want = 8L * h->cus;           // enough workgroups to fill every CU several times
     while (F > h->R && (long)nch * ((nhops + F - 1) / F) < want) F >>= 1;
     if (F < 1) F = 1;

@@ -295,7 +295,8 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
         // ---- 8. zero the shifted spectrum (pv:121) ----
         for (int k = tid; k < H; k += THREADS) B[k] = float2{0.f, 0.f};
         __syncthreads();
-        // ---- 9. shiftPeaks (pv:119-173) as a per-source-bin rule + LDS atomic scatter ----
+        // ---- 9. shiftPeaks (pv:119-173) as a per-source-bin rule + LDS scatter (atomic only when regions can collide) ----
+        const bool disjoint = (pf >= 1.0);
         for (int b = tid; b < upper_end; b += THREADS) {
             int prv, nxt;
             if (b < H) {
@@ -324,8 +325,12 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
             float2 v;
             if (b < H) { const double2 xv = A[b]; v = float2{(float)xv.x, (float)xv.y}; } else v = B[b];
             const float2 y = cmul(v, rot);
-            atomicAdd(&B[tgt].x, y.x);
-            atomicAdd(&B[tgt].y, y.y);
+            if (disjoint) {
+                B[tgt] = y;                                                // f >= 1: delta_i non-decreasing => shifted regions never overlap
+            } else {
+                atomicAdd(&B[tgt].x, y.x);                                 // f < 1: regions compress, += collisions (pv:169-170)
+                atomicAdd(&B[tgt].y, y.y);
+            }
         }
         __syncthreads();
         if (p.dbg_Y && ch == p.dbg_ch && m == p.dbg_frame)

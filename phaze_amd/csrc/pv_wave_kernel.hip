@@ -212,6 +212,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
     const long cbase = (long)ch * p.ch_stride;
     const WaveSrc src{p.in + cbase, p.hist_in + (long)ch * (N - HOP), N - HOP};
     float *outp = p.out + cbase;
+    const bool vec_out = (reinterpret_cast<uintptr_t>(outp) & 7u) == 0;           // 8-byte aligned channel base: float2 stores
+    const bool vec_in = ((reinterpret_cast<uintptr_t>(src.in) | reinterpret_cast<uintptr_t>(src.hist)) & 7u) == 0;
     const float *pitch_row = p.pitch + (p.pitch_stride ? (long)(ch / p.ch_per_stream) * p.pitch_stride : 0);
 
     const double2 wl = p.tw64[l];          // split pass: W_1024^{l + 64 r} = wl * W_16^r (W_16^r is wave-uniform)
@@ -250,7 +252,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
 #pragma unroll
             for (int r = 0; r < S_ROWS; r++) {
                 const long s = s1 + 2 * l + 128 * (8 - S_ROWS + r);
-                nxt_raw[r] = more ? float2{src.at(s), src.at(s + 1)} : float2{0.f, 0.f};
+                if (!more) nxt_raw[r] = float2{0.f, 0.f};
+                else if (vec_in) nxt_raw[r] = *reinterpret_cast<const float2 *>(s < 0 ? src.hist + s + src.hist_len : src.in + s);   // s is even
+                else nxt_raw[r] = float2{src.at(s), src.at(s + 1)};
             }
         }
 
@@ -527,7 +531,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
                 const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
                 if (emit_out) {
                     float *dst = outp + (long)m * HOP + 2 * l + 128 * r;
-                    dst[0] = o.x; dst[1] = o.y;
+                    if (vec_out) *reinterpret_cast<float2 *>(dst) = o;
+                    else { dst[0] = o.x; dst[1] = o.y; }
                 }
             }
 #pragma unroll
