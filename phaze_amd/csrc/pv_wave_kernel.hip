@@ -145,7 +145,7 @@ constexpr int TAB_TW2F = TAB_TW1F + 8 * 64 * 8;  // float2[8*8]
 constexpr int TAB_HANN = TAB_TW2F + 8 * 8 * 8;   // float2[512]    0.5 * Hann at samples 2n, 2n+1 (analysis; 1/2 of the split pass folded in, exact)
 constexpr int TAB_HANNI = TAB_HANN + 512 * 8;    // float2[512]    Hann / R (synthesis; the 1/R of the overlap-add folded in, exact: R = 2^k)
 constexpr int TAB_BYTES = TAB_HANNI + 512 * 8;   // 22016
-constexpr int WAVE_LDS = 9216 + 528 * 4 + 1024;  // per-wave: transposes/Y/RES | MAG/ROUTE | PSH
+constexpr int WAVE_LDS = 9216 + 528 * 4 + 1024 + 1056;  // per-wave: transposes/Y/RES | MAG/ROUTE | PSH | CLAIM
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
 template <int S_ROWS, bool ABL>
@@ -200,6 +200,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
     float *MAG = reinterpret_cast<float *>(smem + 9216);                 // MAG[4 + k], k in [-4, 524)
     unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + 9216);         // aliases MAG once the flags are taken: route of source bin b
     short *PSH = reinterpret_cast<short *>(smem + 9216 + 528 * 4);       // Math.round(p * f) per candidate peak bin p (0x7FFF: dropped)
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + 9216 + 528 * 4 + 1024);   // claim id per target bin (f < 1 scatter)
     unsigned psh_key = 0x7FC12345u;                                      // bit pattern of the f the table was built for (starts invalid)
 
     const int first_out = chunk * p.frames_per_chunk;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
         for (int r = 0; r < 8; r++) Y[l + 64 * r] = float2{0.f, 0.f};
         if (l == 0) Y[512] = float2{0.f, 0.f};
         // ---- residue above Nyquist only when the last region reads it ----
-        const bool need_res = upper_end > H;
+        const bool need_res = (upper_end > H) && !(ablate & 32);
         wave_sync();
         if (need_res) {
             // re-run fft.js's stage structure on [N/2, N) in fp32 (bundle:306-442) -- rare path, LDS/global based
@@ -454,12 +455,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
         }
         // ---- shiftPeaks (pv:119-173): each lane moves its own source bins (registers) along the precomputed routes ----
         {
-            // For f >= 1, delta_i = round(p_i f) - p_i is non-decreasing in i, so the shifted regions stay disjoint and a plain
-            // store replaces the LDS float atomic (which serialises: it was 2/3 of all LDS cycles).
-            const bool disjoint = (pf >= 1.0);
-            auto emit = [&](unsigned route, float2 v) {
+            auto rotate = [&](unsigned route, float2 v) -> float2 {
                 const unsigned ridx = route >> 16;
-                const int tgt = (int)(route & 0xFFFFu);
                 float2 y;
                 if (R == 4) {
                     const unsigned qd = ridx >> (LOG2N - 2);               // (delta*t) mod N is a multiple of N/4: rotation = j^qd
@@ -470,26 +467,73 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
                 } else {
                     y = cmul(v, cconj(p.tw32[ridx & (N - 1)]));
                 }
-                if (route != 0xFFFFFFFFu) {
-                    if (disjoint) {
-                        Y[tgt] = y;
-                    } else {
-                        atomicAdd(&Y[tgt].x, y.x);                         // f < 1: regions compress, += collisions (pv:169-170)
-                        atomicAdd(&Y[tgt].y, y.y);
-                    }
-                }
+                return y;
             };
-            if (!(ablate & 8))
+            constexpr unsigned NOROUTE = 0xFFFFFFFFu;
+            // routes of the sources above Nyquist (rare path): all owned by the last peak (pv:133)
+            const int up_delta = need_res ? (int)PSH[last_peak < 0 ? 0 : last_peak] - last_peak : 0;
+            const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+            auto up_route = [&](int b) -> unsigned {
+                const int tgt = b + up_delta;
+                return (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+            };
+            // For f >= 1, delta_i = round(p_i f) - p_i is non-decreasing in i, so the shifted regions stay disjoint: plain stores.
+            const bool disjoint = (pf >= 1.0) || (ablate & 64);
+            if (disjoint) {
+                if (!(ablate & 8))
 #pragma unroll
-            for (int r = 0; r < 8; r++) emit(ROUTE[l + 64 * r], X32[r]);
-            if (l == 0) emit(ROUTE[512], float2{x512f, 0.f});
-            if (need_res) {
-                const int ps = (int)PSH[last_peak < 0 ? 0 : last_peak];
-                const int delta = ps - last_peak;
-                const unsigned ridx = (unsigned)((delta & (N - 1)) * tmod) & (N - 1);
-                for (int b = H + l; b < upper_end; b += 64) {
-                    const int tgt = b + delta;
-                    emit((tgt >= 0 && tgt < H) ? ((ridx << 16) | (unsigned)tgt) : 0xFFFFFFFFu, RES[b]);
+                for (int r = 0; r < 8; r++) {
+                    const unsigned rt = ROUTE[l + 64 * r];
+                    if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate(rt, X32[r]);
+                }
+                if (l == 0) { const unsigned rt = ROUTE[512]; if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate(rt, float2{x512f, 0.f}); }
+                if (need_res)                                              // only reachable with the ablation switch (f >= 1 never reads above Nyquist)
+                    for (int b = H + l; b < upper_end; b += 64) { const unsigned rt = up_route(b); if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate(rt, RES[b]); }
+            } else {
+                // f < 1: regions compress and `+=` collisions happen (pv:169-170).  LDS float atomics serialise per lane (measured: half of
+                // the frame time), so collisions are resolved by CLAIM ROUNDS instead: every pending source writes its id to CLAIM[target],
+                // the id that sticks wins the round and does a plain read-modify-write; losers retry.  Rounds = max multiplicity (2-3).
+                auto claim_rounds = [&](unsigned (&rt)[9], float2 (&ys)[9], const int (&id)[9]) {
+                    unsigned pend = 0;
+#pragma unroll
+                    for (int r = 0; r < 9; r++) pend |= (rt[r] != NOROUTE) ? (1u << r) : 0u;
+                    while (__any(pend != 0u)) {
+#pragma unroll
+                        for (int r = 0; r < 9; r++) if (pend & (1u << r)) CLAIM[rt[r] & 0xFFFFu] = (unsigned short)id[r];
+                        wave_sync();
+#pragma unroll
+                        for (int r = 0; r < 9; r++) {
+                            if (pend & (1u << r)) {
+                                const int tg = (int)(rt[r] & 0xFFFFu);
+                                if (CLAIM[tg] == (unsigned short)id[r]) {
+                                    const float2 o = Y[tg];
+                                    Y[tg] = float2{o.x + ys[r].x, o.y + ys[r].y};
+                                    pend &= ~(1u << r);
+                                }
+                            }
+                        }
+                        wave_sync();
+                    }
+                };
+                unsigned rt[9];
+                float2 ys[9];
+                int id[9];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { rt[r] = ROUTE[l + 64 * r]; ys[r] = rotate(rt[r], X32[r]); id[r] = l + 64 * r; }
+                rt[8] = (l == 0) ? ROUTE[512] : NOROUTE;
+                ys[8] = rotate(rt[8], float2{x512f, 0.f});
+                id[8] = 512;
+                claim_rounds(rt, ys, id);
+                if (need_res) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const int b = H + l + 64 * r;
+                        rt[r] = up_route(b);
+                        ys[r] = rotate(rt[r], RES[b < N ? b : N - 1]);
+                        id[r] = b;
+                    }
+                    rt[8] = NOROUTE;
+                    claim_rounds(rt, ys, id);
                 }
             }
         }
