@@ -411,8 +411,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
         if (need_res) {
             // re-run fft.js's stage structure on [N/2, N) in fp32 (bundle:306-442) -- rare path, LDS/global based
             const long s0 = (long)(m + 1) * HOP - N;
-            // base stage (radix-4, LOG2N even): blocks t in [N/8, N/4)
-            for (int t = N / 8 + l; t < N / 4; t += 64) {
+            // Quarter 3 of the top block (positions >= 3N/4, the sub-FFT of x[4n+3]) is only read when the last region moves down by
+            // more than N/4 bins (f < ~0.5): skip its whole subtree otherwise.
+            const int res_hi = (upper_end <= 3 * N / 4) ? 3 * N / 4 : N;
+            // base stage (radix-4, LOG2N even): blocks t in [N/8, res_hi/4)
+            for (int t = N / 8 + l; t < res_hi / 4; t += 64) {
                 unsigned rv = __brev((unsigned)t) >> (32 - 8);
                 const int off = (int)(((rv & 0x55555555u) << 1) | ((rv >> 1) & 0x55555555u));
                 const float a = src.at(s0 + off) * p.hann[off];
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
             wave_sync();
             for (int log2m = 4; log2m <= LOG2N - 2; log2m += 2) {
                 const int Mb = 1 << log2m, q = Mb >> 2, hq = q >> 1;
-                const int nblocks = (N / 2) >> log2m;
+                const int nblocks = (res_hi - N / 2) >> log2m;
                 const int tws = LOG2N - log2m;
                 const int total = nblocks * (hq + 1);
                 for (int it = l; it < total; it += 64) {
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
                 }
                 wave_sync();
             }
-            if (dbg) for (int k = H + l; k < N; k += 64) { p.dbg_X[2 * k] = RES[k].x; p.dbg_X[2 * k + 1] = RES[k].y; }
+            if (dbg) for (int k = H + l; k < res_hi; k += 64) { p.dbg_X[2 * k] = RES[k].x; p.dbg_X[2 * k + 1] = RES[k].y; }
         }
         // ---- shiftPeaks (pv:119-173): each lane moves its own source bins (registers) along the precomputed routes ----
         {
