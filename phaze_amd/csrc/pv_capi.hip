@@ -71,11 +71,26 @@ bool live(const pv_handle *h) { return h && h->magic == kMagic; }
 int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
 {
     if (h->frames_per_chunk_cfg > 0) return h->frames_per_chunk_cfg;
-    int F = 24 * h->R;                       // halo overhead (R-1)/F ~ 3 % when the launch is big enough
-    const long want = 8L * h->cus;           // enough workgroups to fill every CU several times
-    while (F > h->R && (long)nch * ((nhops + F - 1) / F) < want) F >>= 1;
-    if (F < 1) F = 1;
-    return F;
+    // Trade-off: long chains amortise the (R-1)-frame halo, but the last partial round of workgroups idles the chip.
+    // resident = chains the GPU runs concurrently (wave kernel: 8 per CU; generic: LDS-limited workgroups per CU).
+    long per_cu;
+    if (h->use_wave) per_cu = 8;
+    else { per_cu = (160 * 1024) / (long)pv_kernel_lds_bytes(h->log2n, h->hop); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1; }
+    const long resident = per_cu * h->cus;
+    const int R = h->R;
+    int best = R > 1 ? R : 1;
+    double best_eff = -1.0;
+    for (int F = 48 * R; F >= (R > 1 ? R : 1); F -= (F > 8 * R ? R : 1)) {
+        if (F > nhops && F > R) continue;
+        const long chains = (long)nch * ((nhops + F - 1) / F);
+        const long rounds = (chains + resident - 1) / resident;
+        const double fill = (double)chains / (double)(rounds * resident);        // tail effect
+        const double halo = (double)F / (double)(F + R - 1);                     // recomputed frames
+        const double eff = fill * halo;
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = F; }
+    }
+    if (best > nhops) best = nhops;
+    return best < 1 ? 1 : best;
 }
 
 // One launch over [nch] channel slots x [nhops] hops; flips the state ping-pong and advances timeCursor.
