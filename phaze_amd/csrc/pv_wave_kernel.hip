@@ -148,10 +148,11 @@ constexpr int TAB_BYTES = TAB_HANNI + 512 * 8;   // 22016
 constexpr int WAVE_LDS = 9216 + 528 * 4 + 1024 + 1056;  // per-wave: transposes/Y/RES | MAG/ROUTE | PSH | CLAIM
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
-template <int S_ROWS, bool ABL>
+// AUX = true: test-tap / phase-ablation build (pv_debug_frame, PHAZE_ABLATE); the production instance carries neither.
+template <int S_ROWS, bool AUX>
 __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKernelParams p)
 {
-    const int ablate = ABL ? p.ablate : 0;                                // phase-ablation build (profiling only); folds away otherwise
+    const int ablate = AUX ? p.ablate : 0;                                // phase-ablation build (profiling only); folds away otherwise
     constexpr int N = 1024, M = 512, H = 513, LOG2N = 10;
     constexpr int HOP = 128 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;    // LROWS rows of carried accumulator
     constexpr int BIG = 1 << 30;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
     for (int m = first_frame; m < last_out; ++m) {
         const double pf = (double)pitch_row[m];
         const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
-        const bool dbg = (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
+        const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
 
         // prefetch the rows the NEXT frame slides in
         float2 nxt_raw[S_ROWS];
@@ -607,11 +608,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
     }
 }
 
-template <int S_ROWS, bool ABL>
+template <int S_ROWS, bool AUX>
 hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
     static bool attr_done[16] = {};
-    auto k = pv_wave_kernel_1024<S_ROWS, ABL>;
+    auto k = pv_wave_kernel_1024<S_ROWS, AUX>;
     int dev = 0;
     hipGetDevice(&dev);
     if (!attr_done[dev & 15]) {
@@ -635,11 +636,12 @@ bool pv_wave_supported(int log2n, int hop) { return log2n == 10 && (hop == 128 |
 
 hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
+    const bool aux = (p.ablate != 0) || (p.dbg_mag != nullptr);
     switch (p.hop) {
-    case 128: return launch_wave<1, false>(p, nch, nchunks, st);
-    case 256: return p.ablate ? launch_wave<2, true>(p, nch, nchunks, st) : launch_wave<2, false>(p, nch, nchunks, st);
-    case 512: return launch_wave<4, false>(p, nch, nchunks, st);
-    case 1024: return launch_wave<8, false>(p, nch, nchunks, st);
+    case 128: return aux ? launch_wave<1, true>(p, nch, nchunks, st) : launch_wave<1, false>(p, nch, nchunks, st);
+    case 256: return aux ? launch_wave<2, true>(p, nch, nchunks, st) : launch_wave<2, false>(p, nch, nchunks, st);
+    case 512: return aux ? launch_wave<4, true>(p, nch, nchunks, st) : launch_wave<4, false>(p, nch, nchunks, st);
+    case 1024: return aux ? launch_wave<8, true>(p, nch, nchunks, st) : launch_wave<8, false>(p, nch, nchunks, st);
     default: return hipErrorInvalidValue;
     }
 }
