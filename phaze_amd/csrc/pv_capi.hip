@@ -74,7 +74,7 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
     // Trade-off: long chains amortise the (R-1)-frame halo, but the last partial round of workgroups idles the chip.
     // resident = chains the GPU runs concurrently (wave kernel: 8 per CU; generic: LDS-limited workgroups per CU).
     long per_cu;
-    if (h->use_wave) per_cu = 8;
+    if (h->use_wave) per_cu = 12;
     else { per_cu = (160 * 1024) / (long)pv_kernel_lds_bytes(h->log2n, h->hop); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1; }
     const long resident = per_cu * h->cus;
     const int R = h->R;

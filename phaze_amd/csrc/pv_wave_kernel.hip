@@ -128,6 +128,10 @@ __device__ __forceinline__ void fft512_wave(typename v2t<T>::type (&a)[8], typen
     radix8<T, INV>(a);
 }
 
+
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+
+
 struct WaveSrc {
     const float *in;
     const float *hist;
@@ -135,9 +139,133 @@ struct WaveSrc {
     __device__ __forceinline__ float at(long s) const { return s < 0 ? hist[s + hist_len] : in[s]; }
 };
 
-__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+constexpr unsigned NOROUTE = 0xFFFFFFFFu;        // route = (rotation index << 16) | target bin
 
-constexpr int WAVES = 4;                         // independent frame chains per workgroup (they only share the LDS tables)
+// Rotation exp(+2 pi j ridx / N) of one source value (pv:155-170).  R = 4: (delta * t) mod N is a multiple of N/4, so the rotation is
+// j^qd exactly: a swap and two sign-bit XORs (j^1 = (-y, x), j^2 = (-x, -y), j^3 = (y, -x)).
+template <int R_>
+__device__ __forceinline__ float2 rotate_route(unsigned route, float2 v, const float2 *__restrict__ tw32)
+{
+    const unsigned ridx = route >> 16;
+    if (R_ == 4) {
+        const unsigned qd = ridx >> 8;
+        const bool sw = (qd & 1u) != 0u;
+        const float a = sw ? v.y : v.x, b = sw ? v.x : v.y;
+        return float2{__uint_as_float(__float_as_uint(a) ^ ((((qd + 1u) >> 1) & 1u) << 31)), __uint_as_float(__float_as_uint(b) ^ ((qd >> 1) << 31))};
+    }
+    return cmul(v, cconj(tw32[ridx & 1023u]));
+}
+
+// f < 1: regions compress and `+=` collisions happen (pv:169-170).  LDS float atomics serialise per lane (measured: half of the frame
+// time), so collisions are resolved by CLAIM ROUNDS: every pending source writes its id to CLAIM[target], the id that sticks wins the
+// round and does a plain read-modify-write on Y; losers retry.  Rounds = max multiplicity of a target (2-3 for f >= 0.3).
+template <int NS>
+__device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned short *CLAIM)
+{
+    unsigned pend = 0;
+#pragma unroll
+    for (int r = 0; r < NS; r++) pend |= (rt[r] != NOROUTE) ? (1u << r) : 0u;
+    while (__any(pend != 0u)) {
+#pragma unroll
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[rt[r] & 0xFFFFu] = (unsigned short)id[r];
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < NS; r++) {
+            if (pend & (1u << r)) {
+                const int tg = (int)(rt[r] & 0xFFFFu);
+                if (CLAIM[tg] == (unsigned short)id[r]) {
+                    const float2 o = Y[tg];
+                    Y[tg] = float2{o.x + ys[r].x, o.y + ys[r].y};
+                    pend &= ~(1u << r);
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// per-wave LDS region (byte offsets): see the carve in the kernel
+constexpr int OFF_Y = 0;            // float2[513]   shifted spectrum
+constexpr int OFF_ROUTE = 4112;     // u32[528] routes | f32 mags (alias) | u16 claim ids (alias, after the routes are in registers)
+constexpr int OFF_RESQ = 6224;      // float2[256]   one quarter of the above-Nyquist residue at a time
+constexpr int OFF_PSH = 9216;       // i16[512]      Math.round(p * f) table
+constexpr int WAVE_LDS = 9216 + 1024;
+
+// Rare path (f < 1 frames whose last region reads above Nyquist): rebuild what fft.js's in-place real DIT leaves at positions
+// N/2+1..N-1 -- one quarter of the buffer at a time (quarter 2 = sub-FFT of x[4n+2], positions 512..767; quarter 3 = x[4n+3], 768..1023),
+// by re-running the reference's stage structure (bundle:306-442,468-508) on that quarter in fp32 -- and add those sources into Y.
+// Kept out of line so that its registers do not count against the main pipeline (3 waves per SIMD need <= 168 VGPRs).
+template <int R_>
+__device__ __attribute__((noinline)) void residue_scatter_1024(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
+                                                               const float2 *__restrict__ tw32, unsigned wave_off, int l, int upper_end, int up_delta,
+                                                               unsigned up_ridx, double *dbg_X)
+{
+    constexpr int N = 1024, H = 513;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    float2 *Y = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_Y);
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + OFF_ROUTE);
+    float2 *Q = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_RESQ);
+    const WaveSrc src{in, hist, hist_len};
+    for (int base = N / 2; base < N && base < upper_end; base += N / 4) {
+        {   // base stage: radix-4 blocks t = base/4 + l (bundle:468-508), input index = base-4 digit reversal of t
+            const int t = base / 4 + l;
+            const unsigned rv = __brev((unsigned)t) >> (32 - 8);
+            const int off = (int)(((rv & 0x55555555u) << 1) | ((rv >> 1) & 0x55555555u));
+            const float a = src.at(s0 + off) * hann[off];
+            const float b = src.at(s0 + off + N / 4) * hann[off + N / 4];
+            const float c = src.at(s0 + off + N / 2) * hann[off + N / 2];
+            const float d = src.at(s0 + off + 3 * N / 4) * hann[off + 3 * N / 4];
+            const float t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+            Q[4 * l] = float2{t0 + t2, 0.f};
+            Q[4 * l + 1] = float2{t1, -t3};
+            Q[4 * l + 2] = float2{t0 - t2, 0.f};
+            Q[4 * l + 3] = float2{t1, t3};
+        }
+        wave_sync();
+#pragma unroll
+        for (int log2m = 4; log2m <= 8; log2m += 2) {                     // block sizes 16, 64, 256 inside the quarter (bundle:329-441)
+            const int q = (1 << log2m) >> 2, hq = q >> 1;                 // butterflies i = 0..hq per block
+            const int nblocks = 256 >> log2m;
+            const int tws = 10 - log2m;                                    // W_Mb^i = tw[i << tws]
+            const int it = l;
+            if (it < nblocks * (hq + 1)) {
+                int blk, i;
+                if (it < nblocks * hq) { blk = it / hq; i = it - blk * hq; } else { blk = it - nblocks * hq; i = hq; }
+                const int o = blk << log2m;
+                const float2 A = Q[o + i];
+                const float2 Bv = cmul(Q[o + q + i], tw32[i << tws]);
+                const float2 C = cmul(Q[o + 2 * q + i], tw32[(2 * i) << tws]);
+                const float2 D = cmul(Q[o + 3 * q + i], tw32[(3 * i) << tws]);
+                const float2 T0 = cadd(A, C), T1 = csub(A, C), T2 = cadd(Bv, D), T3 = csub(Bv, D);
+                Q[o + i] = cadd(T0, T2);
+                Q[o + q + i] = float2{T1.x + T3.y, T1.y - T3.x};          // T1 - j T3
+                if (i == 0) {
+                    Q[o + 2 * q] = csub(T0, T2);                          // bundle:400-406
+                } else if (i != hq) {                                     // bundle:409-440
+                    Q[o + q - i] = float2{T1.x - T3.y, -(T1.y + T3.x)};   // conj(T1 + j T3)
+                    Q[o + 2 * q - i] = float2{T0.x - T2.x, -(T0.y - T2.y)};
+                }
+            }
+            wave_sync();
+        }
+        if (dbg_X)
+            for (int i = l; i < N / 4; i += 64) if (base + i >= H) { dbg_X[2 * (base + i)] = Q[i].x; dbg_X[2 * (base + i) + 1] = Q[i].y; }
+        // the sources of this quarter, all owned by the last peak (pv:133): b -> b + up_delta
+        unsigned rt[4];
+        float2 ys[4];
+        int id[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int b = base + l + 64 * j, tgt = b + up_delta;
+            rt[j] = (b >= H && b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+            ys[j] = rotate_route<R_>(rt[j], Q[l + 64 * j], tw32);
+            id[j] = b;
+        }
+        claim_rounds<4>(rt, ys, id, Y, CLAIM);
+    }
+}
+
+constexpr int WAVES = 12;                        // independent frame chains per workgroup (they only share the LDS tables)
 constexpr int TAB_TW1 = 0;                       // double2[8*64]  W_512^{l k}
 constexpr int TAB_TW2 = TAB_TW1 + 8 * 64 * 16;   // double2[8*8]   W_64^{n0 k}
 constexpr int TAB_TW1F = TAB_TW2 + 8 * 8 * 16;   // float2[8*64]   conj, fp32 (inverse)
@@ -145,12 +273,11 @@ constexpr int TAB_TW2F = TAB_TW1F + 8 * 64 * 8;  // float2[8*8]
 constexpr int TAB_HANN = TAB_TW2F + 8 * 8 * 8;   // float2[512]    0.5 * Hann at samples 2n, 2n+1 (analysis; 1/2 of the split pass folded in, exact)
 constexpr int TAB_HANNI = TAB_HANN + 512 * 8;    // float2[512]    Hann / R (synthesis; the 1/R of the overlap-add folded in, exact: R = 2^k)
 constexpr int TAB_BYTES = TAB_HANNI + 512 * 8;   // 22016
-constexpr int WAVE_LDS = 9216 + 528 * 4 + 1024 + 1056;  // per-wave: transposes/Y/RES | MAG/ROUTE | PSH | CLAIM
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
 // AUX = true: test-tap / phase-ablation build (pv_debug_frame, PHAZE_ABLATE); the production instance carries neither.
 template <int S_ROWS, bool AUX>
-__global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKernelParams p)
+__global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKernelParams p)
 {
     const int ablate = AUX ? p.ablate : 0;                                // phase-ablation build (profiling only); folds away otherwise
     constexpr int N = 1024, M = 512, H = 513, LOG2N = 10;
@@ -193,15 +320,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
     __syncthreads();                                                     // the only workgroup-wide barrier
     if (chunk >= p.nchunks) return;
 
-    unsigned char *smem = smem_all + TAB_BYTES + wv * WAVE_LDS;
-    double2 *S64 = reinterpret_cast<double2 *>(smem);                    // 8*72*16 = 9216 B: fp64 transposes
+    const unsigned wave_off = TAB_BYTES + wv * WAVE_LDS;
+    unsigned char *smem = smem_all + wave_off;
+    double2 *S64 = reinterpret_cast<double2 *>(smem);                    // 8*72*16 = 9216 B: fp64 transposes (whole scratch)
     float2 *S32 = reinterpret_cast<float2 *>(smem);                      // fp32 transposes (first 4608 B)
-    float2 *Y = reinterpret_cast<float2 *>(smem);                        // shifted spectrum Y[0..512] (4104 B), between the FFTs
-    float2 *RES = reinterpret_cast<float2 *>(smem + 4112) - M;           // residue float2 positions [512, 1024) -> smem[4112, 8208)
-    float *MAG = reinterpret_cast<float *>(smem + 9216);                 // MAG[4 + k], k in [-4, 524)
-    unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + 9216);         // aliases MAG once the flags are taken: route of source bin b
-    short *PSH = reinterpret_cast<short *>(smem + 9216 + 528 * 4);       // Math.round(p * f) per candidate peak bin p (0x7FFF: dropped)
-    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + 9216 + 528 * 4 + 1024);   // claim id per target bin (f < 1 scatter)
+    float2 *Y = reinterpret_cast<float2 *>(smem + OFF_Y);                // shifted spectrum Y[0..512], between the FFTs
+    float *MAG = reinterpret_cast<float *>(smem + OFF_ROUTE);            // MAG[4 + k], k in [-4, 524): |X|^2 exchange
+    unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + OFF_ROUTE);    // aliases MAG once the flags are taken: route of source bin b
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + OFF_ROUTE);   // aliases ROUTE once the routes are in registers (f < 1)
+    short *PSH = reinterpret_cast<short *>(smem + OFF_PSH);              // Math.round(p * f) per candidate peak bin p (0x7FFF: dropped)
     unsigned psh_key = 0x7FC12345u;                                      // bit pattern of the f the table was built for (starts invalid)
 
     const int first_out = chunk * p.frames_per_chunk;
@@ -233,32 +360,28 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
         }
     }
 
-    // ---- raw input window in registers ----
-    float2 raw[8];
-    {
-        const long s0 = (long)(first_frame + 1) * HOP - N;
+    // ---- raw input window: 8 rows of (2 samples x 64 lanes).  The next frame's window is (re)loaded while the fp32 half of the
+    //      pipeline runs (the overlapping 3/4 comes from L2), so no input registers are live during the fp64 FFT ----
+    auto load_window = [&](float2 (&w)[8], int frame) {
+        const long s0 = (long)(frame + 1) * HOP - N + 2 * l;
+        if (vec_in) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) raw[r] = float2{src.at(s0 + 2 * l + 128 * r), src.at(s0 + 2 * l + 128 * r + 1)};
-    }
+            for (int r = 0; r < 8; r++) {
+                const long sx = s0 + 128 * r;
+                w[r] = *reinterpret_cast<const float2 *>(sx < 0 ? src.hist + sx + src.hist_len : src.in + sx);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) w[r] = float2{src.at(s0 + 128 * r), src.at(s0 + 128 * r + 1)};
+        }
+    };
+    float2 raw[8];
+    load_window(raw, first_frame);
 
     for (int m = first_frame; m < last_out; ++m) {
         const double pf = (double)pitch_row[m];
         const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
         const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
-
-        // prefetch the rows the NEXT frame slides in
-        float2 nxt_raw[S_ROWS];
-        {
-            const long s1 = (long)(m + 2) * HOP - N;
-            const bool more = (m + 1 < last_out);
-#pragma unroll
-            for (int r = 0; r < S_ROWS; r++) {
-                const long s = s1 + 2 * l + 128 * (8 - S_ROWS + r);
-                if (!more) nxt_raw[r] = float2{0.f, 0.f};
-                else if (vec_in) nxt_raw[r] = *reinterpret_cast<const float2 *>(s < 0 ? src.hist + s + src.hist_len : src.in + s);   // s is even
-                else nxt_raw[r] = float2{src.at(s), src.at(s + 1)};
-            }
-        }
 
         // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded into the table (exact) ----
         double2 z[8];
@@ -306,6 +429,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
                 if (l == 0) { p.dbg_X[2 * 512] = x512; p.dbg_X[2 * 512 + 1] = 0.0; }
             }
         }
+        // next frame's window: issued here, consumed at the top of the next iteration (latency hidden behind the shift + inverse FFT)
+        if (m + 1 < last_out) load_window(raw, m + 1);
         // ---- Math.round(peak * f) (pv:125) for every possible peak bin, cached while f does not change ----
         {
             const unsigned pfb = __float_as_uint(pitch_row[m]);
@@ -409,78 +534,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
         // ---- residue above Nyquist only when the last region reads it ----
         const bool need_res = (upper_end > H) && !(ablate & 32);
         wave_sync();
-        if (need_res) {
-            // re-run fft.js's stage structure on [N/2, N) in fp32 (bundle:306-442) -- rare path, LDS/global based
-            const long s0 = (long)(m + 1) * HOP - N;
-            // Quarter 3 of the top block (positions >= 3N/4, the sub-FFT of x[4n+3]) is only read when the last region moves down by
-            // more than N/4 bins (f < ~0.5): skip its whole subtree otherwise.
-            const int res_hi = (upper_end <= 3 * N / 4) ? 3 * N / 4 : N;
-            // base stage (radix-4, LOG2N even): blocks t in [N/8, res_hi/4)
-            for (int t = N / 8 + l; t < res_hi / 4; t += 64) {
-                unsigned rv = __brev((unsigned)t) >> (32 - 8);
-                const int off = (int)(((rv & 0x55555555u) << 1) | ((rv >> 1) & 0x55555555u));
-                const float a = src.at(s0 + off) * p.hann[off];
-                const float b = src.at(s0 + off + N / 4) * p.hann[off + N / 4];
-                const float c = src.at(s0 + off + N / 2) * p.hann[off + N / 2];
-                const float d = src.at(s0 + off + 3 * N / 4) * p.hann[off + 3 * N / 4];
-                const float t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
-                RES[4 * t] = float2{t0 + t2, 0.f};
-                RES[4 * t + 1] = float2{t1, -t3};
-                RES[4 * t + 2] = float2{t0 - t2, 0.f};
-                RES[4 * t + 3] = float2{t1, t3};
-            }
-            wave_sync();
-            for (int log2m = 4; log2m <= LOG2N - 2; log2m += 2) {
-                const int Mb = 1 << log2m, q = Mb >> 2, hq = q >> 1;
-                const int nblocks = (res_hi - N / 2) >> log2m;
-                const int tws = LOG2N - log2m;
-                const int total = nblocks * (hq + 1);
-                for (int it = l; it < total; it += 64) {
-                    int blk, i;
-                    if (it < nblocks * hq) { blk = it / hq; i = it - blk * hq; } else { blk = it - nblocks * hq; i = hq; }
-                    const int o = N / 2 + (blk << log2m);
-                    const float2 A = RES[o + i];
-                    const float2 Bv = cmul(RES[o + q + i], p.tw32[i << tws]);
-                    const float2 C = cmul(RES[o + 2 * q + i], p.tw32[(2 * i) << tws]);
-                    const float2 D = cmul(RES[o + 3 * q + i], p.tw32[(3 * i) << tws]);
-                    const float2 T0 = cadd(A, C), T1 = csub(A, C), T2 = cadd(Bv, D), T3 = csub(Bv, D);
-                    RES[o + i] = cadd(T0, T2);
-                    RES[o + q + i] = float2{T1.x + T3.y, T1.y - T3.x};
-                    if (i == 0) {
-                        RES[o + 2 * q] = csub(T0, T2);
-                    } else if (i != hq) {
-                        RES[o + q - i] = float2{T1.x - T3.y, -(T1.y + T3.x)};
-                        RES[o + 2 * q - i] = float2{T0.x - T2.x, -(T0.y - T2.y)};
-                    }
-                }
-                wave_sync();
-            }
-            if (dbg) for (int k = H + l; k < res_hi; k += 64) { p.dbg_X[2 * k] = RES[k].x; p.dbg_X[2 * k + 1] = RES[k].y; }
-        }
         // ---- shiftPeaks (pv:119-173): each lane moves its own source bins (registers) along the precomputed routes ----
         {
-            auto rotate = [&](unsigned route, float2 v) -> float2 {
-                const unsigned ridx = route >> 16;
-                float2 y;
-                if (R == 4) {
-                    const unsigned qd = ridx >> (LOG2N - 2);               // (delta*t) mod N is a multiple of N/4: rotation = j^qd
-                    const bool sw = (qd & 1u) != 0u;                       // j^1 = (-y, x), j^2 = (-x, -y), j^3 = (y, -x)
-                    const float a = sw ? v.y : v.x, b = sw ? v.x : v.y;
-                    y.x = __uint_as_float(__float_as_uint(a) ^ ((((qd + 1u) >> 1) & 1u) << 31));
-                    y.y = __uint_as_float(__float_as_uint(b) ^ ((qd >> 1) << 31));
-                } else {
-                    y = cmul(v, cconj(p.tw32[ridx & (N - 1)]));
-                }
-                return y;
-            };
-            constexpr unsigned NOROUTE = 0xFFFFFFFFu;
-            // routes of the sources above Nyquist (rare path): all owned by the last peak (pv:133)
-            const int up_delta = need_res ? (int)PSH[last_peak < 0 ? 0 : last_peak] - last_peak : 0;
-            const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
-            auto up_route = [&](int b) -> unsigned {
-                const int tgt = b + up_delta;
-                return (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
-            };
             // For f >= 1, delta_i = round(p_i f) - p_i is non-decreasing in i, so the shifted regions stay disjoint: plain stores.
             const bool disjoint = (pf >= 1.0) || (ablate & 64);
             if (disjoint) {
@@ -488,56 +543,25 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const unsigned rt = ROUTE[l + 64 * r];
-                    if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate(rt, X32[r]);
+                    if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R>(rt, X32[r], p.tw32);
                 }
-                if (l == 0) { const unsigned rt = ROUTE[512]; if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate(rt, float2{x512f, 0.f}); }
-                if (need_res)                                              // only reachable with the ablation switch (f >= 1 never reads above Nyquist)
-                    for (int b = H + l; b < upper_end; b += 64) { const unsigned rt = up_route(b); if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate(rt, RES[b]); }
+                if (l == 0) { const unsigned rt = ROUTE[512]; if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R>(rt, float2{x512f, 0.f}, p.tw32); }
             } else {
-                // f < 1: regions compress and `+=` collisions happen (pv:169-170).  LDS float atomics serialise per lane (measured: half of
-                // the frame time), so collisions are resolved by CLAIM ROUNDS instead: every pending source writes its id to CLAIM[target],
-                // the id that sticks wins the round and does a plain read-modify-write; losers retry.  Rounds = max multiplicity (2-3).
-                auto claim_rounds = [&](unsigned (&rt)[9], float2 (&ys)[9], const int (&id)[9]) {
-                    unsigned pend = 0;
-#pragma unroll
-                    for (int r = 0; r < 9; r++) pend |= (rt[r] != NOROUTE) ? (1u << r) : 0u;
-                    while (__any(pend != 0u)) {
-#pragma unroll
-                        for (int r = 0; r < 9; r++) if (pend & (1u << r)) CLAIM[rt[r] & 0xFFFFu] = (unsigned short)id[r];
-                        wave_sync();
-#pragma unroll
-                        for (int r = 0; r < 9; r++) {
-                            if (pend & (1u << r)) {
-                                const int tg = (int)(rt[r] & 0xFFFFu);
-                                if (CLAIM[tg] == (unsigned short)id[r]) {
-                                    const float2 o = Y[tg];
-                                    Y[tg] = float2{o.x + ys[r].x, o.y + ys[r].y};
-                                    pend &= ~(1u << r);
-                                }
-                            }
-                        }
-                        wave_sync();
-                    }
-                };
                 unsigned rt[9];
                 float2 ys[9];
                 int id[9];
 #pragma unroll
-                for (int r = 0; r < 8; r++) { rt[r] = ROUTE[l + 64 * r]; ys[r] = rotate(rt[r], X32[r]); id[r] = l + 64 * r; }
+                for (int r = 0; r < 8; r++) { rt[r] = ROUTE[l + 64 * r]; ys[r] = rotate_route<R>(rt[r], X32[r], p.tw32); id[r] = l + 64 * r; }
                 rt[8] = (l == 0) ? ROUTE[512] : NOROUTE;
-                ys[8] = rotate(rt[8], float2{x512f, 0.f});
+                ys[8] = rotate_route<R>(rt[8], float2{x512f, 0.f}, p.tw32);
                 id[8] = 512;
-                claim_rounds(rt, ys, id);
-                if (need_res) {
-#pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        const int b = H + l + 64 * r;
-                        rt[r] = up_route(b);
-                        ys[r] = rotate(rt[r], RES[b < N ? b : N - 1]);
-                        id[r] = b;
-                    }
-                    rt[8] = NOROUTE;
-                    claim_rounds(rt, ys, id);
+                wave_sync();                                               // routes are in registers: CLAIM may overwrite ROUTE
+                claim_rounds<9>(rt, ys, id, Y, CLAIM);
+                if (need_res) {                                            // sources above Nyquist, all owned by the last peak (pv:133)
+                    const int up_delta = (int)PSH[last_peak < 0 ? 0 : last_peak] - last_peak;
+                    const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+                    residue_scatter_1024<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, wave_off, l, upper_end, up_delta,
+                                            up_ridx, dbg ? p.dbg_X : nullptr);
                 }
             }
         }
@@ -589,11 +613,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void pv_wave_kernel_1024(const PvKer
                 acc[r] = (s < LROWS) ? float2{acc[s].x + fr[s].x, acc[s].y + fr[s].y} : fr[s];
             }
         }
-        // ---- slide the raw window ----
-#pragma unroll
-        for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
-#pragma unroll
-        for (int r = 0; r < S_ROWS; r++) raw[8 - S_ROWS + r] = nxt_raw[r];
     }
 
     if (chunk == p.nchunks - 1) {
