@@ -7,6 +7,7 @@ if libphaze_amd.so cannot be loaded, or no HIP device exists, construction raise
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -57,6 +58,15 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64; two HIP runtimes in one process cannot both open the GPU ("no ROCm-capable
+    # device").  If torch is installed, load it FIRST so that this library binds to the runtime torch already mapped (same SONAME).
+    if "torch" not in sys.modules and not os.environ.get("PHAZE_NO_TORCH_PRELOAD"):
+        try:
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(_LIB_PATH):
         raise PvError(PV_ERR_DEVICE, f"{_LIB_PATH} is missing: build it with phaze_amd.build_library() / __graft_entry__.build(); "
                                      "there is no CPU fallback")

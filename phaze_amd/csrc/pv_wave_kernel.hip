@@ -22,6 +22,8 @@
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));   // clang vector type (the nontemporal builtins need one)
+
 template <typename T> struct v2t;
 template <> struct v2t<float> { using type = float2; };
 template <> struct v2t<double> { using type = double2; };
@@ -360,23 +362,19 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
         }
     }
 
-    // ---- raw input window: 8 rows of (2 samples x 64 lanes).  The next frame's window is (re)loaded while the fp32 half of the
-    //      pipeline runs (the overlapping 3/4 comes from L2), so no input registers are live during the fp64 FFT ----
-    auto load_window = [&](float2 (&w)[8], int frame) {
+    // ---- raw input window in registers: 8 rows of (2 samples x 64 lanes); a frame advances by S_ROWS rows, so only those rows are
+    //      loaded per frame (prefetched one frame ahead) and every input sample is fetched from HBM once ----
+    auto load_rows = [&](float2 *w, int nrows, int first_row, int frame) {
         const long s0 = (long)(frame + 1) * HOP - N + 2 * l;
-        if (vec_in) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const long sx = s0 + 128 * r;
-                w[r] = *reinterpret_cast<const float2 *>(sx < 0 ? src.hist + sx + src.hist_len : src.in + sx);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; r++) w[r] = float2{src.at(s0 + 128 * r), src.at(s0 + 128 * r + 1)};
+        for (int r = 0; r < nrows; r++) {
+            const long sx = s0 + 128 * (first_row + r);
+            if (vec_in) w[r] = *reinterpret_cast<const float2 *>(sx < 0 ? src.hist + sx + src.hist_len : src.in + sx);
+            else w[r] = float2{src.at(sx), src.at(sx + 1)};
         }
     };
     float2 raw[8];
-    load_window(raw, first_frame);
+    load_rows(raw, 8, 0, first_frame);
 
     for (int m = first_frame; m < last_out; ++m) {
         const double pf = (double)pitch_row[m];
@@ -429,8 +427,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
                 if (l == 0) { p.dbg_X[2 * 512] = x512; p.dbg_X[2 * 512 + 1] = 0.0; }
             }
         }
-        // next frame's window: issued here, consumed at the top of the next iteration (latency hidden behind the shift + inverse FFT)
-        if (m + 1 < last_out) load_window(raw, m + 1);
+        // slide the window: the rows the next frame adds are issued here and land behind the shift + inverse FFT
+#pragma unroll
+        for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
+        if (m + 1 < last_out) load_rows(&raw[8 - S_ROWS], S_ROWS, 8 - S_ROWS, m + 1);
         // ---- Math.round(peak * f) (pv:125) for every possible peak bin, cached while f does not change ----
         {
             const unsigned pfb = __float_as_uint(pitch_row[m]);
@@ -603,8 +603,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
                 const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
                 if (emit_out) {
                     float *dst = outp + (long)m * HOP + 2 * l + 128 * r;
-                    if (vec_out) *reinterpret_cast<float2 *>(dst) = o;
-                    else { dst[0] = o.x; dst[1] = o.y; }
+                    // streaming output: non-temporal, so the 1 GB/launch of results does not evict the input windows the next
+                    // frames re-read from L2
+                    if (vec_out) __builtin_nontemporal_store(v2f{o.x, o.y}, reinterpret_cast<v2f *>(dst));
+                    else { __builtin_nontemporal_store(o.x, dst); __builtin_nontemporal_store(o.y, dst + 1); }
                 }
             }
 #pragma unroll
