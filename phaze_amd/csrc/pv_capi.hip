@@ -40,6 +40,7 @@ struct pv_handle {
     int64_t time_cursor;
     int active_nch;
     bool use_wave;                               // N = 1024: wave-per-frame kernel (pv_wave_kernel.hip)
+    bool use_wg;                                 // N = 2048..8192, R <= 8: register-resident workgroup kernel (pv_wg_kernel.hip)
     char devname[64];
     char err[256];
 };
@@ -75,6 +76,7 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
     // resident = chains the GPU runs concurrently (wave kernel: 8 per CU; generic: LDS-limited workgroups per CU).
     long per_cu;
     if (h->use_wave) per_cu = 12;
+    else if (h->use_wg) { per_cu = (160 * 1024) / (long)pv_wg_lds_bytes(h->log2n); if (per_cu < 1) per_cu = 1; }
     else { per_cu = (160 * 1024) / (long)pv_kernel_lds_bytes(h->log2n, h->hop); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1; }
     const long resident = per_cu * h->cus;
     const int R = h->R;
@@ -112,7 +114,9 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     if (dbg_ch >= 0) { p.dbg_X = h->d_dbgX; p.dbg_mag = h->d_dbgMag; p.dbg_flags = h->d_dbgFlags; p.dbg_Y = h->d_dbgY; p.dbg_ch = dbg_ch; p.dbg_frame = 0; }
     const int nchunks = (nhops + p.frames_per_chunk - 1) / p.frames_per_chunk;
     h->last_frames_per_chunk = p.frames_per_chunk;
-    hipError_t e = h->use_wave ? pv_launch_wave(p, nch, nchunks, h->stream) : pv_launch_chain(h->log2n, p, nch, nchunks, h->stream);
+    hipError_t e = h->use_wave ? pv_launch_wave(p, nch, nchunks, h->stream)
+                 : h->use_wg ? pv_launch_wg(h->log2n, p, nch, nchunks, h->stream)
+                             : pv_launch_chain(h->log2n, p, nch, nchunks, h->stream);
     if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
     if (commit) {
         // channels outside [0, nch) keep their state: copy them across the ping-pong flip
@@ -179,6 +183,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     {
         const char *g = getenv("PHAZE_GENERIC_KERNEL");      // A/B switch for tests and profiling
         h->use_wave = pv_wave_supported(log2n, hop) && !(g && g[0] == '1');
+        h->use_wg = pv_wg_supported(log2n, hop) && !(g && g[0] == '1');
     }
 #define CHK(call)                                                          \
     do {                                                                   \
@@ -266,9 +271,9 @@ int pv_get_info(const pv_handle *h, pv_info *out)
     memset(out, 0, sizeof *out);
     out->fft_size = h->N; out->hop_size = h->hop; out->overlaps = h->R;
     out->max_channels = h->max_channels; out->max_hops = h->max_hops;
-    out->threads_per_workgroup = h->use_wave ? pv_wave_threads() : pv_kernel_threads(h->log2n);
-    snprintf(out->kernel_name, sizeof out->kernel_name, "%s", h->use_wave ? "pv_wave_kernel_1024" : "pv_chain_kernel");
-    out->lds_bytes_per_workgroup = (int32_t)(h->use_wave ? pv_wave_lds_bytes() : pv_kernel_lds_bytes(h->log2n, h->hop));
+    out->threads_per_workgroup = h->use_wave ? pv_wave_threads() : h->use_wg ? pv_wg_threads(h->log2n) : pv_kernel_threads(h->log2n);
+    snprintf(out->kernel_name, sizeof out->kernel_name, "%s", h->use_wave ? "pv_wave_kernel_1024" : h->use_wg ? "pv_wg_kernel" : "pv_chain_kernel");
+    out->lds_bytes_per_workgroup = (int32_t)(h->use_wave ? pv_wave_lds_bytes() : h->use_wg ? pv_wg_lds_bytes(h->log2n) : pv_kernel_lds_bytes(h->log2n, h->hop));
     out->frames_per_chunk = h->last_frames_per_chunk;
     out->compute_units = h->cus; out->device_id = h->device;
     snprintf(out->device_name, sizeof out->device_name, "%s", h->devname);

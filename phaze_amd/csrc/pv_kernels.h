@@ -40,3 +40,9 @@ size_t pv_wave_lds_bytes();
 int pv_wave_threads();
 bool pv_wave_supported(int log2n, int hop);
 hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
+
+// register-resident workgroup kernel for N = 2048..8192, hop in {N/8, N/4, N/2, N} (pv_wg_kernel.hip)
+bool pv_wg_supported(int log2n, int hop);
+size_t pv_wg_lds_bytes(int log2n);
+int pv_wg_threads(int log2n);
+hipError_t pv_launch_wg(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st);

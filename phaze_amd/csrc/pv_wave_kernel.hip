@@ -19,82 +19,11 @@
 #include <stdint.h>
 
 #include "pv_kernels.h"
+#include "pv_device_common.h"
 
 namespace {
 
-typedef float v2f __attribute__((ext_vector_type(2)));   // clang vector type (the nontemporal builtins need one)
-
-template <typename T> struct v2t;
-template <> struct v2t<float> { using type = float2; };
-template <> struct v2t<double> { using type = double2; };
-
-template <typename T2> __device__ __forceinline__ T2 cadd(T2 a, T2 b) { return T2{a.x + b.x, a.y + b.y}; }
-template <typename T2> __device__ __forceinline__ T2 csub(T2 a, T2 b) { return T2{a.x - b.x, a.y - b.y}; }
-template <typename T2> __device__ __forceinline__ T2 cmul(T2 a, T2 b) { return T2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-template <typename T2> __device__ __forceinline__ T2 cconj(T2 a) { return T2{a.x, -a.y}; }
-// multiply by -j (forward) or +j (inverse)
-template <bool INV, typename T2> __device__ __forceinline__ T2 rot90(T2 a) { return INV ? T2{-a.y, a.x} : T2{a.y, -a.x}; }
-
-// In-register 8-point DFT, natural order in and out.  INV selects exp(+2 pi j nk/8).
-template <typename T, bool INV>
-__device__ __forceinline__ void radix8(typename v2t<T>::type (&a)[8])
-{
-    using T2 = typename v2t<T>::type;
-    const T h = (T)0.70710678118654752440;
-    const T2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
-    const T2 b1 = cadd(a[1], a[5]), b5 = csub(a[1], a[5]);
-    const T2 b2 = cadd(a[2], a[6]), b6 = csub(a[2], a[6]);
-    const T2 b3 = cadd(a[3], a[7]), b7 = csub(a[3], a[7]);
-    // odd half: c_n = b_{n+4} * W8^n
-    T2 c1, c3;
-    if (!INV) { c1 = T2{(b5.x + b5.y) * h, (b5.y - b5.x) * h}; c3 = T2{(b7.y - b7.x) * h, -(b7.x + b7.y) * h}; }
-    else      { c1 = T2{(b5.x - b5.y) * h, (b5.x + b5.y) * h}; c3 = T2{-(b7.x + b7.y) * h, (b7.x - b7.y) * h}; }
-    const T2 c0 = b4, c2 = rot90<INV>(b6);
-    // even outputs: 4-pt DFT of b0..b3
-    {
-        const T2 e0 = cadd(b0, b2), e1 = csub(b0, b2), e2 = cadd(b1, b3), e3 = rot90<INV>(csub(b1, b3));
-        a[0] = cadd(e0, e2); a[4] = csub(e0, e2); a[2] = cadd(e1, e3); a[6] = csub(e1, e3);
-    }
-    // odd outputs: 4-pt DFT of c0..c3
-    {
-        const T2 e0 = cadd(c0, c2), e1 = csub(c0, c2), e2 = cadd(c1, c3), e3 = rot90<INV>(csub(c1, c3));
-        a[1] = cadd(e0, e2); a[5] = csub(e0, e2); a[3] = cadd(e1, e3); a[7] = csub(e1, e3);
-    }
-}
-
-// o * exp(-+2 pi j r / 16): the wave-uniform part of the split-pass twiddle (INV = conjugate)
-template <typename T, bool INV>
-__device__ __forceinline__ typename v2t<T>::type mul_w16(typename v2t<T>::type o, int r)
-{
-    using T2 = typename v2t<T>::type;
-    const T c = (T)0.92387953251128675613, s = (T)0.38268343236508977173, h = (T)0.70710678118654752440;
-    T2 w;
-    switch (r) {               // r is a compile-time constant at every call site (unrolled loops)
-    case 0: return o;
-    case 4: return rot90<INV>(o);
-    case 1: w = T2{c, -s}; break;
-    case 2: w = T2{h, -h}; break;
-    case 3: w = T2{s, -c}; break;
-    case 5: w = T2{-s, -c}; break;
-    case 6: w = T2{-h, -h}; break;
-    default: w = T2{-c, -s}; break;
-    }
-    if (INV) w.y = -w.y;
-    return cmul(o, w);
-}
-
 constexpr int TP = 72;   // padded row of the transpose scratch (elements); conflict-free with the skew below
-
-// Wave-local ordering of LDS traffic: LDS instructions of one wave execute in order, so only the compiler must be fenced.
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef PV_SCHED_FENCE
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
 
 // 512-point complex FFT across one wave: in/out layout lane l, reg r <-> element l + 64 r.
 // TW1[k*64 + l] = W_512^{l k}, TW2[k*8 + n0] = W_64^{n0 k} (k = 1..7) live in LDS, shared by the waves of the workgroup,
@@ -133,30 +62,6 @@ __device__ __forceinline__ void fft512_wave(typename v2t<T>::type (&a)[8], typen
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
-
-struct WaveSrc {
-    const float *in;
-    const float *hist;
-    int hist_len;
-    __device__ __forceinline__ float at(long s) const { return s < 0 ? hist[s + hist_len] : in[s]; }
-};
-
-constexpr unsigned NOROUTE = 0xFFFFFFFFu;        // route = (rotation index << 16) | target bin
-
-// Rotation exp(+2 pi j ridx / N) of one source value (pv:155-170).  R = 4: (delta * t) mod N is a multiple of N/4, so the rotation is
-// j^qd exactly: a swap and two sign-bit XORs (j^1 = (-y, x), j^2 = (-x, -y), j^3 = (y, -x)).
-template <int R_>
-__device__ __forceinline__ float2 rotate_route(unsigned route, float2 v, const float2 *__restrict__ tw32)
-{
-    const unsigned ridx = route >> 16;
-    if (R_ == 4) {
-        const unsigned qd = ridx >> 8;
-        const bool sw = (qd & 1u) != 0u;
-        const float a = sw ? v.y : v.x, b = sw ? v.x : v.y;
-        return float2{__uint_as_float(__float_as_uint(a) ^ ((((qd + 1u) >> 1) & 1u) << 31)), __uint_as_float(__float_as_uint(b) ^ ((qd >> 1) << 31))};
-    }
-    return cmul(v, cconj(tw32[ridx & 1023u]));
-}
 
 // f < 1: regions compress and `+=` collisions happen (pv:169-170).  LDS float atomics serialise per lane (measured: half of the frame
 // time), so collisions are resolved by CLAIM ROUNDS: every pending source writes its id to CLAIM[target], the id that sticks wins the
@@ -260,7 +165,7 @@ __device__ __attribute__((noinline)) void residue_scatter_1024(const float *in, 
         for (int j = 0; j < 4; j++) {
             const int b = base + l + 64 * j, tgt = b + up_delta;
             rt[j] = (b >= H && b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
-            ys[j] = rotate_route<R_>(rt[j], Q[l + 64 * j], tw32);
+            ys[j] = rotate_route<R_, 10>(rt[j], Q[l + 64 * j], tw32);
             id[j] = b;
         }
         claim_rounds<4>(rt, ys, id, Y, CLAIM);
@@ -543,17 +448,17 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const unsigned rt = ROUTE[l + 64 * r];
-                    if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R>(rt, X32[r], p.tw32);
+                    if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R, 10>(rt, X32[r], p.tw32);
                 }
-                if (l == 0) { const unsigned rt = ROUTE[512]; if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R>(rt, float2{x512f, 0.f}, p.tw32); }
+                if (l == 0) { const unsigned rt = ROUTE[512]; if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R, 10>(rt, float2{x512f, 0.f}, p.tw32); }
             } else {
                 unsigned rt[9];
                 float2 ys[9];
                 int id[9];
 #pragma unroll
-                for (int r = 0; r < 8; r++) { rt[r] = ROUTE[l + 64 * r]; ys[r] = rotate_route<R>(rt[r], X32[r], p.tw32); id[r] = l + 64 * r; }
+                for (int r = 0; r < 8; r++) { rt[r] = ROUTE[l + 64 * r]; ys[r] = rotate_route<R, 10>(rt[r], X32[r], p.tw32); id[r] = l + 64 * r; }
                 rt[8] = (l == 0) ? ROUTE[512] : NOROUTE;
-                ys[8] = rotate_route<R>(rt[8], float2{x512f, 0.f}, p.tw32);
+                ys[8] = rotate_route<R, 10>(rt[8], float2{x512f, 0.f}, p.tw32);
                 id[8] = 512;
                 wave_sync();                                               // routes are in registers: CLAIM may overwrite ROUTE
                 claim_rounds<9>(rt, ys, id, Y, CLAIM);

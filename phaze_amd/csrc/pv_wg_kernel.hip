@@ -1,0 +1,611 @@
+// pv_wg_kernel.hip -- register-resident frame pipeline for N = 2048, 4096, 8192 (BASELINE configs[2..4]).
+//
+// Generalisation of pv_wave_kernel_1024: one frame is held by G = N/1024 wavefronts (T = 64 G threads = one workgroup = one
+// frame chain), 8 packed complex elements per thread:
+//
+//   thread t, register r  <->  element t + T r   of   z[n] = xw[2n] + j xw[2n+1],   n in [0, M),  M = N/2 = 512 G = 8*8*8*G
+//
+// FFT = four in-register passes (radix 8, 8, 8, G) with three register<->thread transposes through LDS (row-padded layouts from
+// tools/lds_layout_check.py):
+//   pass A over r            -> digit kA (weight 1),   twiddle W_M^{t kA}
+//   pass B over t_hi         -> digit kB (weight 8),   twiddle W_T^{t_lo kB}          t  = t_hi * 8G + t_lo
+//   pass C over u_hi         -> digit kC (weight 64),  twiddle W_{8G}^{u_lo kC}       t_lo = u_hi * G + u_lo
+//   pass D over u_lo (radix G) -> digit kD (weight 512)
+// and the result lands again as thread t', register r' <-> bin t' + T r'.  Everything between the two FFTs (split pass, |X|^2, peak
+// flags on 8 consecutive bins per thread, routes, scatter with claim rounds for f < 1, per-quarter residue, c2r pre-pass) and the
+// register-resident overlap-add follow the wave kernel; exchanges that were wave-local there (bpermute, ballot) go through LDS here.
+// Reference citations are those of pv_kernels.hip / pv_wave_kernel.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pv_kernels.h"
+#include "pv_device_common.h"
+
+namespace {
+
+template <int G>
+struct WgCfg {
+    static constexpr int T = 64 * G, M = 512 * G, N = 1024 * G, H = M + 1;
+    static constexpr int A2 = (G == 2) ? 2 : 0, P2 = 8 * (8 * G + A2) + 8;      // transpose 2: per-kA row pad, row length
+    static constexpr int A3 = (G == 2) ? 4 : 1, P3 = 8 * (8 * G + A3);          // transpose 3
+    static constexpr int P1 = T;                                                 // transpose 1 is conflict-free unpadded
+    static constexpr int PMAX = (P2 > P3 ? (P2 > P1 ? P2 : P1) : (P3 > P1 ? P3 : P1));
+    static constexpr int SCRATCH = 8 * PMAX * 16;                                // bytes (fp64 complex)
+    // inside the scratch, between the two FFTs:
+    static constexpr int OFF_Y = 0;                                              // float2[H]
+    static constexpr int OFF_ROUTE = ((8 * H + 15) / 16) * 16;                   // u32[M + 16] routes | f32 mags | u16 claim ids (aliases)
+    static constexpr int OFF_RESQ = OFF_ROUTE + 4 * (M + 16);                    // float2[N / 4] one residue quarter
+    static_assert(OFF_RESQ + 8 * (N / 4) <= SCRATCH, "scratch too small");
+    // after the scratch:
+    static constexpr int OFF_PSH = SCRATCH;                                      // i16[M]
+    static constexpr int OFF_NEAR = OFF_PSH + 2 * M;                             // i32 LASTIN[T], FIRSTIN[T]
+    static constexpr int OFF_OCC = OFF_NEAR + 8 * T;                             // u64[G]
+    static constexpr int OFF_TWA = ((OFF_OCC + 8 * G + 15) / 16) * 16;           // double2[8][T]
+    static constexpr int OFF_TWB = OFF_TWA + 16 * 8 * T;                         // double2[8][8G]
+    static constexpr int OFF_TWC = OFF_TWB + 16 * 8 * 8 * G;                     // double2[8][G]
+    static constexpr int LDS_BYTES = OFF_TWC + 16 * 8 * G;
+};
+
+template <typename T_, bool INV>
+__device__ __forceinline__ typename v2t<T_>::type twc(double2 w) { return typename v2t<T_>::type{(T_)w.x, INV ? (T_)(-w.y) : (T_)w.y}; }
+
+// M-point complex FFT across the T threads of the workgroup: in/out layout thread t, reg r <-> element t + T r.
+template <typename T_, bool INV, int G>
+__device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename v2t<T_>::type *S, const double2 *TWA, const double2 *TWB,
+                                       const double2 *TWC, int t)
+{
+    using C = WgCfg<G>;
+    using T2 = typename v2t<T_>::type;
+    // ---- pass A ----
+    radix8<T_, INV>(a);
+#pragma unroll
+    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWA[k * C::T + t]));
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k * C::P1 + t] = a[k];
+    __syncthreads();
+    const int kA1 = t / (8 * G), tlo = t % (8 * G);
+#pragma unroll
+    for (int n = 0; n < 8; n++) a[n] = S[kA1 * C::P1 + n * 8 * G + tlo];
+    __syncthreads();
+    // ---- pass B ----
+    radix8<T_, INV>(a);
+#pragma unroll
+    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWB[k * 8 * G + tlo]));
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k * C::P2 + kA1 * (8 * G + C::A2) + tlo] = a[k];
+    __syncthreads();
+    const int kB2 = tlo / G, ulo = tlo % G;               // destination role of this thread: (kA1, kB2, ulo)
+#pragma unroll
+    for (int n = 0; n < 8; n++) a[n] = S[kB2 * C::P2 + kA1 * (8 * G + C::A2) + n * G + ulo];
+    __syncthreads();
+    // ---- pass C ----
+    radix8<T_, INV>(a);
+#pragma unroll
+    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWC[k * G + ulo]));
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k * C::P3 + kA1 * (8 * G + C::A3) + kB2 * G + ulo] = a[k];
+    __syncthreads();
+    const int kA3 = t & 7, kB3 = (t >> 3) & 7, c3 = t >> 6;  // destination role: bin low part kA3 + 8 kB3 + 64 c3
+#pragma unroll
+    for (int q = 0; q < 8; q++) a[q] = S[(c3 + G * (q / G)) * C::P3 + kA3 * (8 * G + C::A3) + kB3 * G + (q % G)];
+    __syncthreads();
+    // ---- pass D: (8/G) independent radix-G DFTs over u_lo; output register j + (8/G) kD ----
+    if (G == 8) {
+        radix8<T_, INV>(a);
+    } else if (G == 4) {
+        T2 o[8];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const T2 e0 = cadd(a[4 * j], a[4 * j + 2]), e1 = csub(a[4 * j], a[4 * j + 2]);
+            const T2 e2 = cadd(a[4 * j + 1], a[4 * j + 3]), e3 = rot90<INV>(csub(a[4 * j + 1], a[4 * j + 3]));
+            o[j] = cadd(e0, e2); o[j + 2] = cadd(e1, e3); o[j + 4] = csub(e0, e2); o[j + 6] = csub(e1, e3);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] = o[q];
+    } else {
+        T2 o[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { o[j] = cadd(a[2 * j], a[2 * j + 1]); o[j + 4] = csub(a[2 * j], a[2 * j + 1]); }
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] = o[q];
+    }
+}
+
+// Workgroup-wide claim rounds (see claim_rounds in pv_wave_kernel.hip): the loop condition is reduced over the workgroup.
+template <int NS>
+__device__ __forceinline__ void claim_rounds_wg(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned short *CLAIM)
+{
+    unsigned pend = 0;
+#pragma unroll
+    for (int r = 0; r < NS; r++) pend |= (rt[r] != NOROUTE) ? (1u << r) : 0u;
+    while (__syncthreads_or(pend != 0u)) {
+#pragma unroll
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[rt[r] & 0xFFFFu] = (unsigned short)id[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NS; r++) {
+            if (pend & (1u << r)) {
+                const int tg = (int)(rt[r] & 0xFFFFu);
+                if (CLAIM[tg] == (unsigned short)id[r]) {
+                    const float2 o = Y[tg];
+                    Y[tg] = float2{o.x + ys[r].x, o.y + ys[r].y};
+                    pend &= ~(1u << r);
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int digitrev4_(int v, int nd)
+{
+    if (nd == 0) return 0;
+    const unsigned r = __brev((unsigned)v) >> (32 - 2 * nd);
+    return (int)(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u));
+}
+
+// Rare path: above-Nyquist residue of fft.js's in-place real DIT, one quarter of the buffer at a time, then its sources
+// are added into Y.  Same structure as residue_scatter_1024, any LOG2N (radix-2 base stage when log2 N is odd: bundle:447-463).
+template <int LOG2N, int R_>
+__device__ __attribute__((noinline)) void residue_scatter_wg(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
+                                                             const float2 *__restrict__ tw32, int t, int upper_end, int up_delta, unsigned up_ridx,
+                                                             double *dbg_X)
+{
+    constexpr int G = 1 << (LOG2N - 10);
+    using C = WgCfg<G>;
+    constexpr int N = C::N, H = C::H, T = C::T, QN = N / 4;
+    constexpr bool BASE4 = (LOG2N % 2) == 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *Y = reinterpret_cast<float2 *>(smem + C::OFF_Y);
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + C::OFF_ROUTE);
+    float2 *Q = reinterpret_cast<float2 *>(smem + C::OFF_RESQ);
+    const WaveSrc src{in, hist, hist_len};
+    for (int base = N / 2; base < N && base < upper_end; base += QN) {
+        if (BASE4) {
+            constexpr int nd = (LOG2N - 2) / 2;
+            const int blk = base / 4 + t;                                  // QN/4 = T blocks per quarter
+            const int off = digitrev4_(blk, nd);
+            const float a = src.at(s0 + off) * hann[off], b = src.at(s0 + off + N / 4) * hann[off + N / 4];
+            const float c = src.at(s0 + off + N / 2) * hann[off + N / 2], d = src.at(s0 + off + 3 * N / 4) * hann[off + 3 * N / 4];
+            const float t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+            Q[4 * t] = float2{t0 + t2, 0.f};
+            Q[4 * t + 1] = float2{t1, -t3};
+            Q[4 * t + 2] = float2{t0 - t2, 0.f};
+            Q[4 * t + 3] = float2{t1, t3};
+        } else {
+            constexpr int nd = (LOG2N - 1) / 2;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {                                  // QN/2 = 2T blocks per quarter
+                const int lb = t + T * i, blk = base / 2 + lb;
+                const int off = digitrev4_(blk, nd);
+                const float a = src.at(s0 + off) * hann[off], b = src.at(s0 + off + N / 2) * hann[off + N / 2];
+                Q[2 * lb] = float2{a + b, 0.f};
+                Q[2 * lb + 1] = float2{a - b, 0.f};
+            }
+        }
+        __syncthreads();
+        constexpr int LOG2BASE = BASE4 ? 2 : 1;
+        for (int log2m = LOG2BASE + 2; log2m <= LOG2N - 2; log2m += 2) {  // block sizes 4*base .. N/4 inside the quarter
+            const int q = (1 << log2m) >> 2, hq = q >> 1;
+            const int nblocks = QN >> log2m;
+            const int tws = LOG2N - log2m;
+            if (t < nblocks * (hq + 1)) {
+                int blk, i;
+                if (t < nblocks * hq) { blk = t / hq; i = t - blk * hq; } else { blk = t - nblocks * hq; i = hq; }
+                const int o = blk << log2m;
+                const float2 A = Q[o + i];
+                const float2 Bv = cmul(Q[o + q + i], tw32[i << tws]);
+                const float2 Cc = cmul(Q[o + 2 * q + i], tw32[(2 * i) << tws]);
+                const float2 D = cmul(Q[o + 3 * q + i], tw32[(3 * i) << tws]);
+                const float2 T0 = cadd(A, Cc), T1 = csub(A, Cc), T2 = cadd(Bv, D), T3 = csub(Bv, D);
+                Q[o + i] = cadd(T0, T2);
+                Q[o + q + i] = float2{T1.x + T3.y, T1.y - T3.x};
+                if (i == 0) {
+                    Q[o + 2 * q] = csub(T0, T2);
+                } else if (i != hq) {
+                    Q[o + q - i] = float2{T1.x - T3.y, -(T1.y + T3.x)};
+                    Q[o + 2 * q - i] = float2{T0.x - T2.x, -(T0.y - T2.y)};
+                }
+            }
+            __syncthreads();
+        }
+        if (dbg_X)
+            for (int i = t; i < QN; i += T) if (base + i >= H) { dbg_X[2 * (base + i)] = Q[i].x; dbg_X[2 * (base + i) + 1] = Q[i].y; }
+        unsigned rt[4];
+        float2 ys[4];
+        int id[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int b = base + t + T * j, tgt = b + up_delta;
+            rt[j] = (b >= H && b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+            ys[j] = rotate_route<R_, LOG2N>(rt[j], Q[t + T * j], tw32);
+            id[j] = b - N / 2;                                             // unique within a round, fits 16 bits for N = 8192
+        }
+        claim_rounds_wg<4>(rt, ys, id, Y, CLAIM);
+        __syncthreads();
+    }
+}
+
+template <int LOG2N, int S_ROWS, bool AUX>
+__global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKernelParams p)
+{
+    constexpr int G = 1 << (LOG2N - 10);
+    using C = WgCfg<G>;
+    constexpr int N = C::N, M = C::M, H = C::H, T = C::T;
+    constexpr int HOP = 2 * T * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;
+    constexpr int BIG = 1 << 30;
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int ch = blockIdx.y, chunk = blockIdx.x;
+    const int ablate = AUX ? p.ablate : 0;
+    (void)ablate;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2 *S64 = reinterpret_cast<double2 *>(smem);
+    float2 *S32 = reinterpret_cast<float2 *>(smem);
+    float2 *Y = reinterpret_cast<float2 *>(smem + C::OFF_Y);
+    float *MAG = reinterpret_cast<float *>(smem + C::OFF_ROUTE);
+    unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + C::OFF_ROUTE);
+    short *PSH = reinterpret_cast<short *>(smem + C::OFF_PSH);
+    int *LASTIN = reinterpret_cast<int *>(smem + C::OFF_NEAR), *FIRSTIN = LASTIN + T;
+    unsigned long long *OCC = reinterpret_cast<unsigned long long *>(smem + C::OFF_OCC);
+    double2 *TWA = reinterpret_cast<double2 *>(smem + C::OFF_TWA);
+    double2 *TWB = reinterpret_cast<double2 *>(smem + C::OFF_TWB);
+    double2 *TWC = reinterpret_cast<double2 *>(smem + C::OFF_TWC);
+
+    // ---- tables: W_M^{t k} = tw[2 t k], W_T^{q k} = tw[16 q k], W_{8G}^{q k} = tw[128 q k]  (tw[i] = exp(-2 pi j i / N)) ----
+#pragma unroll
+    for (int k = 0; k < 8; k++) TWA[k * T + t] = p.tw64[(2 * t * k) & (N - 1)];
+    for (int i = t; i < 8 * 8 * G; i += T) TWB[i] = p.tw64[(16 * (i % (8 * G)) * (i / (8 * G))) & (N - 1)];
+    for (int i = t; i < 8 * G; i += T) TWC[i] = p.tw64[(128 * (i % G) * (i / G)) & (N - 1)];
+
+    const int first_out = chunk * p.frames_per_chunk;
+    int last_out = first_out + p.frames_per_chunk;
+    if (last_out > p.nhops) last_out = p.nhops;
+    int first_frame = first_out - (R - 1);
+    const bool from_state = (first_frame <= 0);
+    if (from_state) first_frame = 0;
+
+    const long cbase = (long)ch * p.ch_stride;
+    const WaveSrc src{p.in + cbase, p.hist_in + (long)ch * (N - HOP), N - HOP};
+    float *outp = p.out + cbase;
+    const bool vec_out = (reinterpret_cast<uintptr_t>(outp) & 7u) == 0;
+    const bool vec_in = ((reinterpret_cast<uintptr_t>(src.in) | reinterpret_cast<uintptr_t>(src.hist)) & 7u) == 0;
+    const float *pitch_row = p.pitch + (p.pitch_stride ? (long)(ch / p.ch_per_stream) * p.pitch_stride : 0);
+    const float invR = 1.0f / (float)R;
+    unsigned psh_key = 0x7FC12345u;
+
+    const double2 wl = p.tw64[t];                          // split pass: W_N^{t + T r} = wl * W_16^r  (N = 16 T)
+    const float2 wlf = cconj(p.tw32[t]);
+    float2 hw[8];                                          // Hann at samples 2(t + T r), +1
+#pragma unroll
+    for (int r = 0; r < 8; r++) hw[r] = float2{p.hann[2 * (t + T * r)], p.hann[2 * (t + T * r) + 1]};
+
+    float2 acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) acc[r] = float2{0.f, 0.f};
+    if (from_state) {
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) {
+            const float *a = p.acc_in + (long)ch * (N - HOP) + 2 * t + 2 * T * r;
+            acc[r] = float2{a[0], a[1]};
+        }
+    }
+    auto load_rows = [&](float2 *w, int nrows, int first_row, int frame) {
+        const long s0 = (long)(frame + 1) * HOP - N + 2 * t;
+#pragma unroll
+        for (int r = 0; r < nrows; r++) {
+            const long sx = s0 + 2 * T * (first_row + r);
+            if (vec_in) w[r] = *reinterpret_cast<const float2 *>(sx < 0 ? src.hist + sx + src.hist_len : src.in + sx);
+            else w[r] = float2{src.at(sx), src.at(sx + 1)};
+        }
+    };
+    float2 raw[8];
+    load_rows(raw, 8, 0, first_frame);
+    __syncthreads();
+
+    for (int m = first_frame; m < last_out; ++m) {
+        const double pf = (double)pitch_row[m];
+        const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
+        const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
+
+        // ---- Hann (pv:55), pack, forward FFT in fp64 (the split pass's 1/2 is folded into the window, exact) ----
+        double2 z[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) z[r] = double2{(double)(raw[r].x * (0.5f * hw[r].x)), (double)(raw[r].y * (0.5f * hw[r].y))};
+        fft_wg<double, false, G>(z, S64, TWA, TWB, TWC, t);
+
+        // ---- split pass: the partner bin Z[M - k] lives in another thread (mostly another wave) -> exchange through LDS ----
+        float2 X32[8];
+        float xMf;
+        {
+#pragma unroll
+            for (int r = 0; r < 8; r++) S64[t + T * r] = z[r];
+            __syncthreads();
+            double2 X[8];
+            double xM = 0.0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = t + T * r;
+                const double2 zm = (k == 0) ? z[0] : S64[M - k];
+                const double2 E{z[r].x + zm.x, z[r].y - zm.y};
+                const double2 O{z[r].x - zm.x, z[r].y + zm.y};
+                const double2 WO = cmul(wl, mul_w16<double, false>(O, r));
+                X[r] = double2{E.x + WO.y, E.y - WO.x};
+            }
+            if (t == 0) {
+                X[0] = double2{2.0 * (z[0].x + z[0].y), 0.0};
+                xM = 2.0 * (z[0].x - z[0].y);
+            }
+            __syncthreads();                                               // partner reads done: the scratch becomes MAG / Y / ROUTE
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                MAG[4 + t + T * r] = (float)(X[r].x * X[r].x + X[r].y * X[r].y);
+                X32[r] = float2{(float)X[r].x, (float)X[r].y};
+            }
+            if (t == 0) MAG[4 + M] = (float)(xM * xM);
+            xMf = (float)xM;
+            if (dbg) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) { const int k = t + T * r; p.dbg_X[2 * k] = X[r].x; p.dbg_X[2 * k + 1] = X[r].y; }
+                if (t == 0) { p.dbg_X[2 * M] = xM; p.dbg_X[2 * M + 1] = 0.0; }
+            }
+        }
+        // slide the raw window; the rows the next frame adds are issued here
+#pragma unroll
+        for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
+        if (m + 1 < last_out) load_rows(&raw[8 - S_ROWS], S_ROWS, 8 - S_ROWS, m + 1);
+        // ---- Math.round(peak * f) table (pv:125), rebuilt only when f changes ----
+        {
+            const unsigned pfb = __float_as_uint(pitch_row[m]);
+            if (pfb != psh_key) {
+                psh_key = pfb;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int pk = t + T * r;
+                    const double ps = floor((double)pk * pf + 0.5);
+                    const bool ok = (ps <= (double)H) && (ps >= -(double)(2 * N));
+                    PSH[pk] = ok ? (short)(int)ps : (short)0x7FFF;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- peak flags on bins 8t..8t+7 (pv:95-116) ----
+        unsigned bits = 0;
+        {
+            float mg[12];
+            const float2 q0 = *reinterpret_cast<const float2 *>(&MAG[4 + 8 * t - 2]);
+            const float4 q1 = *reinterpret_cast<const float4 *>(&MAG[4 + 8 * t]);
+            const float4 q2 = *reinterpret_cast<const float4 *>(&MAG[4 + 8 * t + 4]);
+            const float2 q3 = *reinterpret_cast<const float2 *>(&MAG[4 + 8 * t + 8]);
+            mg[0] = q0.x; mg[1] = q0.y; mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w;
+            mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w; mg[10] = q3.x; mg[11] = q3.y;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int k = 8 * t + i;
+                const float c = mg[i + 2];
+                const bool f = (k >= 2) && (k < H - 2) && (mg[i + 1] < c) && (mg[i] < c) && (mg[i + 3] < c) && (mg[i + 4] < c);
+                bits |= f ? (1u << i) : 0u;
+            }
+            if (dbg) {
+                for (int i = 0; i < 8; i++) { p.dbg_flags[8 * t + i] = (bits >> i) & 1; p.dbg_mag[8 * t + i] = mg[i + 2]; }
+                if (t == T - 1) { p.dbg_flags[M] = 0; p.dbg_mag[M] = mg[10]; }
+            }
+        }
+        // ---- nearest peaks outside this thread's byte: per-wave occupancy ballots + per-thread last/first peak, through LDS ----
+        const int last_in = bits ? 8 * t + 31 - __clz((int)bits) : -BIG;
+        const int first_in = bits ? 8 * t + __ffs((int)bits) - 1 : BIG;
+        {
+            const unsigned long long occ = __ballot(bits != 0u);
+            LASTIN[t] = last_in;
+            FIRSTIN[t] = first_in;
+            if (l == 0) OCC[wv] = occ;
+        }
+        __syncthreads();                                                   // also: every MAG read is done -> ROUTE may overwrite MAG
+        int cprev = -BIG, cnext = BIG, last_peak = -1;
+        {
+            const unsigned long long mine = OCC[wv];
+            {
+                int srcT = -1;
+                const unsigned long long below = mine & ((1ull << l) - 1ull);
+                if (below) srcT = wv * 64 + 63 - __clzll((long long)below);
+                else
+                    for (int w = wv - 1; w >= 0; --w) { const unsigned long long o = OCC[w]; if (o) { srcT = w * 64 + 63 - __clzll((long long)o); break; } }
+                if (srcT >= 0) cprev = LASTIN[srcT];
+            }
+            {
+                int srcT = -1;
+                const unsigned long long above = (l == 63) ? 0ull : (mine >> (l + 1));
+                if (above) srcT = wv * 64 + l + __ffsll((long long)above);
+                else
+                    for (int w = wv + 1; w < G; ++w) { const unsigned long long o = OCC[w]; if (o) { srcT = w * 64 + __ffsll((long long)o) - 1; break; } }
+                if (srcT >= 0) cnext = FIRSTIN[srcT];
+            }
+            for (int w = G - 1; w >= 0; --w) { const unsigned long long o = OCC[w]; if (o) { last_peak = LASTIN[w * 64 + 63 - __clzll((long long)o)]; break; } }
+        }
+        {
+            auto route_of = [&](int b, int prv, int nxt) -> unsigned {
+                const int owner = (b - prv < nxt - b) ? prv : nxt;
+                const bool has = (unsigned)owner < (unsigned)H;
+                const int ps = (int)PSH[has && owner < M ? owner : 0];
+                const int delta = ps - owner;
+                const int tgt = b + delta;
+                const bool ok = has && (ps != 0x7FFF) && ((unsigned)tgt < (unsigned)H);
+                const unsigned ridx = (unsigned)((delta & (N - 1)) * tmod) & (N - 1);
+                return ok ? ((ridx << 16) | (unsigned)tgt) : NOROUTE;
+            };
+            unsigned rt[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const unsigned lowm = bits & ((2u << i) - 1u), highm = bits >> (i + 1);
+                const int prv = lowm ? 8 * t + 31 - __clz((int)lowm) : cprev;
+                const int nxt = highm ? 8 * t + i + __ffs((int)highm) : cnext;
+                rt[i] = route_of(8 * t + i, prv, nxt);
+            }
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * t]) = uint4{rt[0], rt[1], rt[2], rt[3]};
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * t + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
+            if (t == T - 1) ROUTE[M] = route_of(M, bits ? last_in : cprev, BIG);
+        }
+        int upper_end = H;
+        if (last_peak >= 0) {
+            const int ps = (int)PSH[last_peak];
+            if (ps != 0x7FFF) {
+                const int d = ps - last_peak;
+                if (d < 0) { upper_end = H - d; if (upper_end > N) upper_end = N; }
+            }
+        }
+        // ---- zero Y (pv:121) ----
+#pragma unroll
+        for (int r = 0; r < 8; r++) Y[t + T * r] = float2{0.f, 0.f};
+        if (t == 0) Y[M] = float2{0.f, 0.f};
+        const bool need_res = upper_end > H;
+        __syncthreads();
+        // ---- shiftPeaks (pv:119-173) ----
+        {
+            const bool disjoint = (pf >= 1.0);
+            if (disjoint) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const unsigned rt = ROUTE[t + T * r];
+                    if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R, LOG2N>(rt, X32[r], p.tw32);
+                }
+                if (t == 0) { const unsigned rt = ROUTE[M]; if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R, LOG2N>(rt, float2{xMf, 0.f}, p.tw32); }
+            } else {
+                unsigned rt[9];
+                float2 ys[9];
+                int id[9];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { rt[r] = ROUTE[t + T * r]; ys[r] = rotate_route<R, LOG2N>(rt[r], X32[r], p.tw32); id[r] = t + T * r; }
+                rt[8] = (t == 0) ? ROUTE[M] : NOROUTE;
+                ys[8] = rotate_route<R, LOG2N>(rt[8], float2{xMf, 0.f}, p.tw32);
+                id[8] = M;
+                claim_rounds_wg<9>(rt, ys, id, Y, CLAIM);                  // its first barrier also separates the ROUTE reads from CLAIM writes
+                if (need_res) {
+                    __syncthreads();
+                    const int up_delta = (int)PSH[last_peak] - last_peak;
+                    const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+                    residue_scatter_wg<LOG2N, R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, t, upper_end, up_delta, up_ridx,
+                                                 dbg ? p.dbg_X : nullptr);
+                }
+            }
+        }
+        __syncthreads();
+        if (dbg) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) { const int k = t + T * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
+            if (t == 0) { p.dbg_Y[2 * M] = Y[M].x; p.dbg_Y[2 * M + 1] = Y[M].y; }
+        }
+        // ---- c2r pre-pass ----
+        float2 zi[8];
+        {
+            const float sc = 1.0f / (float)N;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = t + T * r;
+                float2 yk = Y[k], ym = Y[M - k];
+                if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
+                const float2 E{yk.x + ym.x, yk.y - ym.y};
+                const float2 O{yk.x - ym.x, yk.y + ym.y};
+                const float2 c = cmul(wlf, mul_w16<float, true>(O, r));
+                zi[r] = float2{(E.x - c.y) * sc, (E.y + c.x) * sc};
+            }
+        }
+        __syncthreads();
+        fft_wg<float, true, G>(zi, S32, TWA, TWB, TWC, t);
+        // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
+        {
+            const bool emit_out = (m >= first_out);
+            float2 fr[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) fr[r] = float2{zi[r].x * (hw[r].x * invR), zi[r].y * (hw[r].y * invR)};
+#pragma unroll
+            for (int r = 0; r < S_ROWS; r++) {
+                const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
+                if (emit_out) {
+                    float *dst = outp + (long)m * HOP + 2 * t + 2 * T * r;
+                    if (vec_out) __builtin_nontemporal_store(v2f{o.x, o.y}, reinterpret_cast<v2f *>(dst));
+                    else { dst[0] = o.x; dst[1] = o.y; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < LROWS; r++) {
+                const int s = r + S_ROWS;
+                acc[r] = (s < LROWS) ? float2{acc[s].x + fr[s].x, acc[s].y + fr[s].y} : fr[s];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (chunk == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) {
+            float *a = p.acc_out + (long)ch * (N - HOP) + 2 * t + 2 * T * r;
+            a[0] = acc[r].x; a[1] = acc[r].y;
+            float *hs = p.hist_out + (long)ch * (N - HOP) + 2 * t + 2 * T * r;
+            const long s = (long)p.nhops * HOP - (N - HOP) + 2 * t + 2 * T * r;
+            hs[0] = src.at(s); hs[1] = src.at(s + 1);
+        }
+    }
+}
+
+template <int LOG2N, int S_ROWS, bool AUX>
+hipError_t launch_wg(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+{
+    constexpr int G = 1 << (LOG2N - 10);
+    static bool attr_done[16] = {};
+    auto k = pv_wg_kernel<LOG2N, S_ROWS, AUX>;
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (!attr_done[dev & 15]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<G>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done[dev & 15] = true;
+    }
+    hipLaunchKernelGGL(k, dim3(nchunks, nch, 1), dim3(64 * G, 1, 1), WgCfg<G>::LDS_BYTES, st, p);
+    return hipGetLastError();
+}
+
+template <int LOG2N>
+hipError_t launch_wg_n(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+{
+    const int N = 1 << LOG2N;
+    const bool aux = (p.ablate != 0) || (p.dbg_mag != nullptr);
+    const int rows = 8 * p.hop / N;
+    switch (rows) {
+    case 1: return aux ? launch_wg<LOG2N, 1, true>(p, nch, nchunks, st) : launch_wg<LOG2N, 1, false>(p, nch, nchunks, st);
+    case 2: return aux ? launch_wg<LOG2N, 2, true>(p, nch, nchunks, st) : launch_wg<LOG2N, 2, false>(p, nch, nchunks, st);
+    case 4: return aux ? launch_wg<LOG2N, 4, true>(p, nch, nchunks, st) : launch_wg<LOG2N, 4, false>(p, nch, nchunks, st);
+    case 8: return aux ? launch_wg<LOG2N, 8, true>(p, nch, nchunks, st) : launch_wg<LOG2N, 8, false>(p, nch, nchunks, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+bool pv_wg_supported(int log2n, int hop)
+{
+    if (log2n < 11 || log2n > 13) return false;
+    const int N = 1 << log2n;
+    return hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N;
+}
+
+size_t pv_wg_lds_bytes(int log2n)
+{
+    switch (log2n) {
+    case 11: return WgCfg<2>::LDS_BYTES;
+    case 12: return WgCfg<4>::LDS_BYTES;
+    case 13: return WgCfg<8>::LDS_BYTES;
+    default: return 0;
+    }
+}
+
+int pv_wg_threads(int log2n) { return 64 << (log2n - 10); }
+
+hipError_t pv_launch_wg(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+{
+    switch (log2n) {
+    case 11: return launch_wg_n<11>(p, nch, nchunks, st);
+    case 12: return launch_wg_n<12>(p, nch, nchunks, st);
+    case 13: return launch_wg_n<13>(p, nch, nchunks, st);
+    default: return hipErrorInvalidValue;
+    }
+}

@@ -50,3 +50,51 @@ if __name__ == "__main__":
                 # T2: write lane'=(k0,n0)=8*k0+n0, reg k1 ; read lane''=k0+8*k1, reg n0 ; A = k1*P + k0*8 + ((n0 + sk*k0) % 8)
                 A = lambda k0, k1, n0: k1 * P + k0 * 8 + ((n0 + sk * k0) % 8)
                 check(f"T2 elem={elem} P={P} skew={sk}", elem, lambda l, r: A(l >> 3, r, l & 7), lambda l, r: A(l & 7, l >> 3, r))
+
+
+def check_multi(name, elem, T, wr_addr, rd_addr, verbose=True):
+    """Frame handled by T = 64*G lanes (G waves); each wave issues its own instruction: cost summed over waves and 8 registers."""
+    rg, wg = (R128, W128) if elem == 16 else (R64, W64)
+    wc = rc = 0
+    for w in range(T // 64):
+        for r in range(8):
+            wc += cost([wr_addr(64 * w + l, r) * elem for l in range(64)], wg, 32, elem)
+            rc += cost([rd_addr(64 * w + l, r) * elem for l in range(64)], rg, 64, elem)
+    iw, ir = 8 * len(wg) * (T // 64), 8 * len(rg) * (T // 64)
+    if verbose:
+        print(f"{name}: write {wc} (ideal {iw}), read {rc} (ideal {ir})")
+    return wc - iw, rc - ir
+
+
+def search_general():
+    """Transposes of the G-wave FFT (pv_wg_kernel): M = 512 G = 8*8*8*G, T = 64 G lanes, see DESIGN.md."""
+    for G in (2, 4, 8):
+        T = 64 * G
+        for elem in (16, 8):
+            best = {}
+            for pad in range(0, 136, 8):
+                P = T + pad
+                for sk in (0, 1):
+                    # T1: src lane t = t_hi*8G + t_lo, reg kA -> dst lane kA*8G + t_lo, reg t_hi ; addr = kA*P + t (skew on t_lo by kA)
+                    def a1(kA, t_hi, t_lo): return kA * P + t_hi * 8 * G + ((t_lo + sk * 8 * kA) % (8 * G))
+                    e = check_multi("", elem, T, lambda t, r: a1(r, t // (8 * G), t % (8 * G)), lambda d, r: a1(d // (8 * G), r, d % (8 * G)), False)
+                    best.setdefault("T1", []).append((sum(e), pad, sk, e))
+                    # T2: src lane s = kA*8G + u_hi*G + u_lo, reg kB -> dst lane kA*8G + kB*G + u_lo, reg u_hi ; addr = kB*P + kA*8G + ((u_hi + sk*kA)%8)*G + u_lo
+                    def a2(kA, kB, u_hi, u_lo): return kB * P + kA * 8 * G + ((u_hi + sk * kA) % 8) * G + u_lo
+                    e = check_multi("", elem, T, lambda s, r: a2(s // (8 * G), r, (s % (8 * G)) // G, s % G),
+                                    lambda d, r: a2(d // (8 * G), (d % (8 * G)) // G, r, d % G), False)
+                    best.setdefault("T2", []).append((sum(e), pad, sk, e))
+                    # T3: src lane s = kA*8G + kB*G + u_lo, reg kC -> dst lane kA + 8 kB + 64 c, reg j*G + u_lo, kC = c + G j ; addr = kC*P + perm(s)
+                    def a3(kA, kB, kC, u_lo): return kC * P + kA * 8 * G + ((kB + sk * kA) % 8) * G + u_lo
+                    e = check_multi("", elem, T, lambda s, r: a3(s // (8 * G), (s % (8 * G)) // G, r, s % G),
+                                    lambda d, r: a3(d % 8, (d // 8) % 8, (d // 64) + G * (r // G), r % G), False)
+                    best.setdefault("T3", []).append((sum(e), pad, sk, e))
+            for k, v in best.items():
+                v.sort()
+                print(f"G={G} elem={elem} {k}: best (extra cycles, pad, skew, (w,r)) = {v[0]}   unpadded = {[x for x in v if x[1] == 0 and x[2] == 0][0]}")
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "general":
+        search_general()
