@@ -197,3 +197,23 @@ def test_errors_match_reference_behaviour():
     with pytest.raises(phaze_amd.PvError):
         pv.process_batch(np.zeros((2, 1024), np.float32), np.ones(4, np.float32))     # capacity
     pv.close()
+
+
+@pytest.mark.parametrize("fft,hop", [(1024, 256), (2048, 512), (4096, 1024), (8192, 2048)])
+def test_generic_kernel_fallback_parity(fft, hop, monkeypatch):
+    """The LDS-staged generic kernel stays the fallback for the shapes the register-resident kernels cover; keep it honest.
+    PHAZE_GENERIC_KERNEL=1 (read at pv_create) forces it; the two kernels must agree with the oracle and with each other."""
+    T = 20
+    x = np.stack([S.make_signal("tonal", c, T * hop, stream=1) for c in range(2)])
+    p = (0.6 + 1.2 * np.arange(T) / (T - 1)).astype(np.float32)
+    yo = oracle_lib.Oracle(fft, hop, 2).process_planar(x, p)
+    outs = {}
+    for forced in ("0", "1"):
+        monkeypatch.setenv("PHAZE_GENERIC_KERNEL", forced)
+        pv = _pv(fft_size=fft, hop_size=hop, max_channels=2, max_hops=T)
+        outs[forced] = pv.process_batch(x, p)
+        name = pv.info()["kernel_name"]
+        pv.close()
+        assert (name == "pv_chain_kernel") == (forced == "1"), name
+        assert S.rms(outs[forced].astype(np.float64) - yo) < REGRESSION_RMS
+    assert S.rms(outs["0"].astype(np.float64) - outs["1"]) < 1e-7
