@@ -76,7 +76,7 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
     // resident = chains the GPU runs concurrently (wave kernel: 8 per CU; generic: LDS-limited workgroups per CU).
     long per_cu;
     if (h->use_wave) per_cu = 12;
-    else if (h->use_wg) { per_cu = (160 * 1024) / (long)pv_wg_lds_bytes(h->log2n); if (per_cu < 1) per_cu = 1; }
+    else if (h->use_wg) { per_cu = (160 * 1024) / (long)pv_wg_lds_bytes(h->log2n, h->hop); if (per_cu < 1) per_cu = 1; }
     else { per_cu = (160 * 1024) / (long)pv_kernel_lds_bytes(h->log2n, h->hop); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1; }
     const long resident = per_cu * h->cus;
     const int R = h->R;
@@ -273,7 +273,7 @@ int pv_get_info(const pv_handle *h, pv_info *out)
     out->max_channels = h->max_channels; out->max_hops = h->max_hops;
     out->threads_per_workgroup = h->use_wave ? pv_wave_threads() : h->use_wg ? pv_wg_threads(h->log2n) : pv_kernel_threads(h->log2n);
     snprintf(out->kernel_name, sizeof out->kernel_name, "%s", h->use_wave ? "pv_wave_kernel_1024" : h->use_wg ? "pv_wg_kernel" : "pv_chain_kernel");
-    out->lds_bytes_per_workgroup = (int32_t)(h->use_wave ? pv_wave_lds_bytes() : h->use_wg ? pv_wg_lds_bytes(h->log2n) : pv_kernel_lds_bytes(h->log2n, h->hop));
+    out->lds_bytes_per_workgroup = (int32_t)(h->use_wave ? pv_wave_lds_bytes() : h->use_wg ? pv_wg_lds_bytes(h->log2n, h->hop) : pv_kernel_lds_bytes(h->log2n, h->hop));
     out->frames_per_chunk = h->last_frames_per_chunk;
     out->compute_units = h->cus; out->device_id = h->device;
     snprintf(out->device_name, sizeof out->device_name, "%s", h->devname);

@@ -87,7 +87,7 @@ __device__ __forceinline__ float2 rotate_route(unsigned route, float2 v, const f
         const float a = sw ? v.y : v.x, b = sw ? v.x : v.y;
         return float2{__uint_as_float(__float_as_uint(a) ^ ((((qd + 1u) >> 1) & 1u) << 31)), __uint_as_float(__float_as_uint(b) ^ ((qd >> 1) << 31))};
     }
-    return cmul(v, cconj(tw32[ridx]));
+    return cmul(v, cconj(tw32[ridx & ((1u << LOG2N_) - 1u)]));   // masked: NOROUTE carries ridx = 0xFFFF
 }
 
 

@@ -43,6 +43,6 @@ hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStre
 
 // register-resident workgroup kernel for N = 2048..8192, hop in {N/8, N/4, N/2, N} (pv_wg_kernel.hip)
 bool pv_wg_supported(int log2n, int hop);
-size_t pv_wg_lds_bytes(int log2n);
+size_t pv_wg_lds_bytes(int log2n, int hop);
 int pv_wg_threads(int log2n);
 hipError_t pv_launch_wg(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st);

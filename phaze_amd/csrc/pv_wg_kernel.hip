@@ -44,6 +44,8 @@ struct WgCfg {
     static constexpr int OFF_TWB = OFF_TWA + 16 * 8 * T;                         // double2[8][8G]
     static constexpr int OFF_TWC = OFF_TWB + 16 * 8 * 8 * G;                     // double2[8][G]
     static constexpr int LDS_BYTES = OFF_TWC + 16 * 8 * G;
+    static constexpr int OFF_ACC = LDS_BYTES;                                    // f32[N - hop] overlap-add ring, only for hops below N/8 (S_ROWS = 0)
+    static constexpr int LDS_BYTES_RING = OFF_ACC + 4 * N;
 };
 
 template <typename T_, bool INV>
@@ -231,7 +233,14 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
     constexpr int G = 1 << (LOG2N - 10);
     using C = WgCfg<G>;
     constexpr int N = C::N, M = C::M, H = C::H, T = C::T;
-    constexpr int HOP = 2 * T * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;
+    // S_ROWS = hop / (2T) in {1,2,4,8}: the frame advances by whole register rows -> overlap-add accumulator and input window live in
+    // registers.  S_ROWS = 0: any other (even) hop dividing N, e.g. the reference's native 2048/128 (R = 16): accumulator ring in LDS
+    // (reference order, ola:149-157), window re-loaded per frame (the overlap comes from L2).
+    constexpr bool RING = (S_ROWS == 0);
+    const int HOP = RING ? p.hop : 2 * T * S_ROWS;
+    constexpr int R = RING ? 0 : N / (2 * T * (S_ROWS ? S_ROWS : 1));    // compile-time R (4 => exact j^q rotations); 0 = run time
+    const int Rrt = N / HOP;
+    constexpr int LROWS = RING ? 0 : 8 - S_ROWS;
     constexpr int BIG = 1 << 30;
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int ch = blockIdx.y, chunk = blockIdx.x;
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
     const int first_out = chunk * p.frames_per_chunk;
     int last_out = first_out + p.frames_per_chunk;
     if (last_out > p.nhops) last_out = p.nhops;
-    int first_frame = first_out - (R - 1);
+    int first_frame = first_out - (Rrt - 1);
     const bool from_state = (first_frame <= 0);
     if (from_state) first_frame = 0;
 
@@ -271,7 +280,10 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
     const bool vec_out = (reinterpret_cast<uintptr_t>(outp) & 7u) == 0;
     const bool vec_in = ((reinterpret_cast<uintptr_t>(src.in) | reinterpret_cast<uintptr_t>(src.hist)) & 7u) == 0;
     const float *pitch_row = p.pitch + (p.pitch_stride ? (long)(ch / p.ch_per_stream) * p.pitch_stride : 0);
-    const float invR = 1.0f / (float)R;
+    const float invR = 1.0f / (float)Rrt;
+    float *ACC = reinterpret_cast<float *>(smem + C::OFF_ACC);          // RING only
+    const int Lr = N - HOP;
+    int ring = 0;
     unsigned psh_key = 0x7FC12345u;
 
     const double2 wl = p.tw64[t];                          // split pass: W_N^{t + T r} = wl * W_16^r  (N = 16 T)
@@ -283,7 +295,9 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
     float2 acc[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) acc[r] = float2{0.f, 0.f};
-    if (from_state) {
+    if (RING) {
+        for (int j = t; j < Lr; j += T) ACC[j] = from_state ? p.acc_in[(long)ch * Lr + j] : 0.f;
+    } else if (from_state) {
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
             const float *a = p.acc_in + (long)ch * (N - HOP) + 2 * t + 2 * T * r;
@@ -351,9 +365,13 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
             }
         }
         // slide the raw window; the rows the next frame adds are issued here
+        if (RING) {
+            if (m + 1 < last_out) load_rows(raw, 8, 0, m + 1);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
-        if (m + 1 < last_out) load_rows(&raw[8 - S_ROWS], S_ROWS, 8 - S_ROWS, m + 1);
+            for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
+            if (m + 1 < last_out) load_rows(&raw[8 - (RING ? 8 : S_ROWS)], S_ROWS, 8 - S_ROWS, m + 1);
+        }
         // ---- Math.round(peak * f) table (pv:125), rebuilt only when f changes ----
         {
             const unsigned pfb = __float_as_uint(pitch_row[m]);
@@ -517,8 +535,37 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
             float2 fr[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) fr[r] = float2{zi[r].x * (hw[r].x * invR), zi[r].y * (hw[r].y * invR)};
+            if (RING) {
+                // phase 1: samples below N - hop read their slot (emit the first hop, accumulate the rest); phase 2: the last hop samples
+                // of the frame take over the slots the emitted hop freed (0 + x, ola:130-137)
 #pragma unroll
-            for (int r = 0; r < S_ROWS; r++) {
+                for (int r = 0; r < 8; r++) {
+                    const int j = 2 * t + 2 * T * r;
+                    if (j < Lr) {
+                        int slot = ring + j; if (slot >= Lr) slot -= Lr;
+                        const float2 a = *reinterpret_cast<const float2 *>(&ACC[slot]);
+                        const float2 o{a.x + fr[r].x, a.y + fr[r].y};
+                        if (j < HOP) {
+                            if (emit_out) { float *dst = outp + (long)m * HOP + j; dst[0] = o.x; dst[1] = o.y; }
+                        } else {
+                            *reinterpret_cast<float2 *>(&ACC[slot]) = o;
+                        }
+                    } else if (Lr == 0 && emit_out) {                       // hop == N cannot happen here (S_ROWS = 8 covers it)
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int j = 2 * t + 2 * T * r;
+                    if (j >= Lr) {
+                        int slot = ring + (j - Lr); if (slot >= Lr) slot -= Lr;
+                        *reinterpret_cast<float2 *>(&ACC[slot]) = fr[r];
+                    }
+                }
+                ring += HOP; if (ring >= Lr) ring -= Lr;
+            } else {
+#pragma unroll
+            for (int r = 0; r < (RING ? 0 : S_ROWS); r++) {
                 const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
                 if (emit_out) {
                     float *dst = outp + (long)m * HOP + 2 * t + 2 * T * r;
@@ -531,11 +578,19 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
                 const int s = r + S_ROWS;
                 acc[r] = (s < LROWS) ? float2{acc[s].x + fr[s].x, acc[s].y + fr[s].y} : fr[s];
             }
+            }
         }
         __syncthreads();
     }
 
-    if (chunk == (int)gridDim.x - 1) {
+    if (RING && chunk == (int)gridDim.x - 1) {
+        for (int j = t; j < Lr; j += T) {
+            int slot = ring + j; if (slot >= Lr) slot -= Lr;
+            p.acc_out[(long)ch * Lr + j] = ACC[slot];
+            p.hist_out[(long)ch * Lr + j] = src.at((long)p.nhops * HOP - Lr + j);
+        }
+    }
+    if (!RING && chunk == (int)gridDim.x - 1) {
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
             float *a = p.acc_out + (long)ch * (N - HOP) + 2 * t + 2 * T * r;
@@ -556,11 +611,12 @@ hipError_t launch_wg(const PvKernelParams &p, int nch, int nchunks, hipStream_t 
     int dev = 0;
     hipGetDevice(&dev);
     if (!attr_done[dev & 15]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<G>::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           S_ROWS ? WgCfg<G>::LDS_BYTES : WgCfg<G>::LDS_BYTES_RING);
         if (e != hipSuccess) return e;
         attr_done[dev & 15] = true;
     }
-    hipLaunchKernelGGL(k, dim3(nchunks, nch, 1), dim3(64 * G, 1, 1), WgCfg<G>::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(k, dim3(nchunks, nch, 1), dim3(64 * G, 1, 1), S_ROWS ? WgCfg<G>::LDS_BYTES : WgCfg<G>::LDS_BYTES_RING, st, p);
     return hipGetLastError();
 }
 
@@ -569,8 +625,9 @@ hipError_t launch_wg_n(const PvKernelParams &p, int nch, int nchunks, hipStream_
 {
     const int N = 1 << LOG2N;
     const bool aux = (p.ablate != 0) || (p.dbg_mag != nullptr);
-    const int rows = 8 * p.hop / N;
+    const int rows = (8 * p.hop % N == 0) ? 8 * p.hop / N : 0;
     switch (rows) {
+    case 0: return aux ? launch_wg<LOG2N, 0, true>(p, nch, nchunks, st) : launch_wg<LOG2N, 0, false>(p, nch, nchunks, st);
     case 1: return aux ? launch_wg<LOG2N, 1, true>(p, nch, nchunks, st) : launch_wg<LOG2N, 1, false>(p, nch, nchunks, st);
     case 2: return aux ? launch_wg<LOG2N, 2, true>(p, nch, nchunks, st) : launch_wg<LOG2N, 2, false>(p, nch, nchunks, st);
     case 4: return aux ? launch_wg<LOG2N, 4, true>(p, nch, nchunks, st) : launch_wg<LOG2N, 4, false>(p, nch, nchunks, st);
@@ -585,15 +642,18 @@ bool pv_wg_supported(int log2n, int hop)
 {
     if (log2n < 11 || log2n > 13) return false;
     const int N = 1 << log2n;
-    return hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N;
+    if (hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N) return true;      // register-resident overlap-add
+    return hop >= 2 && hop % 2 == 0 && N % hop == 0 && pv_wg_lds_bytes(log2n, hop) <= 160 * 1024;   // LDS ring (e.g. native 2048/128)
 }
 
-size_t pv_wg_lds_bytes(int log2n)
+size_t pv_wg_lds_bytes(int log2n, int hop)
 {
+    const int N = 1 << log2n;
+    const bool ring = !(hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N);
     switch (log2n) {
-    case 11: return WgCfg<2>::LDS_BYTES;
-    case 12: return WgCfg<4>::LDS_BYTES;
-    case 13: return WgCfg<8>::LDS_BYTES;
+    case 11: return ring ? WgCfg<2>::LDS_BYTES_RING : WgCfg<2>::LDS_BYTES;
+    case 12: return ring ? WgCfg<4>::LDS_BYTES_RING : WgCfg<4>::LDS_BYTES;
+    case 13: return ring ? WgCfg<8>::LDS_BYTES_RING : WgCfg<8>::LDS_BYTES;
     default: return 0;
     }
 }
