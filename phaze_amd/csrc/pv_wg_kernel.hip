@@ -40,10 +40,11 @@ struct WgCfg {
     static constexpr int OFF_PSH = SCRATCH;                                      // i16[M]
     static constexpr int OFF_NEAR = OFF_PSH + 2 * M;                             // i32 LASTIN[T], FIRSTIN[T]
     static constexpr int OFF_OCC = OFF_NEAR + 8 * T;                             // u64[G]
-    static constexpr int OFF_TWA = ((OFF_OCC + 8 * G + 15) / 16) * 16;           // double2[8][T]
-    static constexpr int OFF_TWB = OFF_TWA + 16 * 8 * T;                         // double2[8][8G]
-    static constexpr int OFF_TWC = OFF_TWB + 16 * 8 * 8 * G;                     // double2[8][G]
-    static constexpr int LDS_BYTES = OFF_TWC + 16 * 8 * G;
+    // twiddle rows k = 1..7 only (row 0 is all ones): keeps G = 2 at 4 workgroups per CU
+    static constexpr int OFF_TWA = ((OFF_OCC + 8 * G + 15) / 16) * 16;           // double2[7][T]
+    static constexpr int OFF_TWB = OFF_TWA + 16 * 7 * T;                         // double2[7][8G]
+    static constexpr int OFF_TWC = OFF_TWB + 16 * 7 * 8 * G;                     // double2[7][G]
+    static constexpr int LDS_BYTES = OFF_TWC + 16 * 7 * G;
     static constexpr int OFF_ACC = LDS_BYTES;                                    // f32[N - hop] overlap-add ring, only for hops below N/8 (S_ROWS = 0)
     static constexpr int LDS_BYTES_RING = OFF_ACC + 4 * N;
 };
@@ -61,7 +62,7 @@ __device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename 
     // ---- pass A ----
     radix8<T_, INV>(a);
 #pragma unroll
-    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWA[k * C::T + t]));
+    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWA[(k - 1) * C::T + t]));
 #pragma unroll
     for (int k = 0; k < 8; k++) S[k * C::P1 + t] = a[k];
     __syncthreads();
@@ -72,7 +73,7 @@ __device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename 
     // ---- pass B ----
     radix8<T_, INV>(a);
 #pragma unroll
-    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWB[k * 8 * G + tlo]));
+    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWB[(k - 1) * 8 * G + tlo]));
 #pragma unroll
     for (int k = 0; k < 8; k++) S[k * C::P2 + kA1 * (8 * G + C::A2) + tlo] = a[k];
     __syncthreads();
@@ -83,7 +84,7 @@ __device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename 
     // ---- pass C ----
     radix8<T_, INV>(a);
 #pragma unroll
-    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWC[k * G + ulo]));
+    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWC[(k - 1) * G + ulo]));
 #pragma unroll
     for (int k = 0; k < 8; k++) S[k * C::P3 + kA1 * (8 * G + C::A3) + kB2 * G + ulo] = a[k];
     __syncthreads();
@@ -263,9 +264,9 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
 
     // ---- tables: W_M^{t k} = tw[2 t k], W_T^{q k} = tw[16 q k], W_{8G}^{q k} = tw[128 q k]  (tw[i] = exp(-2 pi j i / N)) ----
 #pragma unroll
-    for (int k = 0; k < 8; k++) TWA[k * T + t] = p.tw64[(2 * t * k) & (N - 1)];
-    for (int i = t; i < 8 * 8 * G; i += T) TWB[i] = p.tw64[(16 * (i % (8 * G)) * (i / (8 * G))) & (N - 1)];
-    for (int i = t; i < 8 * G; i += T) TWC[i] = p.tw64[(128 * (i % G) * (i / G)) & (N - 1)];
+    for (int k = 1; k < 8; k++) TWA[(k - 1) * T + t] = p.tw64[(2 * t * k) & (N - 1)];
+    for (int i = t; i < 7 * 8 * G; i += T) TWB[i] = p.tw64[(16 * (i % (8 * G)) * (i / (8 * G) + 1)) & (N - 1)];
+    for (int i = t; i < 7 * G; i += T) TWC[i] = p.tw64[(128 * (i % G) * (i / G + 1)) & (N - 1)];
 
     const int first_out = chunk * p.frames_per_chunk;
     int last_out = first_out + p.frames_per_chunk;
