@@ -1,0 +1,74 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/phaze_amd.h declares, reports
+reference-compatible errors without touching a device, and refuses to run without a GPU (no CPU compute path exists)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "phaze_amd.h")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"PV_API\s+[\w\s\*]+?\b(pv_\w+)\s*\(", txt)))
+
+
+def _lib():
+    import phaze_amd
+    if not os.path.exists(phaze_amd.library_path()):
+        phaze_amd.build_library()
+    return phaze_amd.load_library()
+
+
+def test_header_declares_the_documented_surface():
+    names = _declared()
+    for must in ("pv_create", "pv_destroy", "pv_process", "pv_process_batch", "pv_process_batch_device", "pv_reset", "pv_reset_channels",
+                 "pv_last_error", "pv_get_info", "pv_set_stream", "pv_synchronize", "pv_get_time_cursor", "pv_debug_frame"):
+        assert must in names
+    assert "/root/reference/src/ola-processor.js:159-171" in open(HEADER).read()      # every entry point cites what it replaces
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib()
+    missing = [n for n in _declared() if not hasattr(L, n)]
+    assert not missing, missing
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "phaze_amd", "lib", "libphaze_amd.so")], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (pv_\w+)", out))
+    assert set(_declared()) <= exported
+    assert not [s for s in exported if "oracle" in s.lower()]                         # the checker is not linked into the product
+
+
+def test_errors_without_device():
+    import phaze_amd
+    from phaze_amd import capi
+    L = _lib()
+    h = C.c_void_p()
+    cfg = capi._Config(1000, 250, 1, 1, 0, 0)
+    assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_FFT_SIZE
+    assert L.pv_last_error(None).decode() == "FFT size must be a power of two and bigger than 1"     # bundle:6-7
+    cfg = capi._Config(1024, 300, 1, 1, 0, 0)
+    assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_ARGUMENT
+    cfg = capi._Config(16384, 4096, 1, 1, 0, 0)
+    assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_UNSUPPORTED
+    assert L.pv_status_string(capi.PV_ERR_DEVICE).decode() == "HIP device error"
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        cfg = capi._Config(1024, 256, 1, 1, 0, 0)
+        assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_DEVICE                           # fails loudly: no CPU fallback
+        with pytest.raises(phaze_amd.PvError):
+            phaze_amd.PhaseVocoder(fft_size=1024, hop_size=256)
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    for base, _, files in os.walk(os.path.join(ROOT, "phaze_amd")):
+        for f in files:
+            if f.endswith((".hip", ".h", ".c", ".py", ".js")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                assert "pv_oracle" not in txt and "oracle_lib" not in txt and "libpv_oracle" not in txt, os.path.join(base, f)
