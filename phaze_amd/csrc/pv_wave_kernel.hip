@@ -1,20 +1,24 @@
 // pv_wave_kernel.hip -- wave-per-frame kernel for N = 1024 (BASELINE configs[0..1], the bench workload).
 //
-// One 64-lane wavefront owns one channel and a chain of consecutive frames.  Everything that can stay in
-// registers does; LDS is used only for the two register<->lane transposes of each FFT, the magnitude /
-// peak-mask exchange and the shifted spectrum Y:
+// One 64-lane wavefront owns one channel and a chain of consecutive frames; 12 independent chains share a workgroup (and its LDS
+// tables) = 3 waves per SIMD.  Everything that can stay in registers does; LDS carries only the two register<->lane transposes of
+// each FFT, the magnitude / route exchange and the shifted spectrum Y:
 //
 //   lane l, register r  <->  packed complex element z[l + 64 r]   (z[n] = xw[2n] + j xw[2n+1], N/2 = 512 = 8*8*8)
 //
-//   * raw input samples slide in registers (hop = 128*S samples = S register rows): 2*S new loads per frame
-//   * forward 512-pt complex FFT in fp64: three radix-8 butterflies per lane, two conflict-free LDS transposes
-//     (layouts from tools/lds_layout_check.py), per-lane twiddles held in registers for the whole chain
-//   * split pass with the partner bin fetched by ds_bpermute (lane 64-l), |X|^2 -> f32 in registers
-//   * peak flags on 8 consecutive bins per lane -> byte masks; scatter with the source bin taken from registers
-//   * c2r pre-pass + 512-pt inverse FFT in fp32 (same structure), Hann, overlap-add accumulator in registers,
-//     finished hop stored coalesced
+//   * raw input samples slide in registers (hop = 128*S samples = S register rows): S new float2 loads per frame, issued a frame ahead
+//   * forward 512-pt complex FFT in fp64 (pv:57; fp64 because the peak decisions are taken on the f32-rounded |X|^2 of an fp64
+//     spectrum): three radix-8 butterflies per lane, two conflict-free LDS transposes (layouts from tools/lds_layout_check.py),
+//     twiddles from LDS tables shared by the workgroup
+//   * split pass: partner bin fetched by ds_bpermute (lane 64-l); |X|^2 -> f32 in registers (pv:82-92)
+//   * peak flags on 8 consecutive bins per lane (pv:95-116); nearest peaks by one ballot + two bpermutes; owner rule + cached
+//     Math.round(p f) table -> one route per source bin (pv:119-152)
+//   * scatter of the register-resident source bins along their routes (pv:155-170): plain stores when f >= 1 (regions disjoint),
+//     claim rounds when f < 1; above-Nyquist residue rebuilt per quarter in an out-of-line function
+//   * c2r pre-pass + 512-pt inverse FFT in fp32 (same structure), Hann, overlap-add accumulator in registers in reference order
+//     (ola:149-157), finished hop stored coalesced, non-temporal
 //
-// Semantics are those of pv_chain_kernel (same reference citations); tests run both against the oracle.
+// Semantics are those of pv_chain_kernel (same reference citations); tests run every kernel against the oracle.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
