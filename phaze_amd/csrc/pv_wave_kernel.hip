@@ -27,6 +27,15 @@
 
 namespace {
 
+constexpr int WAVES = 12;                        // independent frame chains per workgroup (they only share the LDS tables)
+constexpr int TAB_TW1 = 0;                       // double2[8*64]  W_512^{l k}
+constexpr int TAB_TW2 = TAB_TW1 + 8 * 64 * 16;   // double2[8*8]   W_64^{n0 k}
+constexpr int TAB_TW1F = TAB_TW2 + 8 * 8 * 16;   // float2[8*64]   conj, fp32 (inverse)
+constexpr int TAB_TW2F = TAB_TW1F + 8 * 64 * 8;  // float2[8*8]
+constexpr int TAB_HANN = TAB_TW2F + 8 * 8 * 8;   // float2[512]    0.5 * Hann at samples 2n, 2n+1 (analysis; 1/2 of the split pass folded in, exact)
+constexpr int TAB_HANNI = TAB_HANN + 512 * 8;    // float2[512]    Hann / R (synthesis; the 1/R of the overlap-add folded in, exact: R = 2^k)
+constexpr int TAB_BYTES = TAB_HANNI + 512 * 8;   // 22016
+
 constexpr int TP = 72;   // padded row of the transpose scratch (elements); conflict-free with the skew below
 
 // 512-point complex FFT across one wave: in/out layout lane l, reg r <-> element l + 64 r.
@@ -116,16 +125,19 @@ __device__ __attribute__((noinline)) void residue_scatter_1024(const float *in, 
     float2 *Y = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_Y);
     unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + OFF_ROUTE);
     float2 *Q = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_RESQ);
+    const float *HWf = reinterpret_cast<const float *>(smem_all + TAB_HANN);       // 0.5 * Hann, shared table
+    const float2 *TW1F = reinterpret_cast<const float2 *>(smem_all + TAB_TW1F);    // conj(W_512^{l k}) = conj(W_1024^{2 l k}), fp32
+    (void)hann;
     const WaveSrc src{in, hist, hist_len};
     for (int base = N / 2; base < N && base < upper_end; base += N / 4) {
         {   // base stage: radix-4 blocks t = base/4 + l (bundle:468-508), input index = base-4 digit reversal of t
             const int t = base / 4 + l;
             const unsigned rv = __brev((unsigned)t) >> (32 - 8);
             const int off = (int)(((rv & 0x55555555u) << 1) | ((rv >> 1) & 0x55555555u));
-            const float a = src.at(s0 + off) * hann[off];
-            const float b = src.at(s0 + off + N / 4) * hann[off + N / 4];
-            const float c = src.at(s0 + off + N / 2) * hann[off + N / 2];
-            const float d = src.at(s0 + off + 3 * N / 4) * hann[off + 3 * N / 4];
+            const float a = src.at(s0 + off) * (2.0f * HWf[off]);                       // Hann from the LDS table (2 * 0.5 w: exact)
+            const float b = src.at(s0 + off + N / 4) * (2.0f * HWf[off + N / 4]);
+            const float c = src.at(s0 + off + N / 2) * (2.0f * HWf[off + N / 2]);
+            const float d = src.at(s0 + off + 3 * N / 4) * (2.0f * HWf[off + 3 * N / 4]);
             const float t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
             Q[4 * l] = float2{t0 + t2, 0.f};
             Q[4 * l + 1] = float2{t1, -t3};
@@ -137,16 +149,16 @@ __device__ __attribute__((noinline)) void residue_scatter_1024(const float *in, 
         for (int log2m = 4; log2m <= 8; log2m += 2) {                     // block sizes 16, 64, 256 inside the quarter (bundle:329-441)
             const int q = (1 << log2m) >> 2, hq = q >> 1;                 // butterflies i = 0..hq per block
             const int nblocks = 256 >> log2m;
-            const int tws = 10 - log2m;                                    // W_Mb^i = tw[i << tws]
+            const int step = 256 >> log2m;                                 // W_Mb^{i m} = W_1024^{1024 i m / Mb} = W_512^{(i step)(2m)}: table row 2m
             const int it = l;
             if (it < nblocks * (hq + 1)) {
                 int blk, i;
                 if (it < nblocks * hq) { blk = it / hq; i = it - blk * hq; } else { blk = it - nblocks * hq; i = hq; }
                 const int o = blk << log2m;
                 const float2 A = Q[o + i];
-                const float2 Bv = cmul(Q[o + q + i], tw32[i << tws]);
-                const float2 C = cmul(Q[o + 2 * q + i], tw32[(2 * i) << tws]);
-                const float2 D = cmul(Q[o + 3 * q + i], tw32[(3 * i) << tws]);
+                const float2 Bv = cmul(Q[o + q + i], cconj(TW1F[2 * 64 + i * step]));
+                const float2 C = cmul(Q[o + 2 * q + i], cconj(TW1F[4 * 64 + i * step]));
+                const float2 D = cmul(Q[o + 3 * q + i], cconj(TW1F[6 * 64 + i * step]));
                 const float2 T0 = cadd(A, C), T1 = csub(A, C), T2 = cadd(Bv, D), T3 = csub(Bv, D);
                 Q[o + i] = cadd(T0, T2);
                 Q[o + q + i] = float2{T1.x + T3.y, T1.y - T3.x};          // T1 - j T3
@@ -176,14 +188,6 @@ __device__ __attribute__((noinline)) void residue_scatter_1024(const float *in, 
     }
 }
 
-constexpr int WAVES = 12;                        // independent frame chains per workgroup (they only share the LDS tables)
-constexpr int TAB_TW1 = 0;                       // double2[8*64]  W_512^{l k}
-constexpr int TAB_TW2 = TAB_TW1 + 8 * 64 * 16;   // double2[8*8]   W_64^{n0 k}
-constexpr int TAB_TW1F = TAB_TW2 + 8 * 8 * 16;   // float2[8*64]   conj, fp32 (inverse)
-constexpr int TAB_TW2F = TAB_TW1F + 8 * 64 * 8;  // float2[8*8]
-constexpr int TAB_HANN = TAB_TW2F + 8 * 8 * 8;   // float2[512]    0.5 * Hann at samples 2n, 2n+1 (analysis; 1/2 of the split pass folded in, exact)
-constexpr int TAB_HANNI = TAB_HANN + 512 * 8;    // float2[512]    Hann / R (synthesis; the 1/R of the overlap-add folded in, exact: R = 2^k)
-constexpr int TAB_BYTES = TAB_HANNI + 512 * 8;   // 22016
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
 // AUX = true: test-tap / phase-ablation build (pv_debug_frame, PHAZE_ABLATE); the production instance carries neither.
@@ -191,7 +195,7 @@ template <int S_ROWS, bool AUX>
 __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKernelParams p)
 {
     const int ablate = AUX ? p.ablate : 0;                                // phase-ablation build (profiling only); folds away otherwise
-    constexpr int N = 1024, M = 512, H = 513, LOG2N = 10;
+    constexpr int N = 1024, M = 512, H = 513;
     constexpr int HOP = 128 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;    // LROWS rows of carried accumulator
     constexpr int BIG = 1 << 30;
     const int l = threadIdx.x & 63;
