@@ -171,7 +171,8 @@ def main():
             "metric": "stft_frames_per_sec_1024pt_hop256_48k" if (fft, hop) == (1024, 256) else f"stft_frames_per_sec_{fft}pt_hop{hop}",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64 forward FFT + peak decisions, f32 shift/inverse/OLA", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "dtype_note": "forward FFT and peak decisions in f64 (decision parity), shift / inverse FFT / overlap-add in f32, I/O f32",
+            "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {'mono' if nch == 1 else str(nch) + '-ch'} 48 kHz FFT={fft} hop={hop} pitchFactor={args.pitch}, "
                                    f"throughput mode, one resident stream of {T} hops per GPU per step",
                        "fft": fft, "hop": hop, "channels": nch, "hops_per_step": T, "pitch_factor": args.pitch,
