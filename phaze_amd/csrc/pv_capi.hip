@@ -36,6 +36,7 @@ struct pv_handle {
     float *d_stage_in, *d_stage_out, *d_pitch;   // host-buffer batch staging
     float *h_pin;                                // pinned: [hdr | max_channels*hop in | max_channels*hop out]
     float *d_quantum;                            // device twin of h_pin
+    float *d_pin_mapped;                         // device view of h_pin (zero-copy streaming quantum); null = stage through d_quantum
     double *d_dbgX; float *d_dbgMag; int *d_dbgFlags; float *d_dbgY;
     int64_t time_cursor;
     int active_nch;
@@ -235,7 +236,15 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     CHK(hipMalloc(&h->d_stage_out, stage));
     CHK(hipMalloc(&h->d_pitch, sizeof(float) * (size_t)maxch * (size_t)maxhops));
     const size_t quantum = sizeof(float) * (kHdrFloats + 2 * (size_t)maxch * hop);
-    CHK(hipHostMalloc((void **)&h->h_pin, quantum, hipHostMallocDefault));
+    CHK(hipHostMalloc((void **)&h->h_pin, quantum, hipHostMallocMapped));
+    {
+        // streaming quantum: the kernel reads the hop straight from / writes it straight to pinned host memory (one launch + one sync,
+        // no copy nodes).  PHAZE_STREAM_COPY=1 restores H2D + kernel + D2H staging.
+        const char *sc = getenv("PHAZE_STREAM_COPY");
+        void *dp = nullptr;
+        if (!(sc && sc[0] == '1') && hipHostGetDevicePointer(&dp, h->h_pin, 0) == hipSuccess) h->d_pin_mapped = (float *)dp;
+        (void)hipGetLastError();
+    }
     CHK(hipMalloc(&h->d_quantum, quantum));
     CHK(hipMalloc(&h->d_dbgX, sizeof(double) * 2 * N));
     CHK(hipMalloc(&h->d_dbgMag, sizeof(float) * (N / 2 + 1)));
@@ -354,12 +363,19 @@ int pv_process(pv_handle *h, const float *const *in, float *const *out, int32_t 
         if (paused || !in[c]) memset(pin_in + (size_t)c * hop, 0, sizeof(float) * hop);
         else memcpy(pin_in + (size_t)c * hop, in[c], sizeof(float) * hop);       // host block is only valid during the call (ola:64)
     }
-    float *dq_in = h->d_quantum + kHdrFloats, *dq_out = dq_in + (size_t)h->max_channels * hop;
-    HIPCHK(h, hipMemcpyAsync(h->d_quantum, h->h_pin, sizeof(float) * (kHdrFloats + (size_t)nch * hop), hipMemcpyHostToDevice, h->stream));
-    const int rc = run_chain(h, dq_in, dq_out, nch, 1, hop, h->d_quantum, 0, 1, true, -1);
-    if (rc != PV_OK) return rc;
-    HIPCHK(h, hipMemcpyAsync(pin_out, dq_out, sizeof(float) * (size_t)nch * hop, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_pin_mapped) {
+        float *m_in = h->d_pin_mapped + kHdrFloats, *m_out = m_in + (size_t)h->max_channels * hop;
+        const int rc = run_chain(h, m_in, m_out, nch, 1, hop, h->d_pin_mapped, 0, 1, true, -1);
+        if (rc != PV_OK) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else {
+        float *dq_in = h->d_quantum + kHdrFloats, *dq_out = dq_in + (size_t)h->max_channels * hop;
+        HIPCHK(h, hipMemcpyAsync(h->d_quantum, h->h_pin, sizeof(float) * (kHdrFloats + (size_t)nch * hop), hipMemcpyHostToDevice, h->stream));
+        const int rc = run_chain(h, dq_in, dq_out, nch, 1, hop, h->d_quantum, 0, 1, true, -1);
+        if (rc != PV_OK) return rc;
+        HIPCHK(h, hipMemcpyAsync(pin_out, dq_out, sizeof(float) * (size_t)nch * hop, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     for (int c = 0; c < nch; c++)
         if (out[c]) memcpy(out[c], pin_out + (size_t)c * hop, sizeof(float) * hop);
     return PV_OK;                                                                // ola-processor.js:170: return true
