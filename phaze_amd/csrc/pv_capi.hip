@@ -114,6 +114,7 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     { const char *ab = getenv("PHAZE_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
     if (dbg_ch >= 0) { p.dbg_X = h->d_dbgX; p.dbg_mag = h->d_dbgMag; p.dbg_flags = h->d_dbgFlags; p.dbg_Y = h->d_dbgY; p.dbg_ch = dbg_ch; p.dbg_frame = 0; }
     const int nchunks = (nhops + p.frames_per_chunk - 1) / p.frames_per_chunk;
+    if (nch > 65535) return fail(h, PV_ERR_CAPACITY, "more than 65535 channel slots in one launch (grid.y limit): split the call");
     h->last_frames_per_chunk = p.frames_per_chunk;
     hipError_t e = h->use_wave ? pv_launch_wave(p, nch, nchunks, h->stream)
                  : h->use_wg ? pv_launch_wg(h->log2n, p, nch, nchunks, h->stream)
