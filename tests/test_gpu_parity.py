@@ -169,9 +169,10 @@ def test_oracle_parity_random_configs():
     print("worst rms vs oracle", worst)
 
 
-def test_per_stream_pitch_rows_and_channel_independence():
-    """Batched independent processors: channel c uses pitch row c // channels_per_stream; K5: stereo == two monos."""
-    fft, hop, T = 1024, 256, 16
+@pytest.mark.parametrize("fft,hop", [(512, 128), (1024, 256), (2048, 512), (4096, 512)])
+def test_per_stream_pitch_rows_and_channel_independence(fft, hop):
+    """Batched independent processors: channel c uses pitch row c // channels_per_stream; K5: stereo == two monos.  One size per kernel."""
+    T = 16
     x = np.stack([S.make_signal("noise", c, T * hop) for c in range(4)])
     rows = np.stack([np.full(T, 1.5, np.float32), np.full(T, 0.8, np.float32)])
     pv = _pv(fft_size=fft, hop_size=hop, max_channels=4, max_hops=T)
