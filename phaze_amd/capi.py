@@ -12,7 +12,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libphaze_amd.so")
+_LIB_PATH = os.environ.get("PHAZE_LIB") or os.path.join(_HERE, "lib", "libphaze_amd.so")   # PHAZE_LIB: A/B builds of the same ABI
 _lib = None
 
 PV_OK, PV_ERR_FFT_SIZE, PV_ERR_ARGUMENT, PV_ERR_UNSUPPORTED, PV_ERR_CAPACITY, PV_ERR_DEVICE, PV_ERR_DESTROYED = range(7)

@@ -82,7 +82,7 @@ __device__ __forceinline__ float2 rotate_route(unsigned route, float2 v, const f
 {
     const unsigned ridx = route >> 16;
     if (R_ == 4) {
-        const unsigned qd = ridx >> (LOG2N_ - 2);
+        const unsigned qd = (ridx >> (LOG2N_ - 2)) & 3u;                  // bits above the rotation index are don't-care
         const bool sw = (qd & 1u) != 0u;
         const float a = sw ? v.y : v.x, b = sw ? v.x : v.y;
         return float2{__uint_as_float(__float_as_uint(a) ^ ((((qd + 1u) >> 1) & 1u) << 31)), __uint_as_float(__float_as_uint(b) ^ ((qd >> 1) << 31))};

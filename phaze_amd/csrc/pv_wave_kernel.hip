@@ -84,7 +84,7 @@ __device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const flo
 {
     unsigned pend = 0;
 #pragma unroll
-    for (int r = 0; r < NS; r++) pend |= (rt[r] != NOROUTE) ? (1u << r) : 0u;
+    for (int r = 0; r < NS; r++) pend |= ((rt[r] & 0xFFFFu) < 513u) ? (1u << r) : 0u;   // valid route <=> target field < H
     while (__any(pend != 0u)) {
 #pragma unroll
         for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[rt[r] & 0xFFFFu] = (unsigned short)id[r];
@@ -198,6 +198,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
     constexpr int N = 1024, M = 512, H = 513;
     constexpr int HOP = 128 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;    // LROWS rows of carried accumulator
     constexpr int BIG = 1 << 30;
+    constexpr int DROP = 0x4000;                                          // shift sentinel: b + DROP >= H for every bin b
     const int l = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ch = blockIdx.y, chunk = blockIdx.x * WAVES + wv;
@@ -234,6 +235,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
     }
     __syncthreads();                                                     // the only workgroup-wide barrier
     if (chunk >= p.nchunks) return;
+#ifdef PHAZE_EXP_STAGGER
+    for (int i = 0; i < wv; i++) __builtin_amdgcn_s_sleep(PHAZE_EXP_STAGGER);
+#endif
 
     const unsigned wave_off = TAB_BYTES + wv * WAVE_LDS;
     unsigned char *smem = smem_all + wave_off;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
     float *MAG = reinterpret_cast<float *>(smem + OFF_ROUTE);            // MAG[4 + k], k in [-4, 524): |X|^2 exchange
     unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + OFF_ROUTE);    // aliases MAG once the flags are taken: route of source bin b
     unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + OFF_ROUTE);   // aliases ROUTE once the routes are in registers (f < 1)
-    short *PSH = reinterpret_cast<short *>(smem + OFF_PSH);              // Math.round(p * f) per candidate peak bin p (0x7FFF: dropped)
+    short *DSH = reinterpret_cast<short *>(smem + OFF_PSH);              // shift Math.round(p * f) - p per candidate peak bin p (DROP: peak dropped)
     unsigned psh_key = 0x7FC12345u;                                      // bit pattern of the f the table was built for (starts invalid)
 
     const int first_out = chunk * p.frames_per_chunk;
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
 #pragma unroll
         for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
         if (m + 1 < last_out) load_rows(&raw[8 - S_ROWS], S_ROWS, 8 - S_ROWS, m + 1);
-        // ---- Math.round(peak * f) (pv:125) for every possible peak bin, cached while f does not change ----
+        // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change ----
         {
             const unsigned pfb = __float_as_uint(pitch_row[m]);
             if (pfb != psh_key) {
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
                     const int pk = l + 64 * r;
                     const double ps = floor((double)pk * pf + 0.5);                 // x + 0.5 is exact here (<= 37 significant bits)
                     const bool ok = (ps <= (double)H) && (ps >= -(double)(2 * N));   // pv:127-129; NaN -> not ok
-                    PSH[pk] = ok ? (short)(int)ps : (short)0x7FFF;
+                    DSH[pk] = ok ? (short)((int)ps - pk) : (short)DROP;             // DROP pushes every target of the region out of range
                 }
             }
         }
@@ -374,26 +378,30 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
             const float2 q3 = *reinterpret_cast<const float2 *>(&MAG[4 + 8 * l + 8]);
             mg[0] = q0.x; mg[1] = q0.y; mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w;
             mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w; mg[10] = q3.x; mg[11] = q3.y;
-            unsigned bits = 0;
+            // flags as lane masks; the nearest own peak at or below / above each of the 8 bins by two select chains
+            bool fl[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int k = 8 * l + i;
                 const float c = mg[i + 2];
-                const bool f = (k >= 2) && (k < H - 2) && (mg[i + 1] < c) && (mg[i] < c) && (mg[i + 3] < c) && (mg[i + 4] < c);
-                bits |= f ? (1u << i) : 0u;
+                fl[i] = (k >= 2) && (k < H - 2) && (mg[i + 1] < c) && (mg[i] < c) && (mg[i + 3] < c) && (mg[i + 4] < c);
             }
             if (dbg) {
-                p.dbg_flags[8 * l + 0] = bits & 1; p.dbg_flags[8 * l + 1] = (bits >> 1) & 1; p.dbg_flags[8 * l + 2] = (bits >> 2) & 1;
-                p.dbg_flags[8 * l + 3] = (bits >> 3) & 1; p.dbg_flags[8 * l + 4] = (bits >> 4) & 1; p.dbg_flags[8 * l + 5] = (bits >> 5) & 1;
-                p.dbg_flags[8 * l + 6] = (bits >> 6) & 1; p.dbg_flags[8 * l + 7] = (bits >> 7) & 1;
-                for (int i = 0; i < 8; i++) p.dbg_mag[8 * l + i] = mg[i + 2];
+#pragma unroll
+                for (int i = 0; i < 8; i++) { p.dbg_flags[8 * l + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * l + i] = mg[i + 2]; }
                 if (l == 63) { p.dbg_flags[512] = 0; p.dbg_mag[512] = mg[10]; }
             }
+            int lastown[8], firstown[8];                                    // last own peak <= bin i / first own peak > bin i
+            int cur = -BIG;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur = fl[i] ? 8 * l + i : cur; lastown[i] = cur; }
+            int nx = BIG;
+#pragma unroll
+            for (int i = 7; i >= 0; i--) { firstown[i] = nx; nx = fl[i] ? 8 * l + i : nx; }
+            const int last_in = cur, first_in = nx;
             // nearest peak below / above this lane's byte: the 64-bit ballot of non-empty lanes locates the neighbour lane,
             // one bpermute each fetches its last / first peak (two independent LDS round trips instead of a 6-step scan)
-            const int last_in = bits ? 8 * l + 31 - __clz((int)bits) : -BIG;
-            const int first_in = bits ? 8 * l + __ffs((int)bits) - 1 : BIG;
-            const unsigned long long occ = __ballot(bits != 0u);
+            const unsigned long long occ = __ballot(cur >= 0);
             const unsigned long long below = occ & ((1ull << l) - 1ull);
             const unsigned long long above = (l == 63) ? 0ull : (occ >> (l + 1));
             const int src_lo = below ? 63 - __clzll((long long)below) : 0;
@@ -401,43 +409,37 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
             int cprev = __shfl(last_in, src_lo, 64), cnext = __shfl(first_in, src_hi, 64);
             if (!below) cprev = -BIG;
             if (!above) cnext = BIG;
-            const int pm = bits ? last_in : cprev;                          // nearest peak at or below the end of this byte
-            last_peak = occ ? __shfl(last_in, 63 - __clzll((long long)occ), 64) : -1;
-            // owner rule (pv:132-141) + shift (pv:147-152) per source bin -> ROUTE = (rotation index << 16) | target, or ~0
-            // pv:132-141: regions tile [0, N); a bin belongs to the peak on its left iff it is strictly closer to it
-            // (b < prv + ceil(gap/2)  <=>  b - prv < nxt - b; the midpoint of an even gap goes right).  Sentinels make the
-            // first region start at 0 (pv:132) and the last one end at N (pv:133).
-            auto route_of = [&](int b, int prv, int nxt) -> unsigned {
-                const int owner = (b - prv < nxt - b) ? prv : nxt;          // prv = -BIG / nxt = +BIG when absent
-                const bool has = (unsigned)owner < (unsigned)H;
-                const int ps = (int)PSH[has ? owner : 0];
-                const int delta = ps - owner;
-                const int tgt = b + delta;
-                const bool ok = has && (ps != 0x7FFF) && ((unsigned)tgt < (unsigned)H);   // pv:127-129, pv:150-152, negative index
-                const unsigned ridx = (unsigned)((delta & (N - 1)) * tmod) & (N - 1);      // (delta * t) mod N  (pv:155-157)
-                return ok ? ((ridx << 16) | (unsigned)tgt) : 0xFFFFFFFFu;
-            };
             unsigned rt[8];
+            unsigned rt512 = NOROUTE;
+            if (occ == 0ull) {                                              // no peak at all (wave-uniform): nothing moves (pv:122 loop is empty)
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const unsigned lowm = bits & ((2u << i) - 1u), highm = bits >> (i + 1);
-                const int prv = lowm ? 8 * l + 31 - __clz((int)lowm) : cprev;
-                const int nxt = highm ? 8 * l + i + __ffs((int)highm) : cnext;
-                rt[i] = route_of(8 * l + i, prv, nxt);
+                for (int i = 0; i < 8; i++) rt[i] = NOROUTE;
+            } else {
+                last_peak = __shfl(last_in, 63 - __clzll((long long)occ), 64);
+                // owner rule (pv:132-141): regions tile [0, N); a bin belongs to the peak on its left iff it is strictly closer to it
+                // (b < prv + ceil(gap/2)  <=>  b - prv < nxt - b; the midpoint of an even gap goes right).  Sentinels make the first
+                // region start at 0 (pv:132) and the last one end at N (pv:133); at least one side is a real peak here.
+                // shift (pv:147-152): ROUTE = ((delta * t) mod N) << 16 | target; a route is valid iff its target field is < H
+                // (pv:127-129 via DROP, pv:150-152, negative index); bits above the 10 rotation bits are don't-care.
+                auto route_of = [&](int b, int prv, int nxt) -> unsigned {
+                    const int owner = (b - prv < nxt - b) ? prv : nxt;
+                    const int delta = (int)DSH[owner];
+                    return __builtin_amdgcn_perm((unsigned)__mul24(delta, tmod), (unsigned)(b + delta), 0x05040100u);
+                };
+#pragma unroll
+                for (int i = 0; i < 8; i++) rt[i] = route_of(8 * l + i, max(lastown[i], cprev), min(firstown[i], cnext));
+                if (l == 63) rt512 = route_of(512, max(last_in, cprev), BIG);   // source bin N/2: owner is the last peak
             }
             // MAG is dead now (every lane has its 12 magnitudes in registers): ROUTE aliases it
             wave_sync();
             *reinterpret_cast<uint4 *>(&ROUTE[8 * l]) = uint4{rt[0], rt[1], rt[2], rt[3]};
             *reinterpret_cast<uint4 *>(&ROUTE[8 * l + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
-            if (l == 63) ROUTE[512] = route_of(512, pm, BIG);               // source bin N/2: owner is the last peak
+            if (l == 63) ROUTE[512] = rt512;
         }
         int upper_end = H;
         if (last_peak >= 0) {
-            const int ps = (int)PSH[last_peak];
-            if (ps != 0x7FFF) {
-                const int d = ps - last_peak;
-                if (d < 0) { upper_end = H - d; if (upper_end > N) upper_end = N; }
-            }
+            const int d = (int)DSH[last_peak];
+            if (d < 0) { upper_end = H - d; if (upper_end > N) upper_end = N; }      // DROP is positive
         }
         // ---- zero Y (pv:121); the transposes of the forward FFT are done with the scratch ----
         if (!(ablate & 8))
@@ -455,10 +457,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
                 if (!(ablate & 8))
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const unsigned rt = ROUTE[l + 64 * r];
-                    if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R, 10>(rt, X32[r], p.tw32);
+                    const unsigned rt = ROUTE[l + 64 * r], tg = rt & 0xFFFFu;
+                    if (tg < (unsigned)H) Y[tg] = rotate_route<R, 10>(rt, X32[r], p.tw32);
                 }
-                if (l == 0) { const unsigned rt = ROUTE[512]; if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R, 10>(rt, float2{x512f, 0.f}, p.tw32); }
+                if (l == 0) { const unsigned rt = ROUTE[512], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rotate_route<R, 10>(rt, float2{x512f, 0.f}, p.tw32); }
             } else {
                 unsigned rt[9];
                 float2 ys[9];
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
                 wave_sync();                                               // routes are in registers: CLAIM may overwrite ROUTE
                 claim_rounds<9>(rt, ys, id, Y, CLAIM);
                 if (need_res) {                                            // sources above Nyquist, all owned by the last peak (pv:133)
-                    const int up_delta = (int)PSH[last_peak < 0 ? 0 : last_peak] - last_peak;
+                    const int up_delta = (int)DSH[last_peak < 0 ? 0 : last_peak];
                     const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
                     residue_scatter_1024<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, wave_off, l, upper_end, up_delta,
                                             up_ridx, dbg ? p.dbg_X : nullptr);
