@@ -305,43 +305,48 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
 
         if (!(ablate & 1)) fft512_wave<double, false>(z, S64, TW1, TW2, l);
 
-        // ---- split pass: X[k] = E - j W^k O with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved) ----
-        float2 X32[8];                     // fp32 copy of the spectrum: the only thing the shift needs after the decisions
-        float x512f;
+        // ---- split pass in conjugate pairs: with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved),
+        //      X[k] = E - j W^k O and X[512-k] = conj(E + j W^k O).  Lane l owns the pairs k = l + 64 r, r < 4 (partner value from lane
+        //      64-l, register 7-r), i.e. bins XA[r] = X[l + 64 r] and XB[r] = X[512 - l - 64 r]; lane 0 also owns the self-paired bin 256.
+        float2 XA[4], XB[4];               // fp32 copy of the spectrum: the only thing the shift needs after the decisions
+        float2 x256f{0.f, 0.f};
         {
-            double2 X[8];
-            double x512 = 0.0;
             const int pl = (64 - l) & 63;
-            if (ablate & 2) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) X[r] = z[r];
-            } else
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                double2 zm{shfl_d(z[7 - r].x, pl), shfl_d(z[7 - r].y, pl)};
-                if (l == 0) zm = (r == 0) ? z[0] : z[8 - r > 7 ? 7 : 8 - r];
-                const double2 E{z[r].x + zm.x, z[r].y - zm.y};
-                const double2 O{z[r].x - zm.x, z[r].y + zm.y};
-                const double2 WO = cmul(wl, mul_w16<double, false>(O, r));     // W_1024^{l+64r} = W^l * W_16^r
-                X[r] = double2{E.x + WO.y, E.y - WO.x};
+            for (int r = 0; r < 4; r++) {
+                double2 xa, xb;
+                if (ablate & 2) {
+                    xa = z[r]; xb = z[7 - r];
+                } else {
+                    double2 zm{shfl_d(z[7 - r].x, pl), shfl_d(z[7 - r].y, pl)};
+                    if (l == 0) zm = (r == 0) ? z[0] : z[8 - r];              // 512 - 64 r = 64 (8 - r): own registers
+                    const double2 E{z[r].x + zm.x, z[r].y - zm.y};
+                    const double2 O{z[r].x - zm.x, z[r].y + zm.y};
+                    const double2 WO = cmul(wl, mul_w16<double, false>(O, r));     // W_1024^{l+64r} = W^l * W_16^r
+                    xa = double2{E.x + WO.y, E.y - WO.x};
+                    xb = double2{E.x - WO.y, -(E.y + WO.x)};
+                    if (r == 0 && l == 0) {
+                        // Z[0] is pre-halved: X[0] = 2(zr + zi), X[512] = 2(zr - zi), both real (bundle:447-508 keep Im = 0)
+                        xa = double2{2.0 * (z[0].x + z[0].y), 0.0};
+                        xb = double2{2.0 * (z[0].x - z[0].y), 0.0};
+                    }
+                }
+                // ---- |X|^2 -> f32 (pv:82-92), exchanged through LDS for the neighbour tests ----
+                MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                XA[r] = float2{(float)xa.x, (float)xa.y};
+                XB[r] = float2{(float)xb.x, (float)xb.y};
+                if (dbg) {
+                    const int ka = l + 64 * r, kb = 512 - ka;
+                    p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
+                    p.dbg_X[2 * kb] = xb.x; p.dbg_X[2 * kb + 1] = xb.y;
+                }
             }
             if (l == 0) {
-                // Z[0] is pre-halved: X[0] = 2(zr + zi), X[512] = 2(zr - zi), both real (bundle:447-508 keep Im = 0)
-                X[0] = double2{2.0 * (z[0].x + z[0].y), 0.0};
-                x512 = 2.0 * (z[0].x - z[0].y);
-            }
-            // ---- |X|^2 -> f32 (pv:82-92), exchanged through LDS for the neighbour tests ----
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                MAG[4 + l + 64 * r] = (float)(X[r].x * X[r].x + X[r].y * X[r].y);
-                X32[r] = float2{(float)X[r].x, (float)X[r].y};
-            }
-            if (l == 0) MAG[4 + 512] = (float)(x512 * x512);
-            x512f = (float)x512;
-            if (dbg) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) { const int k = l + 64 * r; p.dbg_X[2 * k] = X[r].x; p.dbg_X[2 * k + 1] = X[r].y; }
-                if (l == 0) { p.dbg_X[2 * 512] = x512; p.dbg_X[2 * 512 + 1] = 0.0; }
+                const double2 x256{2.0 * z[4].x, -2.0 * z[4].y};              // k = 256 pairs with itself: W^256 = -j, X = 2 conj(Z)
+                MAG[4 + 256] = (float)(x256.x * x256.x + x256.y * x256.y);
+                x256f = float2{(float)x256.x, (float)x256.y};
+                if (dbg) { p.dbg_X[2 * 256] = x256.x; p.dbg_X[2 * 256 + 1] = x256.y; }
             }
         }
         // slide the window: the rows the next frame adds are issued here and land behind the shift + inverse FFT
@@ -456,20 +461,25 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
             if (disjoint) {
                 if (!(ablate & 8))
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const unsigned rt = ROUTE[l + 64 * r], tg = rt & 0xFFFFu;
-                    if (tg < (unsigned)H) Y[tg] = rotate_route<R, 10>(rt, X32[r], p.tw32);
+                for (int r = 0; r < 4; r++) {
+                    const unsigned ra = ROUTE[l + 64 * r], ta = ra & 0xFFFFu;
+                    const unsigned rb = ROUTE[512 - l - 64 * r], tb = rb & 0xFFFFu;
+                    if (ta < (unsigned)H) Y[ta] = rotate_route<R, 10>(ra, XA[r], p.tw32);
+                    if (tb < (unsigned)H) Y[tb] = rotate_route<R, 10>(rb, XB[r], p.tw32);
                 }
-                if (l == 0) { const unsigned rt = ROUTE[512], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rotate_route<R, 10>(rt, float2{x512f, 0.f}, p.tw32); }
+                if (l == 0) { const unsigned rt = ROUTE[256], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rotate_route<R, 10>(rt, x256f, p.tw32); }
             } else {
                 unsigned rt[9];
                 float2 ys[9];
                 int id[9];
 #pragma unroll
-                for (int r = 0; r < 8; r++) { rt[r] = ROUTE[l + 64 * r]; ys[r] = rotate_route<R, 10>(rt[r], X32[r], p.tw32); id[r] = l + 64 * r; }
-                rt[8] = (l == 0) ? ROUTE[512] : NOROUTE;
-                ys[8] = rotate_route<R, 10>(rt[8], float2{x512f, 0.f}, p.tw32);
-                id[8] = 512;
+                for (int r = 0; r < 4; r++) {
+                    id[r] = l + 64 * r; rt[r] = ROUTE[id[r]]; ys[r] = rotate_route<R, 10>(rt[r], XA[r], p.tw32);
+                    id[4 + r] = 512 - l - 64 * r; rt[4 + r] = ROUTE[id[4 + r]]; ys[4 + r] = rotate_route<R, 10>(rt[4 + r], XB[r], p.tw32);
+                }
+                rt[8] = (l == 0) ? ROUTE[256] : NOROUTE;
+                ys[8] = rotate_route<R, 10>(rt[8], x256f, p.tw32);
+                id[8] = 256;
                 wave_sync();                                               // routes are in registers: CLAIM may overwrite ROUTE
                 claim_rounds<9>(rt, ys, id, Y, CLAIM);
                 if (need_res) {                                            // sources above Nyquist, all owned by the last peak (pv:133)
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
             const float sc = 1.0f / (float)N;
             if (ablate & 8) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) zi[r] = float2{X32[r].x * sc, X32[r].y * sc};
+                for (int r = 0; r < 8; r++) zi[r] = float2{XA[r & 3].x * sc, XB[r & 3].y * sc};
             } else
 #pragma unroll
             for (int r = 0; r < 8; r++) {
