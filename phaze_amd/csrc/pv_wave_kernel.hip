@@ -503,16 +503,30 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
             if (ablate & 8) {
 #pragma unroll
                 for (int r = 0; r < 8; r++) zi[r] = float2{XA[r & 3].x * sc, XB[r & 3].y * sc};
-            } else
+            } else {
+                // conjugate pairs again: with E = Yk + conj(Ym), O = Yk - conj(Ym), c = e^{+2 pi j k/N} O (m = 512 - k):
+                // Z[k] = (E + j c) / N and Z[m] = conj(E - j c) / N; lane l computes k = l + 64 r, r < 4, and hands Z[m] to lane 64-l, register 7-r
+                const int pl = (64 - l) & 63;
+                float2 zb[4];
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int k = l + 64 * r;
-                float2 yk = Y[k], ym = Y[M - k];
-                if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
-                const float2 E{yk.x + ym.x, yk.y - ym.y};
-                const float2 O{yk.x - ym.x, yk.y + ym.y};
-                const float2 c = cmul(wlf, mul_w16<float, true>(O, r));
-                zi[r] = float2{(E.x - c.y) * sc, (E.y + c.x) * sc};
+                for (int r = 0; r < 4; r++) {
+                    const int k = l + 64 * r;
+                    float2 yk = Y[k], ym = Y[M - k];
+                    if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
+                    const float2 E{yk.x + ym.x, yk.y - ym.y};
+                    const float2 O{yk.x - ym.x, yk.y + ym.y};
+                    const float2 c = cmul(wlf, mul_w16<float, true>(O, r));
+                    zi[r] = float2{(E.x - c.y) * sc, (E.y + c.x) * sc};
+                    zb[r] = float2{(E.x + c.y) * sc, (c.x - E.y) * sc};
+                }
+                const float2 y256 = Y[256];
+                // lane 0 pairs with itself one register higher (512 - 64 r = 64 (8 - r)); its register 4 is the self-paired bin 256
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float2 snd = (l == 0 && r < 3) ? zb[r + 1] : zb[r];
+                    zi[7 - r] = float2{__shfl(snd.x, pl, 64), __shfl(snd.y, pl, 64)};
+                }
+                if (l == 0) zi[4] = float2{2.0f * y256.x * sc, -2.0f * y256.y * sc};
             }
         }
         wave_sync();
