@@ -24,6 +24,7 @@
 
 #include "pv_kernels.h"
 #include "pv_device_common.h"
+#include "pv_pk_math.h"
 
 namespace {
 
@@ -70,6 +71,44 @@ __device__ __forceinline__ void fft512_wave(typename v2t<T>::type (&a)[8], typen
     wave_sync();
     // pass 3: DFT over n0 -> k2; lane l now holds X[l + 64 k2]
     radix8<T, INV>(a);
+}
+
+
+// The inverse instance in packed fp32 (pv_pk_math.h): same layouts and tables, 106 packed instructions instead of ~210.
+__device__ __forceinline__ void fft512_wave_inv_pk(pk::c32 (&a)[8], pk::c32 *S, const pk::c32 *TW1, const pk::c32 *TW2, int l)
+{
+    const int lh = l >> 3, ll = l & 7;
+    pk::radix8_inv(a);
+#pragma unroll
+    for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], TW1[k * 64 + l]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k * TP + l] = a[k];
+    wave_sync();
+#pragma unroll
+    for (int n = 0; n < 8; n++) a[n] = S[lh * TP + 8 * n + ll];
+    wave_sync();
+    pk::radix8_inv(a);
+#pragma unroll
+    for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], TW2[k * 8 + ll]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k * TP + lh * 8 + ((ll + lh) & 7)] = a[k];
+    wave_sync();
+#pragma unroll
+    for (int n = 0; n < 8; n++) a[n] = S[lh * TP + ll * 8 + ((n + ll) & 7)];
+    wave_sync();
+    pk::radix8_inv(a);
+}
+
+// o * exp(+2 pi j r / 16), r = 0..3 (compile-time): the wave-uniform part of the c2r twiddle, packed
+__device__ __forceinline__ pk::c32 mul_w16_inv_pk(pk::c32 o, int r)
+{
+    const float c = 0.92387953251128675613f, sn = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    switch (r) {
+    case 0: return o;
+    case 1: return pk::cmul(o, pk::c32{c, sn});
+    case 2: return pk::mul(pk::add_j(o, o), pk::c32{h, h});
+    default: return pk::cmul(o, pk::c32{sn, c});
+    }
 }
 
 
@@ -266,6 +305,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
 
     const double2 wl = p.tw64[l];          // split pass: W_1024^{l + 64 r} = wl * W_16^r (W_16^r is wave-uniform)
     const float2 wlf = cconj(p.tw32[l]);
+    const pk::c32 wlfs{wlf.x * (1.0f / (float)N), wlf.y * (1.0f / (float)N)};   // c2r twiddle with the 1/N of the inverse folded in (exact)
 
     // ---- carried overlap-add accumulator in registers: row r <-> samples 2l + 128 r (+1) ----
     float2 acc[8];
@@ -496,41 +536,42 @@ __global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKer
             for (int r = 0; r < 8; r++) { const int k = l + 64 * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
             if (l == 0) { p.dbg_Y[1024] = Y[512].x; p.dbg_Y[1025] = Y[512].y; }
         }
-        // ---- c2r pre-pass (bundle:69-76,102-114 folded): Z[k] = ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)) / N ----
-        float2 zi[8];
+        // ---- c2r pre-pass (bundle:69-76,102-114 folded): Z[k] = ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)) / N, packed fp32 ----
+        pk::c32 zi[8];
         {
             const float sc = 1.0f / (float)N;
+            const pk::c32 scsc{sc, sc};
+            const pk::c32 *Yc = reinterpret_cast<const pk::c32 *>(Y);
             if (ablate & 8) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) zi[r] = float2{XA[r & 3].x * sc, XB[r & 3].y * sc};
+                for (int r = 0; r < 8; r++) zi[r] = pk::c32{XA[r & 3].x * sc, XB[r & 3].y * sc};
             } else {
-                // conjugate pairs again: with E = Yk + conj(Ym), O = Yk - conj(Ym), c = e^{+2 pi j k/N} O (m = 512 - k):
-                // Z[k] = (E + j c) / N and Z[m] = conj(E - j c) / N; lane l computes k = l + 64 r, r < 4, and hands Z[m] to lane 64-l, register 7-r
+                // conjugate pairs again: with E = Yk + conj(Ym), O = Yk - conj(Ym), c = e^{+2 pi j k/N} O / N (m = 512 - k):
+                // Z[k] = E / N + j c and Z[m] = conj(E / N - j c); lane l computes k = l + 64 r, r < 4, and hands Z[m] to lane 64-l, register 7-r
                 const int pl = (64 - l) & 63;
-                float2 zb[4];
+                pk::c32 zb[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int k = l + 64 * r;
-                    float2 yk = Y[k], ym = Y[M - k];
+                    pk::c32 yk = Yc[k], ym = Yc[M - k];
                     if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
-                    const float2 E{yk.x + ym.x, yk.y - ym.y};
-                    const float2 O{yk.x - ym.x, yk.y + ym.y};
-                    const float2 c = cmul(wlf, mul_w16<float, true>(O, r));
-                    zi[r] = float2{(E.x - c.y) * sc, (E.y + c.x) * sc};
-                    zb[r] = float2{(E.x + c.y) * sc, (c.x - E.y) * sc};
+                    const pk::c32 E = pk::add_conj(yk, ym), O = pk::sub_conj(yk, ym);
+                    const pk::c32 c = pk::cmul(mul_w16_inv_pk(O, r), wlfs);
+                    zi[r] = pk::fma_addj(E, scsc, c);
+                    zb[r] = pk::fma_conj_subj(E, scsc, c);
                 }
-                const float2 y256 = Y[256];
+                const pk::c32 y256 = Yc[256];
                 // lane 0 pairs with itself one register higher (512 - 64 r = 64 (8 - r)); its register 4 is the self-paired bin 256
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float2 snd = (l == 0 && r < 3) ? zb[r + 1] : zb[r];
-                    zi[7 - r] = float2{__shfl(snd.x, pl, 64), __shfl(snd.y, pl, 64)};
+                    const pk::c32 snd = (l == 0 && r < 3) ? zb[r + 1] : zb[r];
+                    zi[7 - r] = pk::c32{__shfl(snd.x, pl, 64), __shfl(snd.y, pl, 64)};
                 }
-                if (l == 0) zi[4] = float2{2.0f * y256.x * sc, -2.0f * y256.y * sc};
+                if (l == 0) zi[4] = pk::c32{2.0f * y256.x * sc, -2.0f * y256.y * sc};
             }
         }
         wave_sync();
-        if (!(ablate & 16)) fft512_wave<float, true>(zi, S32, TW1F, TW2F, l);
+        if (!(ablate & 16)) fft512_wave_inv_pk(zi, reinterpret_cast<pk::c32 *>(S32), reinterpret_cast<const pk::c32 *>(TW1F), reinterpret_cast<const pk::c32 *>(TW2F), l);
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         {
             const bool emit_out = (m >= first_out);
