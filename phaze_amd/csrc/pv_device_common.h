@@ -3,6 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Measured on gfx950 (tools/lds_microbench.hip): ds_read2_b64 / ds_read2st64_b64 / ds_read2_b32 occupy the LDS pipe for 8 cycles, twice
+// the cost of the two single reads they replace (2 + 2); ds_write2_b64 is neutral.  The SI load/store optimizer forms them wherever
+// two reads share a base register (Hann tables, the fp32 transposes), so the kernels opt out of it per function.  The attribute only
+// means something to the device pass.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PV_NO_DS_MERGE __attribute__((target("no-load-store-opt")))
+#else
+#define PV_NO_DS_MERGE
+#endif
+
 namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));   // clang vector type (the nontemporal builtins need one)

@@ -155,7 +155,7 @@ constexpr int WAVE_LDS = 9216 + 1024;
 // by re-running the reference's stage structure (bundle:306-442,468-508) on that quarter in fp32 -- and add those sources into Y.
 // Kept out of line so that its registers do not count against the main pipeline (3 waves per SIMD need <= 168 VGPRs).
 template <int R_>
-__device__ __attribute__((noinline)) void residue_scatter_1024(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
                                                                const float2 *__restrict__ tw32, unsigned wave_off, int l, int upper_end, int up_delta,
                                                                unsigned up_ridx, double *dbg_X)
 {
@@ -231,7 +231,7 @@ __device__ __attribute__((noinline)) void residue_scatter_1024(const float *in, 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
 // AUX = true: test-tap / phase-ablation build (pv_debug_frame, PHAZE_ABLATE); the production instance carries neither.
 template <int S_ROWS, bool AUX>
-__global__ __launch_bounds__(64 * WAVES, 3) void pv_wave_kernel_1024(const PvKernelParams p)
+__global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1024(const PvKernelParams p)
 {
     const int ablate = AUX ? p.ablate : 0;                                // phase-ablation build (profiling only); folds away otherwise
     constexpr int N = 1024, M = 512, H = 513;

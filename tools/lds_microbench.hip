@@ -10,7 +10,7 @@
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
-enum Op { RD32, RD64, RD128, WR32, WR64, WR128 };
+enum Op { RD32, RD64, RD128, WR32, WR64, WR128, RD2ST64_B64, RD2_B64_72, WR2_B64_72, RD2_B32_1, BPERM };
 
 template <int OP>
 __global__ __launch_bounds__(1024) void kern(const int *offs, long long *cycles, int iters)
@@ -31,6 +31,11 @@ __global__ __launch_bounds__(1024) void kern(const int *offs, long long *cycles,
             if (OP == RD128) { v4f x; asm volatile("ds_read_b128 %0, %1" : "=v"(x) : "v"(a)); (void)x; }
             if (OP == WR32) asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v.x) : "memory");
             if (OP == WR64) asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v2) : "memory");
+            if (OP == RD2ST64_B64) { v4f x; asm volatile("ds_read2st64_b64 %0, %1 offset1:1" : "=v"(x) : "v"(a)); (void)x; }
+            if (OP == RD2_B64_72) { v4f x; asm volatile("ds_read2_b64 %0, %1 offset1:72" : "=v"(x) : "v"(a)); (void)x; }
+            if (OP == WR2_B64_72) asm volatile("ds_write2_b64 %0, %1, %2 offset1:72" ::"v"(a), "v"(v2), "v"(v2) : "memory");
+            if (OP == RD2_B32_1) { v2f x; asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(x) : "v"(a)); (void)x; }
+            if (OP == BPERM) { float x; asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(x) : "v"(a), "v"(v.x)); (void)x; }
             if (OP == WR128) asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -50,7 +55,8 @@ static double run(int op, const std::vector<int> &offs, int waves)
     for (int rep = 0; rep < 1; rep++) {
         switch (op) {
         case RD32: launch(kern<RD32>); break; case RD64: launch(kern<RD64>); break; case RD128: launch(kern<RD128>); break;
-        case WR32: launch(kern<WR32>); break; case WR64: launch(kern<WR64>); break; case WR128: launch(kern<WR128>); break;
+        case WR32: launch(kern<WR32>); break; case WR64: launch(kern<WR64>); break; case WR128: launch(kern<WR128>); break; case RD2ST64_B64: launch(kern<RD2ST64_B64>); break; case RD2_B64_72: launch(kern<RD2_B64_72>); break;
+        case WR2_B64_72: launch(kern<WR2_B64_72>); break; case RD2_B32_1: launch(kern<RD2_B32_1>); break; case BPERM: launch(kern<BPERM>); break;
         }
         hipDeviceSynchronize();
     }
@@ -72,24 +78,20 @@ int main()
     add("wr32 contiguous", WR32, [](int l) { return 4 * l; });
     add("wr64 contiguous", WR64, [](int l) { return 8 * l; });
     add("wr128 contiguous", WR128, [](int l) { return 16 * l; });
-    // the consecutive-8-bins-per-lane layout: dword index 8l (+ pad c per 64-dword row, i.e. per 8 lanes), byte = 4 * (...)
-    for (int c : {0, 2, 4, 8, 12, 16, 20, 24}) {
-        auto phys = [c](int k) { return 4 * (k + c * (k >> 6)); };
-        add("rd128 8l   rowpad " + std::to_string(c), RD128, [phys](int l) { return phys(8 * l); });
-        add("rd128 8l+4 rowpad " + std::to_string(c), RD128, [phys](int l) { return phys(8 * l + 4); });
-        add("wr128 8l   rowpad " + std::to_string(c), WR128, [phys](int l) { return phys(8 * l); });
-        add("wr128 8l+4 rowpad " + std::to_string(c), WR128, [phys](int l) { return phys(8 * l + 4); });
-        add("rd64  8l+8 rowpad " + std::to_string(c), RD64, [phys](int l) { return phys(8 * l + 8); });
-        add("rd64  8l-2 rowpad " + std::to_string(c), RD64, [phys](int l) { return phys(8 * l + 62) ; });
-    }
-    // pad per 4 lanes / per 2 lanes (k >> 5, k >> 4)
-    for (int sh : {5, 4}) for (int c : {4, 8}) {
-        auto phys = [c, sh](int k) { return 4 * (k + c * (k >> sh)); };
-        std::string tag = " pad" + std::to_string(c) + "per" + std::to_string(1 << (sh - 3)) + "lanes";
-        add("rd128 8l  " + tag, RD128, [phys](int l) { return phys(8 * l); });
-        add("wr128 8l  " + tag, WR128, [phys](int l) { return phys(8 * l); });
-        add("rd64  8l+8" + tag, RD64, [phys](int l) { return phys(8 * l + 8); });
-    }
+    add("rd2st64_b64 contiguous (Hann pair)", RD2ST64_B64, [](int l) { return 8 * l; });
+    add("rd2_b64 +72 contiguous", RD2_B64_72, [](int l) { return 8 * l; });
+    add("wr2_b64 +72 contiguous (T1f pair)", WR2_B64_72, [](int l) { return 8 * l; });
+    add("rd2_b64 +72 T1f read", RD2_B64_72, [](int l) { return 8 * ((l >> 3) * 72 + (l & 7)); });
+    add("rd2_b32 +1 stride 8B", RD2_B32_1, [](int l) { return 8 * l; });
+    add("bpermute lane 64-l", BPERM, [](int l) { return 4 * ((64 - l) & 63); });
+    add("bpermute identity", BPERM, [](int l) { return 4 * l; });
+    add("bpermute broadcast 5", BPERM, [](int l) { return 4 * 5; });
+    add("rd u16-ish random (b32 stride 2B*k)", RD32, [](int l) { return 4 * ((l * 37) & 255); });
+    add("wr64 random-ish", WR64, [](int l) { return 8 * ((l * 37) & 511); });
+    add("rd128 8l rowpad 0", RD128, [](int l) { return 4 * (8 * l); });
+    add("wr128 8l rowpad 0", WR128, [](int l) { return 4 * (8 * l); });
+    add("wr128 8l pad4per4lanes", WR128, [](int l) { return 4 * (8 * l + 4 * (l >> 2)); });
+    add("rd128 8l pad4per4lanes", RD128, [](int l) { return 4 * (8 * l + 4 * (l >> 2)); });
     // fp64 transposes of fft512_wave (TP = 72 double2 per row)
     add("T1 wr128 S[k*72+l]", WR128, [](int l) { return 16 * (3 * 72 + l); });
     add("T1 rd128 S[lh*72+8n+ll]", RD128, [](int l) { return 16 * ((l >> 3) * 72 + 8 * 3 + (l & 7)); });
