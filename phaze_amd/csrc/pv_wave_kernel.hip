@@ -417,10 +417,13 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
             if (l == 63) ROUTE[512] = 512u;
         } else {
             float mg[12];
-            const float2 q0 = *reinterpret_cast<const float2 *>(&MAG[4 + 8 * l - 2]);
-            const float4 q1 = *reinterpret_cast<const float4 *>(&MAG[4 + 8 * l]);
-            const float4 q2 = *reinterpret_cast<const float4 *>(&MAG[4 + 8 * l + 4]);
-            const float2 q3 = *reinterpret_cast<const float2 *>(&MAG[4 + 8 * l + 8]);
+            // volatile vector loads: otherwise the optimizer re-pairs the 12 floats into five misaligned ds_read2_b32 (8 LDS cycles each)
+            typedef const volatile __attribute__((address_space(3))) v2f *lds_v2f;
+            typedef const volatile __attribute__((address_space(3))) v4f *lds_v4f;
+            const v2f q0 = *(lds_v2f)(&MAG[4 + 8 * l - 2]);
+            const v4f q1 = *(lds_v4f)(&MAG[4 + 8 * l]);
+            const v4f q2 = *(lds_v4f)(&MAG[4 + 8 * l + 4]);
+            const v2f q3 = *(lds_v2f)(&MAG[4 + 8 * l + 8]);
             mg[0] = q0.x; mg[1] = q0.y; mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w;
             mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w; mg[10] = q3.x; mg[11] = q3.y;
             // flags as lane masks; the nearest own peak at or below / above each of the 8 bins by two select chains
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
             for (int i = 0; i < 8; i++) {
                 const int k = 8 * l + i;
                 const float c = mg[i + 2];
-                fl[i] = (k >= 2) && (k < H - 2) && (mg[i + 1] < c) && (mg[i] < c) && (mg[i + 3] < c) && (mg[i + 4] < c);
+                fl[i] = (k >= 2) & (k < H - 2) & (mg[i + 1] < c) & (mg[i] < c) & (mg[i + 3] < c) & (mg[i + 4] < c);      // & not &&: no branches
             }
             if (dbg) {
 #pragma unroll
