@@ -351,15 +351,21 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
         float2 XA[4], XB[4];               // fp32 copy of the spectrum: the only thing the shift needs after the decisions
         float2 x256f{0.f, 0.f};
         {
-            const int pl = (64 - l) & 63;
+            // partner values through the (now free) transpose scratch: rows 4..7 written lane-contiguous, read back reversed.  Element
+            // 512 - k of the pair k = l + 64 r sits at (3 - r) * 64 + (64 - l) for every lane (lane 0: 64 (8 - r), its own register
+            // 8 - r); half the LDS cycles of sixteen bpermutes.  (l = 0, r = 0) reads one element past the rows: replaced below.
+            if (!(ablate & 2)) {
+#pragma unroll
+                for (int r = 4; r < 8; r++) S64[(r - 4) * 64 + l] = z[r];
+                wave_sync();
+            }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 double2 xa, xb;
                 if (ablate & 2) {
                     xa = z[r]; xb = z[7 - r];
                 } else {
-                    double2 zm{shfl_d(z[7 - r].x, pl), shfl_d(z[7 - r].y, pl)};
-                    if (l == 0) zm = (r == 0) ? z[0] : z[8 - r];              // 512 - 64 r = 64 (8 - r): own registers
+                    const double2 zm = S64[(3 - r) * 64 + 64 - l];
                     const double2 E{z[r].x + zm.x, z[r].y - zm.y};
                     const double2 O{z[r].x - zm.x, z[r].y + zm.y};
                     const double2 WO = cmul(wl, mul_w16<double, false>(O, r));     // W_1024^{l+64r} = W^l * W_16^r
@@ -551,7 +557,6 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
             } else {
                 // conjugate pairs again: with E = Yk + conj(Ym), O = Yk - conj(Ym), c = e^{+2 pi j k/N} O / N (m = 512 - k):
                 // Z[k] = E / N + j c and Z[m] = conj(E / N - j c); lane l computes k = l + 64 r, r < 4, and hands Z[m] to lane 64-l, register 7-r
-                const int pl = (64 - l) & 63;
                 pk::c32 zb[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -564,12 +569,15 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
                     zb[r] = pk::fma_conj_subj(E, scsc, c);
                 }
                 const pk::c32 y256 = Yc[256];
-                // lane 0 pairs with itself one register higher (512 - 64 r = 64 (8 - r)); its register 4 is the self-paired bin 256
+                // hand-over through LDS (the residue quarter buffer is free here): Z[m] of the pair (l', r') lands in lane 64 - l', register
+                // 7 - r'; read address r * 64 + 64 - l for every lane (lane 0 pairs with itself one register higher, and its register 4
+                // is the self-paired bin 256, replaced below)
+                pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem + OFF_RESQ);
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const pk::c32 snd = (l == 0 && r < 3) ? zb[r + 1] : zb[r];
-                    zi[7 - r] = pk::c32{__shfl(snd.x, pl, 64), __shfl(snd.y, pl, 64)};
-                }
+                for (int r = 0; r < 4; r++) XCH[r * 64 + l] = zb[r];
+                wave_sync();
+#pragma unroll
+                for (int r = 0; r < 4; r++) zi[7 - r] = XCH[r * 64 + 64 - l];
                 if (l == 0) zi[4] = pk::c32{2.0f * y256.x * sc, -2.0f * y256.y * sc};
             }
         }
