@@ -21,6 +21,7 @@
 // Semantics are those of pv_chain_kernel (same reference citations); tests run every kernel against the oracle.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "pv_kernels.h"
 #include "pv_device_common.h"
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
         // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded into the table (exact) ----
         double2 z[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { const float2 hwr = HW[l + 64 * r]; z[r] = double2{(double)(raw[r].x * hwr.x), (double)(raw[r].y * hwr.y)}; }
+        for (int r = 0; r < 8; r++) { const float2 hwr = HW[l + 64 * r]; const v2f xw = v2f{raw[r].x, raw[r].y} * v2f{hwr.x, hwr.y}; z[r] = double2{(double)xw.x, (double)xw.y}; }
 
         if (!(ablate & 1)) fft512_wave<double, false>(z, S64, TW1, TW2, l);
 
@@ -508,15 +509,32 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
             // For f >= 1, delta_i = round(p_i f) - p_i is non-decreasing in i, so the shifted regions stay disjoint: plain stores.
             const bool disjoint = (pf >= 1.0) || (ablate & 64);
             if (disjoint) {
-                if (!(ablate & 8))
+                // R = 4: every rotation of this frame is j^(delta * (m mod 4)); m mod 4 is wave-uniform, so a frame with m = 0 (mod 4) moves
+                // its bins unrotated and m = 2 (mod 4) only flips signs (bit 9 of the rotation index = bit 25 of the route)
+                auto scatter = [&](auto mode_tag) {
+                    constexpr int MODE = decltype(mode_tag)::value;
+                    auto rot = [&](unsigned rt, float2 v) -> float2 {
+                        if (MODE == 0) return v;
+                        if (MODE == 2) {
+                            const unsigned sg = (rt << 6) & 0x80000000u;
+                            return float2{__uint_as_float(__float_as_uint(v.x) ^ sg), __uint_as_float(__float_as_uint(v.y) ^ sg)};
+                        }
+                        return rotate_route<R, 10>(rt, v, p.tw32);
+                    };
+                    if (!(ablate & 8))
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const unsigned ra = ROUTE[l + 64 * r], ta = ra & 0xFFFFu;
-                    const unsigned rb = ROUTE[512 - l - 64 * r], tb = rb & 0xFFFFu;
-                    if (ta < (unsigned)H) Y[ta] = rotate_route<R, 10>(ra, XA[r], p.tw32);
-                    if (tb < (unsigned)H) Y[tb] = rotate_route<R, 10>(rb, XB[r], p.tw32);
-                }
-                if (l == 0) { const unsigned rt = ROUTE[256], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rotate_route<R, 10>(rt, x256f, p.tw32); }
+                    for (int r = 0; r < 4; r++) {
+                        const unsigned ra = ROUTE[l + 64 * r], ta = ra & 0xFFFFu;
+                        const unsigned rb = ROUTE[512 - l - 64 * r], tb = rb & 0xFFFFu;
+                        if (ta < (unsigned)H) Y[ta] = rot(ra, float2{XA[r].x, XA[r].y});
+                        if (tb < (unsigned)H) Y[tb] = rot(rb, float2{XB[r].x, XB[r].y});
+                    }
+                    if (l == 0) { const unsigned rt = ROUTE[256], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, float2{x256f.x, x256f.y}); }
+                };
+                const int mq = (R == 4) ? (tmod >> 8) : 1;
+                if (mq == 0) scatter(std::integral_constant<int, 0>{});
+                else if (mq == 2) scatter(std::integral_constant<int, 2>{});
+                else scatter(std::integral_constant<int, 1>{});
             } else {
                 unsigned rt[9];
                 float2 ys[9];

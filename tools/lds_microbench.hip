@@ -78,38 +78,23 @@ int main()
     add("wr32 contiguous", WR32, [](int l) { return 4 * l; });
     add("wr64 contiguous", WR64, [](int l) { return 8 * l; });
     add("wr128 contiguous", WR128, [](int l) { return 16 * l; });
-    add("rd2st64_b64 contiguous (Hann pair)", RD2ST64_B64, [](int l) { return 8 * l; });
-    add("rd2_b64 +72 contiguous", RD2_B64_72, [](int l) { return 8 * l; });
-    add("wr2_b64 +72 contiguous (T1f pair)", WR2_B64_72, [](int l) { return 8 * l; });
-    add("rd2_b64 +72 T1f read", RD2_B64_72, [](int l) { return 8 * ((l >> 3) * 72 + (l & 7)); });
-    add("rd2_b32 +1 stride 8B", RD2_B32_1, [](int l) { return 8 * l; });
-    add("bpermute lane 64-l", BPERM, [](int l) { return 4 * ((64 - l) & 63); });
-    add("bpermute identity", BPERM, [](int l) { return 4 * l; });
-    add("bpermute broadcast 5", BPERM, [](int l) { return 4 * 5; });
-    add("rd u16-ish random (b32 stride 2B*k)", RD32, [](int l) { return 4 * ((l * 37) & 255); });
-    add("wr64 random-ish", WR64, [](int l) { return 8 * ((l * 37) & 511); });
-    add("rd128 8l rowpad 0", RD128, [](int l) { return 4 * (8 * l); });
-    add("wr128 8l rowpad 0", WR128, [](int l) { return 4 * (8 * l); });
-    add("wr128 8l pad4per4lanes", WR128, [](int l) { return 4 * (8 * l + 4 * (l >> 2)); });
-    add("rd128 8l pad4per4lanes", RD128, [](int l) { return 4 * (8 * l + 4 * (l >> 2)); });
-    // fp64 transposes of fft512_wave (TP = 72 double2 per row)
-    add("T1 wr128 S[k*72+l]", WR128, [](int l) { return 16 * (3 * 72 + l); });
-    add("T1 rd128 S[lh*72+8n+ll]", RD128, [](int l) { return 16 * ((l >> 3) * 72 + 8 * 3 + (l & 7)); });
-    add("T2 wr128 skew", WR128, [](int l) { return 16 * (3 * 72 + (l >> 3) * 8 + (((l & 7) + (l >> 3)) & 7)); });
-    add("T2 rd128 skew", RD128, [](int l) { return 16 * ((l >> 3) * 72 + (l & 7) * 8 + ((3 + (l & 7)) & 7)); });
-    // fp32 versions (float2, TP = 72)
-    add("T1f wr64 S[k*72+l]", WR64, [](int l) { return 8 * (3 * 72 + l); });
-    add("T1f rd64 S[lh*72+8n+ll]", RD64, [](int l) { return 8 * ((l >> 3) * 72 + 8 * 3 + (l & 7)); });
-    add("T2f wr64 skew", WR64, [](int l) { return 8 * (3 * 72 + (l >> 3) * 8 + (((l & 7) + (l >> 3)) & 7)); });
-    add("T2f rd64 skew", RD64, [](int l) { return 8 * ((l >> 3) * 72 + (l & 7) * 8 + ((3 + (l & 7)) & 7)); });
-    // twiddle tables
-    add("TW2 rd128 [k*8+ll]", RD128, [](int l) { return 16 * (3 * 8 + (l & 7)); });
-    add("TW2F rd64 [k*8+ll]", RD64, [](int l) { return 8 * (3 * 8 + (l & 7)); });
-    add("Y rd64 reversed", RD64, [](int l) { return 8 * (512 - l); });
+    for (int mask = 0; mask < 32; mask++) {
+        auto P = [mask](int l) { return 4 * (((mask & 1) ? (l >> 1) : 0) + ((mask & 2) ? (l >> 2) : 0) + ((mask & 4) ? (l >> 3) : 0) + ((mask & 8) ? (l >> 4) : 0) + ((mask & 16) ? (l >> 5) : 0)); };
+        auto phys = [P](int k) { return 4 * (k + P(k >> 3)); };
+        std::string tag = " m" + std::to_string(mask);
+        add("rd128 8l  " + tag, RD128, [phys](int l) { return phys(8 * l); });
+        add("rd128 8l+4" + tag, RD128, [phys](int l) { return phys(8 * l + 4); });
+        add("wr128 8l  " + tag, WR128, [phys](int l) { return phys(8 * l); });
+        add("wr128 8l+4" + tag, WR128, [phys](int l) { return phys(8 * l + 4); });
+        add("rd64  8l+8" + tag, RD64, [phys](int l) { return phys(8 * l + 8); });
+        add("rd64  8l-2" + tag, RD64, [phys](int l) { return phys(8 * l + 6 + 56); });
+        add("wr32  l+64" + tag, WR32, [phys](int l) { return phys(l + 64); });
+        add("rd32  l+64" + tag, RD32, [phys](int l) { return phys(l + 64); });
+    }
     for (auto &p : pats) {
         std::vector<int> offs(64);
         for (int l = 0; l < 64; l++) offs[l] = p.f(l);
-        printf("%-40s  1 wave: %6.1f   8 waves: %6.1f  16 waves: %6.1f clk/instr\n", p.name.c_str(), run(p.op, offs, 1), run(p.op, offs, 8), run(p.op, offs, 16));
+        printf("%-40s  16 waves: %6.1f clk/instr\n", p.name.c_str(), run(p.op, offs, 16));
     }
     return 0;
 }
