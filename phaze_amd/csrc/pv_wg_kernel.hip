@@ -115,12 +115,12 @@ __device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename 
 }
 
 // Workgroup-wide claim rounds (see claim_rounds in pv_wave_kernel.hip): the loop condition is reduced over the workgroup.
-template <int NS>
+template <int NS, int H_>
 __device__ __forceinline__ void claim_rounds_wg(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned short *CLAIM)
 {
     unsigned pend = 0;
 #pragma unroll
-    for (int r = 0; r < NS; r++) pend |= (rt[r] != NOROUTE) ? (1u << r) : 0u;
+    for (int r = 0; r < NS; r++) pend |= ((rt[r] & 0xFFFFu) < (unsigned)H_) ? (1u << r) : 0u;   // valid route <=> target field < H
     while (__syncthreads_or(pend != 0u)) {
 #pragma unroll
         for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[rt[r] & 0xFFFFu] = (unsigned short)id[r];
@@ -149,7 +149,7 @@ __device__ __forceinline__ int digitrev4_(int v, int nd)
 // Rare path: above-Nyquist residue of fft.js's in-place real DIT, one quarter of the buffer at a time, then its sources
 // are added into Y.  Same structure as residue_scatter_1024, any LOG2N (radix-2 base stage when log2 N is odd: bundle:447-463).
 template <int LOG2N, int R_>
-__device__ __attribute__((noinline)) void residue_scatter_wg(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
                                                              const float2 *__restrict__ tw32, int t, int upper_end, int up_delta, unsigned up_ridx,
                                                              double *dbg_X)
 {
@@ -223,13 +223,13 @@ __device__ __attribute__((noinline)) void residue_scatter_wg(const float *in, co
             ys[j] = rotate_route<R_, LOG2N>(rt[j], Q[t + T * j], tw32);
             id[j] = b - N / 2;                                             // unique within a round, fits 16 bits for N = 8192
         }
-        claim_rounds_wg<4>(rt, ys, id, Y, CLAIM);
+        claim_rounds_wg<4, (1 << (LOG2N - 1)) + 1>(rt, ys, id, Y, CLAIM);
         __syncthreads();
     }
 }
 
 template <int LOG2N, int S_ROWS, bool AUX>
-__global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKernelParams p)
+__global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_kernel(const PvKernelParams p)
 {
     constexpr int G = 1 << (LOG2N - 10);
     using C = WgCfg<G>;
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
     const int Rrt = N / HOP;
     constexpr int LROWS = RING ? 0 : 8 - S_ROWS;
     constexpr int BIG = 1 << 30;
+    constexpr int DROP = 0x4000;                                        // shift sentinel: b + DROP >= H for every bin, above every real shift
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int ch = blockIdx.y, chunk = blockIdx.x;
     const int ablate = AUX ? p.ablate : 0;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
     float *MAG = reinterpret_cast<float *>(smem + C::OFF_ROUTE);
     unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);
     unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + C::OFF_ROUTE);
-    short *PSH = reinterpret_cast<short *>(smem + C::OFF_PSH);
+    short *DSH = reinterpret_cast<short *>(smem + C::OFF_PSH);          // shift per candidate peak bin (DROP: peak dropped)
     int *LASTIN = reinterpret_cast<int *>(smem + C::OFF_NEAR), *FIRSTIN = LASTIN + T;
     unsigned long long *OCC = reinterpret_cast<unsigned long long *>(smem + C::OFF_OCC);
     double2 *TWA = reinterpret_cast<double2 *>(smem + C::OFF_TWA);
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
             for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
             if (m + 1 < last_out) load_rows(&raw[8 - (RING ? 8 : S_ROWS)], S_ROWS, 8 - S_ROWS, m + 1);
         }
-        // ---- Math.round(peak * f) table (pv:125), rebuilt only when f changes ----
+        // ---- shift table Math.round(peak * f) - peak (pv:125,147), rebuilt only when f changes ----
         {
             const unsigned pfb = __float_as_uint(pitch_row[m]);
             if (pfb != psh_key) {
@@ -383,38 +384,47 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
                     const int pk = t + T * r;
                     const double ps = floor((double)pk * pf + 0.5);
                     const bool ok = (ps <= (double)H) && (ps >= -(double)(2 * N));
-                    PSH[pk] = ok ? (short)(int)ps : (short)0x7FFF;
+                    DSH[pk] = ok ? (short)((int)ps - pk) : (short)DROP;             // DROP pushes every target of the region out of range
                 }
             }
         }
         __syncthreads();
         // ---- peak flags on bins 8t..8t+7 (pv:95-116) ----
-        unsigned bits = 0;
+        int lastown[8], firstown[8];                                      // last own peak <= bin i / first own peak > bin i
+        int last_in, first_in;
         {
             float mg[12];
-            const float2 q0 = *reinterpret_cast<const float2 *>(&MAG[4 + 8 * t - 2]);
-            const float4 q1 = *reinterpret_cast<const float4 *>(&MAG[4 + 8 * t]);
-            const float4 q2 = *reinterpret_cast<const float4 *>(&MAG[4 + 8 * t + 4]);
-            const float2 q3 = *reinterpret_cast<const float2 *>(&MAG[4 + 8 * t + 8]);
+            // LDS-address-space vector loads: otherwise the optimizer re-pairs the 12 floats into misaligned ds_read2_b32 (8 LDS cycles each)
+            typedef const volatile __attribute__((address_space(3))) v2f *lds_v2f;
+            typedef const volatile __attribute__((address_space(3))) v4f *lds_v4f;
+            const v2f q0 = *(lds_v2f)(&MAG[4 + 8 * t - 2]);
+            const v4f q1 = *(lds_v4f)(&MAG[4 + 8 * t]);
+            const v4f q2 = *(lds_v4f)(&MAG[4 + 8 * t + 4]);
+            const v2f q3 = *(lds_v2f)(&MAG[4 + 8 * t + 8]);
             mg[0] = q0.x; mg[1] = q0.y; mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w;
             mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w; mg[10] = q3.x; mg[11] = q3.y;
+            bool fl[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int k = 8 * t + i;
                 const float c = mg[i + 2];
-                const bool f = (k >= 2) && (k < H - 2) && (mg[i + 1] < c) && (mg[i] < c) && (mg[i + 3] < c) && (mg[i + 4] < c);
-                bits |= f ? (1u << i) : 0u;
+                fl[i] = (k >= 2) & (k < H - 2) & (mg[i + 1] < c) & (mg[i] < c) & (mg[i + 3] < c) & (mg[i + 4] < c);      // & not &&: no branches
             }
             if (dbg) {
-                for (int i = 0; i < 8; i++) { p.dbg_flags[8 * t + i] = (bits >> i) & 1; p.dbg_mag[8 * t + i] = mg[i + 2]; }
+                for (int i = 0; i < 8; i++) { p.dbg_flags[8 * t + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * t + i] = mg[i + 2]; }
                 if (t == T - 1) { p.dbg_flags[M] = 0; p.dbg_mag[M] = mg[10]; }
             }
+            int cur = -BIG;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur = fl[i] ? 8 * t + i : cur; lastown[i] = cur; }
+            int nx = BIG;
+#pragma unroll
+            for (int i = 7; i >= 0; i--) { firstown[i] = nx; nx = fl[i] ? 8 * t + i : nx; }
+            last_in = cur; first_in = nx;
         }
         // ---- nearest peaks outside this thread's byte: per-wave occupancy ballots + per-thread last/first peak, through LDS ----
-        const int last_in = bits ? 8 * t + 31 - __clz((int)bits) : -BIG;
-        const int first_in = bits ? 8 * t + __ffs((int)bits) - 1 : BIG;
         {
-            const unsigned long long occ = __ballot(bits != 0u);
+            const unsigned long long occ = __ballot(last_in >= 0);
             LASTIN[t] = last_in;
             FIRSTIN[t] = first_in;
             if (l == 0) OCC[wv] = occ;
@@ -442,35 +452,31 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
             for (int w = G - 1; w >= 0; --w) { const unsigned long long o = OCC[w]; if (o) { last_peak = LASTIN[w * 64 + 63 - __clzll((long long)o)]; break; } }
         }
         {
-            auto route_of = [&](int b, int prv, int nxt) -> unsigned {
-                const int owner = (b - prv < nxt - b) ? prv : nxt;
-                const bool has = (unsigned)owner < (unsigned)H;
-                const int ps = (int)PSH[has && owner < M ? owner : 0];
-                const int delta = ps - owner;
-                const int tgt = b + delta;
-                const bool ok = has && (ps != 0x7FFF) && ((unsigned)tgt < (unsigned)H);
-                const unsigned ridx = (unsigned)((delta & (N - 1)) * tmod) & (N - 1);
-                return ok ? ((ridx << 16) | (unsigned)tgt) : NOROUTE;
-            };
             unsigned rt[8];
+            unsigned rtM = NOROUTE;
+            if (last_peak < 0) {                                            // no peak at all (workgroup-uniform): nothing moves
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const unsigned lowm = bits & ((2u << i) - 1u), highm = bits >> (i + 1);
-                const int prv = lowm ? 8 * t + 31 - __clz((int)lowm) : cprev;
-                const int nxt = highm ? 8 * t + i + __ffs((int)highm) : cnext;
-                rt[i] = route_of(8 * t + i, prv, nxt);
+                for (int i = 0; i < 8; i++) rt[i] = NOROUTE;
+            } else {
+                // owner rule (pv:132-141) + shift (pv:147-152): ROUTE = ((delta * t) mod N) << 16 | target; a route is valid iff its target
+                // field is < H (pv:127-129 via DROP, pv:150-152, negative index); bits above the rotation index are don't-care
+                auto route_of = [&](int b, int prv, int nxt) -> unsigned {
+                    const int owner = (b - prv < nxt - b) ? prv : nxt;      // at least one side is a real peak here
+                    const int delta = (int)DSH[owner];
+                    return __builtin_amdgcn_perm((unsigned)__mul24(delta, tmod), (unsigned)(b + delta), 0x05040100u);
+                };
+#pragma unroll
+                for (int i = 0; i < 8; i++) rt[i] = route_of(8 * t + i, max(lastown[i], cprev), min(firstown[i], cnext));
+                if (t == T - 1) rtM = route_of(M, max(last_in, cprev), BIG);
             }
             *reinterpret_cast<uint4 *>(&ROUTE[8 * t]) = uint4{rt[0], rt[1], rt[2], rt[3]};
             *reinterpret_cast<uint4 *>(&ROUTE[8 * t + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
-            if (t == T - 1) ROUTE[M] = route_of(M, bits ? last_in : cprev, BIG);
+            if (t == T - 1) ROUTE[M] = rtM;
         }
         int upper_end = H;
         if (last_peak >= 0) {
-            const int ps = (int)PSH[last_peak];
-            if (ps != 0x7FFF) {
-                const int d = ps - last_peak;
-                if (d < 0) { upper_end = H - d; if (upper_end > N) upper_end = N; }
-            }
+            const int d = (int)DSH[last_peak];
+            if (d < 0) { upper_end = H - d; if (upper_end > N) upper_end = N; }      // DROP is positive
         }
         // ---- zero Y (pv:121) ----
 #pragma unroll
@@ -484,10 +490,10 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
             if (disjoint) {
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const unsigned rt = ROUTE[t + T * r];
-                    if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R, LOG2N>(rt, X32[r], p.tw32);
+                    const unsigned rt = ROUTE[t + T * r], tg = rt & 0xFFFFu;
+                    if (tg < (unsigned)H) Y[tg] = rotate_route<R, LOG2N>(rt, X32[r], p.tw32);
                 }
-                if (t == 0) { const unsigned rt = ROUTE[M]; if (rt != NOROUTE) Y[rt & 0xFFFFu] = rotate_route<R, LOG2N>(rt, float2{xMf, 0.f}, p.tw32); }
+                if (t == 0) { const unsigned rt = ROUTE[M], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rotate_route<R, LOG2N>(rt, float2{xMf, 0.f}, p.tw32); }
             } else {
                 unsigned rt[9];
                 float2 ys[9];
@@ -497,10 +503,10 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) void pv_wg_kernel(const PvKe
                 rt[8] = (t == 0) ? ROUTE[M] : NOROUTE;
                 ys[8] = rotate_route<R, LOG2N>(rt[8], float2{xMf, 0.f}, p.tw32);
                 id[8] = M;
-                claim_rounds_wg<9>(rt, ys, id, Y, CLAIM);                  // its first barrier also separates the ROUTE reads from CLAIM writes
+                claim_rounds_wg<9, H>(rt, ys, id, Y, CLAIM);                  // its first barrier also separates the ROUTE reads from CLAIM writes
                 if (need_res) {
                     __syncthreads();
-                    const int up_delta = (int)PSH[last_peak] - last_peak;
+                    const int up_delta = (int)DSH[last_peak];
                     const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
                     residue_scatter_wg<LOG2N, R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, t, upper_end, up_delta, up_ridx,
                                                  dbg ? p.dbg_X : nullptr);
