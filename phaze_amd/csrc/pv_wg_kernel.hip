@@ -20,6 +20,7 @@
 
 #include "pv_kernels.h"
 #include "pv_device_common.h"
+#include "pv_pk_math.h"
 
 namespace {
 
@@ -111,6 +112,76 @@ __device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename 
         for (int j = 0; j < 4; j++) { o[j] = cadd(a[2 * j], a[2 * j + 1]); o[j + 4] = csub(a[2 * j], a[2 * j + 1]); }
 #pragma unroll
         for (int q = 0; q < 8; q++) a[q] = o[q];
+    }
+}
+
+// The inverse instance in packed fp32 (pv_pk_math.h): same layouts as fft_wg<float, true, G>, twiddles conjugated and rounded from the fp64 tables.
+__device__ __forceinline__ pk::c32 twc_inv_pk(double2 w) { return pk::c32{(float)w.x, -(float)w.y}; }
+
+template <int G>
+__device__ __forceinline__ void fft_wg_inv_pk(pk::c32 (&a)[8], pk::c32 *S, const double2 *TWA, const double2 *TWB, const double2 *TWC, int t)
+{
+    using C = WgCfg<G>;
+    pk::radix8_inv(a);
+#pragma unroll
+    for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], twc_inv_pk(TWA[(k - 1) * C::T + t]));
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k * C::P1 + t] = a[k];
+    __syncthreads();
+    const int kA1 = t / (8 * G), tlo = t % (8 * G);
+#pragma unroll
+    for (int n = 0; n < 8; n++) a[n] = S[kA1 * C::P1 + n * 8 * G + tlo];
+    __syncthreads();
+    pk::radix8_inv(a);
+#pragma unroll
+    for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], twc_inv_pk(TWB[(k - 1) * 8 * G + tlo]));
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k * C::P2 + kA1 * (8 * G + C::A2) + tlo] = a[k];
+    __syncthreads();
+    const int kB2 = tlo / G, ulo = tlo % G;
+#pragma unroll
+    for (int n = 0; n < 8; n++) a[n] = S[kB2 * C::P2 + kA1 * (8 * G + C::A2) + n * G + ulo];
+    __syncthreads();
+    pk::radix8_inv(a);
+#pragma unroll
+    for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], twc_inv_pk(TWC[(k - 1) * G + ulo]));
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k * C::P3 + kA1 * (8 * G + C::A3) + kB2 * G + ulo] = a[k];
+    __syncthreads();
+    const int kA3 = t & 7, kB3 = (t >> 3) & 7, c3 = t >> 6;
+#pragma unroll
+    for (int q = 0; q < 8; q++) a[q] = S[(c3 + G * (q / G)) * C::P3 + kA3 * (8 * G + C::A3) + kB3 * G + (q % G)];
+    __syncthreads();
+    if (G == 8) {
+        pk::radix8_inv(a);
+    } else if (G == 4) {
+        pk::c32 o[8];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const pk::c32 e0 = pk::add(a[4 * j], a[4 * j + 2]), e1 = pk::sub(a[4 * j], a[4 * j + 2]);
+            const pk::c32 e2 = pk::add(a[4 * j + 1], a[4 * j + 3]), d = pk::sub(a[4 * j + 1], a[4 * j + 3]);
+            o[j] = pk::add(e0, e2); o[j + 2] = pk::add_j(e1, d); o[j + 4] = pk::sub(e0, e2); o[j + 6] = pk::sub_j(e1, d);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] = o[q];
+    } else {
+        pk::c32 o[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { o[j] = pk::add(a[2 * j], a[2 * j + 1]); o[j + 4] = pk::sub(a[2 * j], a[2 * j + 1]); }
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] = o[q];
+    }
+}
+
+// o * exp(+2 pi j r / 16), r = 0..3 (compile-time): the wave-uniform part of the c2r twiddle, packed
+__device__ __forceinline__ pk::c32 mul_w16_inv_pk_wg(pk::c32 o, int r)
+{
+    const float c = 0.92387953251128675613f, sn = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    switch (r) {
+    case 0: return o;
+    case 1: return pk::cmul(o, pk::c32{c, sn});
+    case 2: return pk::mul(pk::add_j(o, o), pk::c32{h, h});
+    default: return pk::cmul(o, pk::c32{sn, c});
     }
 }
 
@@ -290,6 +361,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
 
     const double2 wl = p.tw64[t];                          // split pass: W_N^{t + T r} = wl * W_16^r  (N = 16 T)
     const float2 wlf = cconj(p.tw32[t]);
+    const pk::c32 wlfs{wlf.x * (1.0f / (float)N), wlf.y * (1.0f / (float)N)};   // c2r twiddle with the 1/N of the inverse folded in (exact)
     float2 hw[8];                                          // Hann at samples 2(t + T r), +1
 #pragma unroll
     for (int r = 0; r < 8; r++) hw[r] = float2{p.hann[2 * (t + T * r)], p.hann[2 * (t + T * r) + 1]};
@@ -330,40 +402,47 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         for (int r = 0; r < 8; r++) z[r] = double2{(double)(raw[r].x * (0.5f * hw[r].x)), (double)(raw[r].y * (0.5f * hw[r].y))};
         fft_wg<double, false, G>(z, S64, TWA, TWB, TWC, t);
 
-        // ---- split pass: the partner bin Z[M - k] lives in another thread (mostly another wave) -> exchange through LDS ----
-        float2 X32[8];
-        float xMf;
+        // ---- split pass in conjugate pairs (see pv_wave_kernel.hip): thread t owns the pairs k = t + T r, r < 4, i.e. bins XA[r] = X[k] and
+        //      XB[r] = X[M - k]; thread 0 also the self-paired bin M/2.  The partner values Z[M - k] are rows 4..7 of other threads -> LDS ----
+        float2 XA[4], XB[4], xHf{0.f, 0.f};
         {
 #pragma unroll
-            for (int r = 0; r < 8; r++) S64[t + T * r] = z[r];
+            for (int r = 4; r < 8; r++) S64[t + T * (r - 4)] = z[r];
             __syncthreads();
-            double2 X[8];
-            double xM = 0.0;
+            double2 xa[4], xb[4], xH{0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
+            for (int r = 0; r < 4; r++) {
                 const int k = t + T * r;
-                const double2 zm = (k == 0) ? z[0] : S64[M - k];
+                const double2 zm = (k == 0) ? z[0] : S64[4 * T - k];          // element M - k sits at (M - k) - 4T of the four stored rows
                 const double2 E{z[r].x + zm.x, z[r].y - zm.y};
                 const double2 O{z[r].x - zm.x, z[r].y + zm.y};
                 const double2 WO = cmul(wl, mul_w16<double, false>(O, r));
-                X[r] = double2{E.x + WO.y, E.y - WO.x};
+                xa[r] = double2{E.x + WO.y, E.y - WO.x};
+                xb[r] = double2{E.x - WO.y, -(E.y + WO.x)};
             }
             if (t == 0) {
-                X[0] = double2{2.0 * (z[0].x + z[0].y), 0.0};
-                xM = 2.0 * (z[0].x - z[0].y);
+                xa[0] = double2{2.0 * (z[0].x + z[0].y), 0.0};                // X[0], X[M]: both real (bundle:447-508 keep Im = 0)
+                xb[0] = double2{2.0 * (z[0].x - z[0].y), 0.0};
+                xH = double2{2.0 * z[4].x, -2.0 * z[4].y};                    // k = M/2 pairs with itself: W^{N/4} = -j, X = 2 conj(Z)
             }
             __syncthreads();                                               // partner reads done: the scratch becomes MAG / Y / ROUTE
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                MAG[4 + t + T * r] = (float)(X[r].x * X[r].x + X[r].y * X[r].y);
-                X32[r] = float2{(float)X[r].x, (float)X[r].y};
+            for (int r = 0; r < 4; r++) {
+                MAG[4 + t + T * r] = (float)(xa[r].x * xa[r].x + xa[r].y * xa[r].y);
+                MAG[4 + M - t - T * r] = (float)(xb[r].x * xb[r].x + xb[r].y * xb[r].y);
+                XA[r] = float2{(float)xa[r].x, (float)xa[r].y};
+                XB[r] = float2{(float)xb[r].x, (float)xb[r].y};
             }
-            if (t == 0) MAG[4 + M] = (float)(xM * xM);
-            xMf = (float)xM;
+            if (t == 0) MAG[4 + M / 2] = (float)(xH.x * xH.x + xH.y * xH.y);
+            xHf = float2{(float)xH.x, (float)xH.y};
             if (dbg) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) { const int k = t + T * r; p.dbg_X[2 * k] = X[r].x; p.dbg_X[2 * k + 1] = X[r].y; }
-                if (t == 0) { p.dbg_X[2 * M] = xM; p.dbg_X[2 * M + 1] = 0.0; }
+                for (int r = 0; r < 4; r++) {
+                    const int ka = t + T * r, kb = M - ka;
+                    p.dbg_X[2 * ka] = xa[r].x; p.dbg_X[2 * ka + 1] = xa[r].y;
+                    p.dbg_X[2 * kb] = xb[r].x; p.dbg_X[2 * kb + 1] = xb[r].y;
+                }
+                if (t == 0) { p.dbg_X[M] = xH.x; p.dbg_X[M + 1] = xH.y; }
             }
         }
         // slide the raw window; the rows the next frame adds are issued here
@@ -489,20 +568,25 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             const bool disjoint = (pf >= 1.0);
             if (disjoint) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const unsigned rt = ROUTE[t + T * r], tg = rt & 0xFFFFu;
-                    if (tg < (unsigned)H) Y[tg] = rotate_route<R, LOG2N>(rt, X32[r], p.tw32);
+                for (int r = 0; r < 4; r++) {
+                    const unsigned ra = ROUTE[t + T * r], ta = ra & 0xFFFFu;
+                    const unsigned rb = ROUTE[M - t - T * r], tb = rb & 0xFFFFu;
+                    if (ta < (unsigned)H) Y[ta] = rotate_route<R, LOG2N>(ra, XA[r], p.tw32);
+                    if (tb < (unsigned)H) Y[tb] = rotate_route<R, LOG2N>(rb, XB[r], p.tw32);
                 }
-                if (t == 0) { const unsigned rt = ROUTE[M], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rotate_route<R, LOG2N>(rt, float2{xMf, 0.f}, p.tw32); }
+                if (t == 0) { const unsigned rt = ROUTE[M / 2], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rotate_route<R, LOG2N>(rt, xHf, p.tw32); }
             } else {
                 unsigned rt[9];
                 float2 ys[9];
                 int id[9];
 #pragma unroll
-                for (int r = 0; r < 8; r++) { rt[r] = ROUTE[t + T * r]; ys[r] = rotate_route<R, LOG2N>(rt[r], X32[r], p.tw32); id[r] = t + T * r; }
-                rt[8] = (t == 0) ? ROUTE[M] : NOROUTE;
-                ys[8] = rotate_route<R, LOG2N>(rt[8], float2{xMf, 0.f}, p.tw32);
-                id[8] = M;
+                for (int r = 0; r < 4; r++) {
+                    id[r] = t + T * r; rt[r] = ROUTE[id[r]]; ys[r] = rotate_route<R, LOG2N>(rt[r], XA[r], p.tw32);
+                    id[4 + r] = M - t - T * r; rt[4 + r] = ROUTE[id[4 + r]]; ys[4 + r] = rotate_route<R, LOG2N>(rt[4 + r], XB[r], p.tw32);
+                }
+                rt[8] = (t == 0) ? ROUTE[M / 2] : NOROUTE;
+                ys[8] = rotate_route<R, LOG2N>(rt[8], xHf, p.tw32);
+                id[8] = M / 2;
                 claim_rounds_wg<9, H>(rt, ys, id, Y, CLAIM);                  // its first barrier also separates the ROUTE reads from CLAIM writes
                 if (need_res) {
                     __syncthreads();
@@ -519,23 +603,36 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             for (int r = 0; r < 8; r++) { const int k = t + T * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
             if (t == 0) { p.dbg_Y[2 * M] = Y[M].x; p.dbg_Y[2 * M + 1] = Y[M].y; }
         }
-        // ---- c2r pre-pass ----
-        float2 zi[8];
+        // ---- c2r pre-pass in conjugate pairs, packed fp32: with E = Yk + conj(Ym), O = Yk - conj(Ym), c = e^{+2 pi j k/N} O / N (m = M - k):
+        //      Z[k] = E / N + j c and Z[m] = conj(E / N - j c); thread t computes k = t + T r, r < 4, and hands Z[m] over through LDS ----
+        pk::c32 zi[8];
         {
             const float sc = 1.0f / (float)N;
+            const pk::c32 scsc{sc, sc};
+            const pk::c32 *Yc = reinterpret_cast<const pk::c32 *>(Y);
+            pk::c32 zb[4];
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
+            for (int r = 0; r < 4; r++) {
                 const int k = t + T * r;
-                float2 yk = Y[k], ym = Y[M - k];
+                pk::c32 yk = Yc[k], ym = Yc[M - k];
                 if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
-                const float2 E{yk.x + ym.x, yk.y - ym.y};
-                const float2 O{yk.x - ym.x, yk.y + ym.y};
-                const float2 c = cmul(wlf, mul_w16<float, true>(O, r));
-                zi[r] = float2{(E.x - c.y) * sc, (E.y + c.x) * sc};
+                const pk::c32 E = pk::add_conj(yk, ym), O = pk::sub_conj(yk, ym);
+                const pk::c32 c = pk::cmul(mul_w16_inv_pk_wg(O, r), wlfs);
+                zi[r] = pk::fma_addj(E, scsc, c);
+                zb[r] = pk::fma_conj_subj(E, scsc, c);
             }
+            const pk::c32 yH = Yc[M / 2];
+            // hand-over buffer = the residue quarter buffer (free here, disjoint from Y): element m = M - k of the packed sequence, m in (4T, 8T)
+            pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem + C::OFF_RESQ);
+#pragma unroll
+            for (int r = 0; r < 4; r++) if (r > 0 || t > 0) XCH[4 * T - t - T * r] = zb[r];   // index m - 4T; (t = 0, r = 0) would be Z[M]: does not exist
+            __syncthreads();
+#pragma unroll
+            for (int r = 4; r < 8; r++) zi[r] = XCH[t + T * (r - 4)];
+            if (t == 0) zi[4] = pk::c32{2.0f * yH.x * sc, -2.0f * yH.y * sc};   // the self-paired bin M/2
         }
         __syncthreads();
-        fft_wg<float, true, G>(zi, S32, TWA, TWB, TWC, t);
+        fft_wg_inv_pk<G>(zi, reinterpret_cast<pk::c32 *>(S32), TWA, TWB, TWC, t);
         // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
         {
             const bool emit_out = (m >= first_out);
