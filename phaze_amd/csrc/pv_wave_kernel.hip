@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
         // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded into the table (exact) ----
         double2 z[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { const float2 hwr = HW[l + 64 * r]; const v2f xw = v2f{raw[r].x, raw[r].y} * v2f{hwr.x, hwr.y}; z[r] = double2{(double)xw.x, (double)xw.y}; }
+        for (int r = 0; r < 8; r++) { const float2 hwr = (ablate & 256) ? float2{0.25f, 0.25f} : HW[l + 64 * r]; const v2f xw = v2f{raw[r].x, raw[r].y} * v2f{hwr.x, hwr.y}; z[r] = double2{(double)xw.x, (double)xw.y}; }
 
         if (!(ablate & 1)) fft512_wave<double, false>(z, S64, TW1, TW2, l);
 
@@ -379,8 +379,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
                     }
                 }
                 // ---- |X|^2 -> f32 (pv:82-92), exchanged through LDS for the neighbour tests ----
-                MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
-                MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                if (!(ablate & 512)) {
+                    MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                    MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                }
                 XA[r] = float2{(float)xa.x, (float)xa.y};
                 XB[r] = float2{(float)xb.x, (float)xb.y};
                 if (dbg) {
@@ -419,9 +421,11 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
         int last_peak = -1;
         if (ablate & 4) {
             wave_sync();
-            *reinterpret_cast<uint4 *>(&ROUTE[8 * l]) = uint4{8u * l, 8u * l + 1, 8u * l + 2, 8u * l + 3};
-            *reinterpret_cast<uint4 *>(&ROUTE[8 * l + 4]) = uint4{8u * l + 4, 8u * l + 5, 8u * l + 6, 8u * l + 7};
-            if (l == 63) ROUTE[512] = 512u;
+            if (!(ablate & 2048)) {
+                *reinterpret_cast<uint4 *>(&ROUTE[8 * l]) = uint4{8u * l, 8u * l + 1, 8u * l + 2, 8u * l + 3};
+                *reinterpret_cast<uint4 *>(&ROUTE[8 * l + 4]) = uint4{8u * l + 4, 8u * l + 5, 8u * l + 6, 8u * l + 7};
+                if (l == 63) ROUTE[512] = 512u;
+            }
         } else {
             float mg[12];
             // volatile vector loads: otherwise the optimizer re-pairs the 12 floats into five misaligned ds_read2_b32 (8 LDS cycles each)
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
             const bool emit_out = (m >= first_out);
             float2 fr[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) { const float2 hwr = HWI[l + 64 * r]; fr[r] = float2{zi[r].x * hwr.x, zi[r].y * hwr.y}; }
+            for (int r = 0; r < 8; r++) { const float2 hwr = (ablate & 1024) ? float2{0.25f, 0.25f} : HWI[l + 64 * r]; fr[r] = float2{zi[r].x * hwr.x, zi[r].y * hwr.y}; }
 #pragma unroll
             for (int r = 0; r < S_ROWS; r++) {
                 const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};

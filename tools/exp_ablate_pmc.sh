@@ -4,7 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/ablate; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for ab in 128 129 131 135 143 159; do
+for ab in ${ABLATE_LIST:-128 129 131 135 143 159}; do
   PHAZE_ABLATE=$ab timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/ab$ab -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/ab$ab.log 2>&1
   python - <<PY
 import csv,glob

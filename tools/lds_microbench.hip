@@ -78,18 +78,10 @@ int main()
     add("wr32 contiguous", WR32, [](int l) { return 4 * l; });
     add("wr64 contiguous", WR64, [](int l) { return 8 * l; });
     add("wr128 contiguous", WR128, [](int l) { return 16 * l; });
-    for (int mask = 0; mask < 32; mask++) {
-        auto P = [mask](int l) { return 4 * (((mask & 1) ? (l >> 1) : 0) + ((mask & 2) ? (l >> 2) : 0) + ((mask & 4) ? (l >> 3) : 0) + ((mask & 8) ? (l >> 4) : 0) + ((mask & 16) ? (l >> 5) : 0)); };
-        auto phys = [P](int k) { return 4 * (k + P(k >> 3)); };
-        std::string tag = " m" + std::to_string(mask);
-        add("rd128 8l  " + tag, RD128, [phys](int l) { return phys(8 * l); });
-        add("rd128 8l+4" + tag, RD128, [phys](int l) { return phys(8 * l + 4); });
-        add("wr128 8l  " + tag, WR128, [phys](int l) { return phys(8 * l); });
-        add("wr128 8l+4" + tag, WR128, [phys](int l) { return phys(8 * l + 4); });
-        add("rd64  8l+8" + tag, RD64, [phys](int l) { return phys(8 * l + 8); });
-        add("rd64  8l-2" + tag, RD64, [phys](int l) { return phys(8 * l + 6 + 56); });
-        add("wr32  l+64" + tag, WR32, [phys](int l) { return phys(l + 64); });
-        add("rd32  l+64" + tag, RD32, [phys](int l) { return phys(l + 64); });
+    for (int base : {0, 16, 32, 64, 128, 4112, 4096, 26128, 36368}) {
+        add("wr128 stride32 base " + std::to_string(base), WR128, [base](int l) { return base + 32 * l; });
+        add("wr128 stride32+16 base " + std::to_string(base), WR128, [base](int l) { return base + 16 + 32 * l; });
+        add("rd128 stride32 base " + std::to_string(base), RD128, [base](int l) { return base + 32 * l; });
     }
     for (auto &p : pats) {
         std::vector<int> offs(64);
