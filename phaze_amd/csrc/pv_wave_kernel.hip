@@ -513,8 +513,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
             // For f >= 1, delta_i = round(p_i f) - p_i is non-decreasing in i, so the shifted regions stay disjoint: plain stores.
             const bool disjoint = (pf >= 1.0) || (ablate & 64);
             if (disjoint) {
-                // R = 4: every rotation of this frame is j^(delta * (m mod 4)); m mod 4 is wave-uniform, so a frame with m = 0 (mod 4) moves
-                // its bins unrotated and m = 2 (mod 4) only flips signs (bit 9 of the rotation index = bit 25 of the route)
+                // every rotation of this frame is exp(2 pi j delta (m mod R) / R) and m mod R is wave-uniform: a frame with m = 0 (mod R) moves its
+                // bins unrotated, m = R/2 (mod R) only flips signs (bit 9 of the rotation index = bit 25 of the route)
                 auto scatter = [&](auto mode_tag) {
                     constexpr int MODE = decltype(mode_tag)::value;
                     auto rot = [&](unsigned rt, float2 v) -> float2 {
@@ -535,9 +535,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
                     }
                     if (l == 0) { const unsigned rt = ROUTE[256], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, float2{x256f.x, x256f.y}); }
                 };
-                const int mq = (R == 4) ? (tmod >> 8) : 1;
-                if (mq == 0) scatter(std::integral_constant<int, 0>{});
-                else if (mq == 2) scatter(std::integral_constant<int, 2>{});
+                // tmod = (m mod R) * N/R: 0 -> no rotation at all, N/2 -> signs only (R = 2: always one of the two; R = 1: always 0)
+                if (tmod == 0) scatter(std::integral_constant<int, 0>{});
+                else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
                 else scatter(std::integral_constant<int, 1>{});
             } else {
                 unsigned rt[9];
