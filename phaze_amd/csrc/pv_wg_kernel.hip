@@ -17,6 +17,7 @@
 // Reference citations are those of pv_kernels.hip / pv_wave_kernel.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "pv_kernels.h"
 #include "pv_device_common.h"
@@ -567,14 +568,30 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         {
             const bool disjoint = (pf >= 1.0);
             if (disjoint) {
+                // every rotation of this frame is exp(2 pi j delta tmod / N) and tmod is uniform: tmod = 0 moves the bins unrotated,
+                // tmod = N/2 only flips signs (top bit of the rotation index = bit 15 + LOG2N of the route)
+                auto scatter = [&](auto mode_tag) {
+                    constexpr int MODE = decltype(mode_tag)::value;
+                    auto rot = [&](unsigned rt, float2 v) -> float2 {
+                        if (MODE == 0) return v;
+                        if (MODE == 2) {
+                            const unsigned sg = (rt << (16 - LOG2N)) & 0x80000000u;
+                            return float2{__uint_as_float(__float_as_uint(v.x) ^ sg), __uint_as_float(__float_as_uint(v.y) ^ sg)};
+                        }
+                        return rotate_route<R, LOG2N>(rt, v, p.tw32);
+                    };
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const unsigned ra = ROUTE[t + T * r], ta = ra & 0xFFFFu;
-                    const unsigned rb = ROUTE[M - t - T * r], tb = rb & 0xFFFFu;
-                    if (ta < (unsigned)H) Y[ta] = rotate_route<R, LOG2N>(ra, XA[r], p.tw32);
-                    if (tb < (unsigned)H) Y[tb] = rotate_route<R, LOG2N>(rb, XB[r], p.tw32);
-                }
-                if (t == 0) { const unsigned rt = ROUTE[M / 2], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rotate_route<R, LOG2N>(rt, xHf, p.tw32); }
+                    for (int r = 0; r < 4; r++) {
+                        const unsigned ra = ROUTE[t + T * r], ta = ra & 0xFFFFu;
+                        const unsigned rb = ROUTE[M - t - T * r], tb = rb & 0xFFFFu;
+                        if (ta < (unsigned)H) Y[ta] = rot(ra, XA[r]);
+                        if (tb < (unsigned)H) Y[tb] = rot(rb, XB[r]);
+                    }
+                    if (t == 0) { const unsigned rt = ROUTE[M / 2], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, xHf); }
+                };
+                if (tmod == 0) scatter(std::integral_constant<int, 0>{});
+                else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
+                else scatter(std::integral_constant<int, 1>{});
             } else {
                 unsigned rt[9];
                 float2 ys[9];
