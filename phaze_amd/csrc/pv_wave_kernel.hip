@@ -147,9 +147,42 @@ __device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const flo
 // per-wave LDS region (byte offsets): see the carve in the kernel
 constexpr int OFF_Y = 0;            // float2[513]   shifted spectrum
 constexpr int OFF_ROUTE = 4112;     // u32[528] routes | f32 mags (alias) | u16 claim ids (alias, after the routes are in registers)
-constexpr int OFF_RESQ = 6224;      // float2[256]   one quarter of the above-Nyquist residue at a time
-constexpr int OFF_PSH = 9216;       // i16[512]      Math.round(p * f) table
-constexpr int WAVE_LDS = 9216 + 1024;
+constexpr int OFF_RESQ = 6224;      // float2[256]   one quarter of the above-Nyquist residue at a time (general path) | c2r hand-over
+constexpr int OFF_XS = 6224;        // float2[513]   fp32 spectrum stash of the fast residue path (aliases RESQ: never live together)
+constexpr int OFF_PSH = 10336;      // i16[512]      shift table Math.round(p * f) - p
+constexpr int WAVE_LDS = OFF_PSH + 1024;   // 11360: 22016 + 12 * 11360 = 158336 B per workgroup (<= 160 KB)
+
+// Above-Nyquist residue, fast path.  What fft.js's in-place real radix-4 DIT leaves at positions 512..640 is the clean first half
+// of the 256-point sub-DFT S2 of xw[4n+2] (its last stage never touches quarter 2, bundle:329-441), and the decimation identity
+//     W^{2k} S2[k] = (X[k] - X[k+256] + X[k+512] - X[k+768]) / 4,   W = exp(-2 pi j / 1024),   X[1024 - i] = conj(X[i])
+// gives it from the spectrum the frame already has: four LDS reads and a twiddle per bin instead of re-running a 256-point FFT.  Valid
+// while the last region ends at or below position 641 (f >= 0.75 always; lower f when the last peak sits low enough); the general path
+// below covers the rest.  Sources b = 513 + l + 64 j, j < 2, all owned by the last peak (pv:133): b -> b + up_delta.
+template <int R_>
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_fast_1024(const float2 *__restrict__ tw32, unsigned wave_off, int l, int upper_end, int up_delta,
+                                                                          unsigned up_ridx, double *dbg_X)
+{
+    constexpr int H = 513;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    float2 *Y = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_Y);
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + OFF_ROUTE);
+    const float2 *XS = reinterpret_cast<const float2 *>(smem_all + wave_off + OFF_XS);
+    unsigned rt[2];
+    float2 ys[2];
+    int id[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int k = 1 + l + 64 * j, b = 512 + k, tgt = b + up_delta;        // k in [1, 128]
+        const float2 x0 = XS[k], x1 = XS[k + 256], x2 = XS[512 - k], x3 = XS[256 - k];
+        const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
+        const float2 s2 = cmul(tsum, cconj(tw32[2 * k]));
+        rt[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+        ys[j] = rotate_route<R_, 10>(rt[j], s2, tw32);
+        id[j] = b;
+        if (dbg_X && b < upper_end) { dbg_X[2 * b] = s2.x; dbg_X[2 * b + 1] = s2.y; }
+    }
+    claim_rounds<2>(rt, ys, id, Y, CLAIM);
+}
 
 // Rare path (f < 1 frames whose last region reads above Nyquist): rebuild what fft.js's in-place real DIT leaves at positions
 // N/2+1..N-1 -- one quarter of the buffer at a time (quarter 2 = sub-FFT of x[4n+2], positions 512..767; quarter 3 = x[4n+3], 768..1023),
@@ -281,7 +314,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
 
     const unsigned wave_off = TAB_BYTES + wv * WAVE_LDS;
     unsigned char *smem = smem_all + wave_off;
-    double2 *S64 = reinterpret_cast<double2 *>(smem);                    // 8*72*16 = 9216 B: fp64 transposes (whole scratch)
+    double2 *S64 = reinterpret_cast<double2 *>(smem);                    // 8*72*16 = 9216 B: fp64 transposes
     float2 *S32 = reinterpret_cast<float2 *>(smem);                      // fp32 transposes (first 4608 B)
     float2 *Y = reinterpret_cast<float2 *>(smem + OFF_Y);                // shifted spectrum Y[0..512], between the FFTs
     float *MAG = reinterpret_cast<float *>(smem + OFF_ROUTE);            // MAG[4 + k], k in [-4, 524): |X|^2 exchange
@@ -551,13 +584,23 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
                 rt[8] = (l == 0) ? ROUTE[256] : NOROUTE;
                 ys[8] = rotate_route<R, 10>(rt[8], x256f, p.tw32);
                 id[8] = 256;
+                const bool fast_res = need_res && (upper_end <= H + 128);
+                if (fast_res) {                                            // stash the fp32 spectrum for residue_fast_1024
+                    float2 *XS = reinterpret_cast<float2 *>(smem + OFF_XS);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { XS[l + 64 * r] = XA[r]; XS[512 - l - 64 * r] = XB[r]; }
+                    if (l == 0) XS[256] = x256f;
+                }
                 wave_sync();                                               // routes are in registers: CLAIM may overwrite ROUTE
                 claim_rounds<9>(rt, ys, id, Y, CLAIM);
                 if (need_res) {                                            // sources above Nyquist, all owned by the last peak (pv:133)
                     const int up_delta = (int)DSH[last_peak < 0 ? 0 : last_peak];
                     const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
-                    residue_scatter_1024<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, wave_off, l, upper_end, up_delta,
-                                            up_ridx, dbg ? p.dbg_X : nullptr);
+                    if (fast_res)
+                        residue_fast_1024<R>(p.tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg ? p.dbg_X : nullptr);
+                    else
+                        residue_scatter_1024<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, wave_off, l, upper_end, up_delta,
+                                                up_ridx, dbg ? p.dbg_X : nullptr);
                 }
             }
         }
