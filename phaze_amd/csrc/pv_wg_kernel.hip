@@ -436,6 +436,11 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             }
             if (t == 0) MAG[4 + M / 2] = (float)(xH.x * xH.x + xH.y * xH.y);
             xHf = float2{(float)xH.x, (float)xH.y};
+            if (pf < 1.0) {                                                // fp32 spectrum stash for the fast residue (Y is not live yet)
+#pragma unroll
+                for (int r = 0; r < 4; r++) { Y[t + T * r] = XA[r]; Y[M - t - T * r] = XB[r]; }
+                if (t == 0) Y[M / 2] = xHf;
+            }
             if (dbg) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -469,6 +474,20 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             }
         }
         __syncthreads();
+        // ---- above-Nyquist residue, fast form (see residue_fast_1024 in pv_wave_kernel.hip): positions N/2+1 .. N/2+N/8 of fft.js's buffer are
+        //      the clean first half of the N/4-point sub-DFT S2 of xw[4n+2], and W^{2k} S2[k] = (X[k] - X[k+N/4] + X[k+N/2] - X[k+3N/4]) / 4.
+        //      Computed speculatively for every f < 1 frame (two bins per thread) while the stash is readable; used if the last region ends
+        //      at or below N/2 + 1 + N/8, else the general path re-runs the reference's stage structure ----
+        float2 s2v[2] = {float2{0.f, 0.f}, float2{0.f, 0.f}};
+        if (pf < 1.0) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int k = 1 + t + T * j;                                // k in [1, N/8]
+                const float2 x0 = Y[k], x1 = Y[k + M / 2], x2 = Y[M - k], x3 = Y[M / 2 - k];
+                const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
+                s2v[j] = cmul(tsum, cconj(p.tw32[2 * k]));
+            }
+        }
         // ---- peak flags on bins 8t..8t+7 (pv:95-116) ----
         int lastown[8], firstown[8];                                      // last own peak <= bin i / first own peak > bin i
         int last_in, first_in;
@@ -609,8 +628,23 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                     __syncthreads();
                     const int up_delta = (int)DSH[last_peak];
                     const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
-                    residue_scatter_wg<LOG2N, R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, t, upper_end, up_delta, up_ridx,
-                                                 dbg ? p.dbg_X : nullptr);
+                    if (upper_end <= H + N / 8) {                           // sources b = H + t + T j, all owned by the last peak (pv:133)
+                        unsigned rt2[2];
+                        float2 ys2[2];
+                        int id2[2];
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const int b = H + t + T * j, tgt = b + up_delta;
+                            rt2[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+                            ys2[j] = rotate_route<R, LOG2N>(rt2[j], s2v[j], p.tw32);
+                            id2[j] = b - N / 2;
+                            if (dbg && b < upper_end) { p.dbg_X[2 * b] = s2v[j].x; p.dbg_X[2 * b + 1] = s2v[j].y; }
+                        }
+                        claim_rounds_wg<2, H>(rt2, ys2, id2, Y, CLAIM);
+                    } else {
+                        residue_scatter_wg<LOG2N, R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, t, upper_end, up_delta, up_ridx,
+                                                     dbg ? p.dbg_X : nullptr);
+                    }
                 }
             }
         }
