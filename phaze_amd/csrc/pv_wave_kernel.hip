@@ -123,21 +123,31 @@ template <int NS>
 __device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned short *CLAIM)
 {
     unsigned pend = 0;
+    unsigned tg[NS];
 #pragma unroll
-    for (int r = 0; r < NS; r++) pend |= ((rt[r] & 0xFFFFu) < 513u) ? (1u << r) : 0u;   // valid route <=> target field < H
+    for (int r = 0; r < NS; r++) {
+        const unsigned t = rt[r] & 0xFFFFu;
+        const bool ok = t < 513u;                                          // valid route <=> target field < H
+        pend |= ok ? (1u << r) : 0u;
+        tg[r] = ok ? t : 0u;                                               // in-range address for the unconditional reads below
+    }
     while (__any(pend != 0u)) {
 #pragma unroll
-        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[rt[r] & 0xFFFFu] = (unsigned short)id[r];
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[tg[r]] = (unsigned short)id[r];
         wave_sync();
+        // all claim words and all current Y values first (two batches of independent reads, one wait), then the winners' stores:
+        // a per-source `if (CLAIM == id) { read Y; write Y }` costs two dependent LDS round trips per source instead
+        unsigned short c[NS];
+        float2 o[NS];
+#pragma unroll
+        for (int r = 0; r < NS; r++) c[r] = CLAIM[tg[r]];
+#pragma unroll
+        for (int r = 0; r < NS; r++) o[r] = Y[tg[r]];
 #pragma unroll
         for (int r = 0; r < NS; r++) {
-            if (pend & (1u << r)) {
-                const int tg = (int)(rt[r] & 0xFFFFu);
-                if (CLAIM[tg] == (unsigned short)id[r]) {
-                    const float2 o = Y[tg];
-                    Y[tg] = float2{o.x + ys[r].x, o.y + ys[r].y};
-                    pend &= ~(1u << r);
-                }
+            if ((pend & (1u << r)) && c[r] == (unsigned short)id[r]) {
+                Y[tg[r]] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
+                pend &= ~(1u << r);
             }
         }
         wave_sync();
@@ -167,6 +177,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_fast_1024(const
     float2 *Y = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_Y);
     unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + OFF_ROUTE);
     const float2 *XS = reinterpret_cast<const float2 *>(smem_all + wave_off + OFF_XS);
+    const float2 *TW1F = reinterpret_cast<const float2 *>(smem_all + TAB_TW1F);    // conj(W_512^{l k}), fp32
     unsigned rt[2];
     float2 ys[2];
     int id[2];
@@ -175,7 +186,14 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_fast_1024(const
         const int k = 1 + l + 64 * j, b = 512 + k, tgt = b + up_delta;        // k in [1, 128]
         const float2 x0 = XS[k], x1 = XS[k + 256], x2 = XS[512 - k], x3 = XS[256 - k];
         const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
-        const float2 s2 = cmul(tsum, cconj(tw32[2 * k]));
+        // W^{-2k} = conj(W_512^k) = conj(W_512^{k & 63}) * conj(W_8^{k >> 6}) from the LDS table (a global table load would sit, exposed, on the
+        // critical path of every f < 1 frame)
+        float2 w = TW1F[64 + (k & 63)];
+        const int k6 = k >> 6;                                             // 0, 1 or 2
+        const float hh = 0.70710678118654752440f;
+        if (k6 == 1) w = float2{(w.x - w.y) * hh, (w.x + w.y) * hh};      // * (h + j h)
+        else if (k6 == 2) w = float2{-w.y, w.x};                          // * j
+        const float2 s2 = cmul(tsum, w);
         rt[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
         ys[j] = rotate_route<R_, 10>(rt[j], s2, tw32);
         id[j] = b;
@@ -261,6 +279,51 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(co
     }
 }
 
+
+// f < 1: the whole colliding scatter (claim rounds + residue) lives out of line, so that its registers (nine routes, nine rotated values,
+// the batched claim reads) do not count against the main pipeline, whose f >= 1 path needs every one of its 168 VGPRs.
+struct Spectrum9 { float2 a[4], b[4], h; };     // bins l + 64 r, 512 - l - 64 r (r < 4), and 256 (lane 0)
+
+template <int R_>
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 X, unsigned wave_off, int l, int tmod, int last_peak, int upper_end,
+                                                                               const float *in, const float *hist, int hist_len, long s0,
+                                                                               const float *__restrict__ hann, const float2 *__restrict__ tw32, double *dbg_X)
+{
+    constexpr int N = 1024, H = 513;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    unsigned char *smem = smem_all + wave_off;
+    float2 *Y = reinterpret_cast<float2 *>(smem + OFF_Y);
+    const unsigned *ROUTE = reinterpret_cast<const unsigned *>(smem + OFF_ROUTE);
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + OFF_ROUTE);
+    const short *DSH = reinterpret_cast<const short *>(smem + OFF_PSH);
+    unsigned rt[9];
+    float2 ys[9];
+    int id[9];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        id[r] = l + 64 * r; rt[r] = ROUTE[id[r]]; ys[r] = rotate_route<R_, 10>(rt[r], X.a[r], tw32);
+        id[4 + r] = 512 - l - 64 * r; rt[4 + r] = ROUTE[id[4 + r]]; ys[4 + r] = rotate_route<R_, 10>(rt[4 + r], X.b[r], tw32);
+    }
+    rt[8] = (l == 0) ? ROUTE[256] : NOROUTE;
+    ys[8] = rotate_route<R_, 10>(rt[8], X.h, tw32);
+    id[8] = 256;
+    const bool need_res = upper_end > H;
+    const bool fast_res = need_res && (upper_end <= H + 128);
+    if (fast_res) {                                                    // stash the fp32 spectrum for residue_fast_1024
+        float2 *XS = reinterpret_cast<float2 *>(smem + OFF_XS);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { XS[l + 64 * r] = X.a[r]; XS[512 - l - 64 * r] = X.b[r]; }
+        if (l == 0) XS[256] = X.h;
+    }
+    wave_sync();                                                       // routes are in registers: CLAIM may overwrite ROUTE
+    claim_rounds<9>(rt, ys, id, Y, CLAIM);
+    if (need_res) {                                                    // sources above Nyquist, all owned by the last peak (pv:133)
+        const int up_delta = (int)DSH[last_peak < 0 ? 0 : last_peak];
+        const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+        if (fast_res) residue_fast_1024<R_>(tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
+        else residue_scatter_1024<R_>(in, hist, hist_len, s0, hann, tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
+    }
+}
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
 // AUX = true: test-tap / phase-ablation build (pv_debug_frame, PHAZE_ABLATE); the production instance carries neither.
@@ -539,7 +602,6 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
         for (int r = 0; r < 8; r++) Y[l + 64 * r] = float2{0.f, 0.f};
         if (l == 0) Y[512] = float2{0.f, 0.f};
         // ---- residue above Nyquist only when the last region reads it ----
-        const bool need_res = (upper_end > H) && !(ablate & 32);
         wave_sync();
         // ---- shiftPeaks (pv:119-173): each lane moves its own source bins (registers) along the precomputed routes ----
         {
@@ -573,35 +635,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
                 else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
                 else scatter(std::integral_constant<int, 1>{});
             } else {
-                unsigned rt[9];
-                float2 ys[9];
-                int id[9];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    id[r] = l + 64 * r; rt[r] = ROUTE[id[r]]; ys[r] = rotate_route<R, 10>(rt[r], XA[r], p.tw32);
-                    id[4 + r] = 512 - l - 64 * r; rt[4 + r] = ROUTE[id[4 + r]]; ys[4 + r] = rotate_route<R, 10>(rt[4 + r], XB[r], p.tw32);
-                }
-                rt[8] = (l == 0) ? ROUTE[256] : NOROUTE;
-                ys[8] = rotate_route<R, 10>(rt[8], x256f, p.tw32);
-                id[8] = 256;
-                const bool fast_res = need_res && (upper_end <= H + 128);
-                if (fast_res) {                                            // stash the fp32 spectrum for residue_fast_1024
-                    float2 *XS = reinterpret_cast<float2 *>(smem + OFF_XS);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { XS[l + 64 * r] = XA[r]; XS[512 - l - 64 * r] = XB[r]; }
-                    if (l == 0) XS[256] = x256f;
-                }
-                wave_sync();                                               // routes are in registers: CLAIM may overwrite ROUTE
-                claim_rounds<9>(rt, ys, id, Y, CLAIM);
-                if (need_res) {                                            // sources above Nyquist, all owned by the last peak (pv:133)
-                    const int up_delta = (int)DSH[last_peak < 0 ? 0 : last_peak];
-                    const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
-                    if (fast_res)
-                        residue_fast_1024<R>(p.tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg ? p.dbg_X : nullptr);
-                    else
-                        residue_scatter_1024<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, wave_off, l, upper_end, up_delta,
-                                                up_ridx, dbg ? p.dbg_X : nullptr);
-                }
+                const int ue = (ablate & 32) ? H : upper_end;
+                scatter_colliding_1024<R>(Spectrum9{{XA[0], XA[1], XA[2], XA[3]}, {XB[0], XB[1], XB[2], XB[3]}, x256f}, wave_off, l, tmod, last_peak, ue,
+                                          src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, dbg ? p.dbg_X : nullptr);
             }
         }
         wave_sync();

@@ -191,21 +191,29 @@ template <int NS, int H_>
 __device__ __forceinline__ void claim_rounds_wg(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned short *CLAIM)
 {
     unsigned pend = 0;
+    unsigned tg[NS];
 #pragma unroll
-    for (int r = 0; r < NS; r++) pend |= ((rt[r] & 0xFFFFu) < (unsigned)H_) ? (1u << r) : 0u;   // valid route <=> target field < H
+    for (int r = 0; r < NS; r++) {
+        const unsigned t = rt[r] & 0xFFFFu;
+        const bool ok = t < (unsigned)H_;                                  // valid route <=> target field < H
+        pend |= ok ? (1u << r) : 0u;
+        tg[r] = ok ? t : 0u;
+    }
     while (__syncthreads_or(pend != 0u)) {
 #pragma unroll
-        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[rt[r] & 0xFFFFu] = (unsigned short)id[r];
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[tg[r]] = (unsigned short)id[r];
         __syncthreads();
+        unsigned short c[NS];
+        float2 o[NS];
+#pragma unroll
+        for (int r = 0; r < NS; r++) c[r] = CLAIM[tg[r]];                   // independent reads first, then the winners' stores (see pv_wave_kernel.hip)
+#pragma unroll
+        for (int r = 0; r < NS; r++) o[r] = Y[tg[r]];
 #pragma unroll
         for (int r = 0; r < NS; r++) {
-            if (pend & (1u << r)) {
-                const int tg = (int)(rt[r] & 0xFFFFu);
-                if (CLAIM[tg] == (unsigned short)id[r]) {
-                    const float2 o = Y[tg];
-                    Y[tg] = float2{o.x + ys[r].x, o.y + ys[r].y};
-                    pend &= ~(1u << r);
-                }
+            if ((pend & (1u << r)) && c[r] == (unsigned short)id[r]) {
+                Y[tg[r]] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
+                pend &= ~(1u << r);
             }
         }
     }
