@@ -280,6 +280,23 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(co
 }
 
 
+// Shift table DSH[p] = Math.round(p * f) - p (pv:125,147) for every candidate peak bin, DROP where the reference skips the peak (pv:127-129).
+// Runs once per chain when f is constant; out of line so that its fp64 temporaries stay out of the main loop's register budget.
+__device__ __attribute__((noinline)) void build_shift_table_1024(float f, unsigned wave_off, int l)
+{
+    constexpr int N = 1024, H = 513, DROP = 0x4000;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    short *DSH = reinterpret_cast<short *>(smem_all + wave_off + OFF_PSH);
+    const double pf = (double)f;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int pk = l + 64 * r;
+        const double ps = floor((double)pk * pf + 0.5);                 // x + 0.5 is exact here (<= 37 significant bits)
+        const bool ok = (ps <= (double)H) && (ps >= -(double)(2 * N));   // pv:127-129; NaN -> not ok
+        DSH[pk] = ok ? (short)((int)ps - pk) : (short)DROP;             // DROP pushes every target of the region out of range
+    }
+}
+
 // f < 1: the whole colliding scatter (claim rounds + residue) lives out of line, so that its registers (nine routes, nine rotated values,
 // the batched claim reads) do not count against the main pipeline, whose f >= 1 path needs every one of its 168 VGPRs.
 struct Spectrum9 { float2 a[4], b[4], h; };     // bins l + 64 r, 512 - l - 64 r (r < 4), and 256 (lane 0)
@@ -501,16 +518,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
         // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change ----
         {
             const unsigned pfb = __float_as_uint(pitch_row[m]);
-            if (pfb != psh_key) {
-                psh_key = pfb;
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const int pk = l + 64 * r;
-                    const double ps = floor((double)pk * pf + 0.5);                 // x + 0.5 is exact here (<= 37 significant bits)
-                    const bool ok = (ps <= (double)H) && (ps >= -(double)(2 * N));   // pv:127-129; NaN -> not ok
-                    DSH[pk] = ok ? (short)((int)ps - pk) : (short)DROP;             // DROP pushes every target of the region out of range
-                }
-            }
+            if (pfb != psh_key) { psh_key = pfb; build_shift_table_1024(pitch_row[m], wave_off, l); }
         }
         wave_sync();
         // ---- peak flags (pv:95-116) for bins 8l..8l+7, nearest peaks by wave scans, then one ROUTE word per source bin ----
