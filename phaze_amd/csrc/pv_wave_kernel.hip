@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
         }
         wave_sync();
         // ---- peak flags (pv:95-116) for bins 8l..8l+7, nearest peaks by wave scans, then one ROUTE word per source bin ----
-        int last_peak = -1;
+        int last_peak = -1, last_shift = 0;
         if (ablate & 4) {
             wave_sync();
             if (!(ablate & 2048)) {
@@ -554,13 +554,23 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
                 for (int i = 0; i < 8; i++) { p.dbg_flags[8 * l + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * l + i] = mg[i + 2]; }
                 if (l == 63) { p.dbg_flags[512] = 0; p.dbg_mag[512] = mg[10]; }
             }
-            int lastown[8], firstown[8];                                    // last own peak <= bin i / first own peak > bin i
-            int cur = -BIG;
+            // Every candidate peak travels as one packed word (bin << 16 | shift & 0xFFFF): the shifts of the lane's own 8 bins come from ONE
+            // 16-byte read of the shift table (a per-bin DSH[owner] lookup is a 4-way bank conflict by construction: lanes l and l + 16 sit
+            // 256 bytes apart), and the neighbour lanes' peaks bring their shift along in the same bpermute.  Packed words order like bins.
+            constexpr int NEGPD = -(2048 << 16), POSPD = 4096 << 16;        // "no peak on this side"
+            typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
+            const v4u dq = *(lds_v4u)(&DSH[8 * l]);
+            int pd[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) { cur = fl[i] ? 8 * l + i : cur; lastown[i] = cur; }
-            int nx = BIG;
+            for (int i = 0; i < 8; i++)                                     // bytes {d.lo, d.hi, bin.lo, bin.hi}
+                pd[i] = (int)__builtin_amdgcn_perm((unsigned)(8 * l + i), dq[i >> 1], (i & 1) ? 0x05040302u : 0x05040100u);
+            int lastown[8], firstown[8];                                    // last own peak <= bin i / first own peak > bin i (packed)
+            int cur = NEGPD;
 #pragma unroll
-            for (int i = 7; i >= 0; i--) { firstown[i] = nx; nx = fl[i] ? 8 * l + i : nx; }
+            for (int i = 0; i < 8; i++) { cur = fl[i] ? pd[i] : cur; lastown[i] = cur; }
+            int nx = POSPD;
+#pragma unroll
+            for (int i = 7; i >= 0; i--) { firstown[i] = nx; nx = fl[i] ? pd[i] : nx; }
             const int last_in = cur, first_in = nx;
             // nearest peak below / above this lane's byte: the 64-bit ballot of non-empty lanes locates the neighbour lane,
             // one bpermute each fetches its last / first peak (two independent LDS round trips instead of a 6-step scan)
@@ -570,28 +580,30 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
             const int src_lo = below ? 63 - __clzll((long long)below) : 0;
             const int src_hi = above ? l + __ffsll((long long)above) : 0;
             int cprev = __shfl(last_in, src_lo, 64), cnext = __shfl(first_in, src_hi, 64);
-            if (!below) cprev = -BIG;
-            if (!above) cnext = BIG;
+            if (!below) cprev = NEGPD;
+            if (!above) cnext = POSPD;
             unsigned rt[8];
             unsigned rt512 = NOROUTE;
             if (occ == 0ull) {                                              // no peak at all (wave-uniform): nothing moves (pv:122 loop is empty)
 #pragma unroll
                 for (int i = 0; i < 8; i++) rt[i] = NOROUTE;
             } else {
-                last_peak = __shfl(last_in, 63 - __clzll((long long)occ), 64);
+                const int lp = __shfl(last_in, 63 - __clzll((long long)occ), 64);
+                last_peak = lp >> 16;
+                last_shift = (int)(short)(lp & 0xFFFF);
                 // owner rule (pv:132-141): regions tile [0, N); a bin belongs to the peak on its left iff it is strictly closer to it
                 // (b < prv + ceil(gap/2)  <=>  b - prv < nxt - b; the midpoint of an even gap goes right).  Sentinels make the first
                 // region start at 0 (pv:132) and the last one end at N (pv:133); at least one side is a real peak here.
                 // shift (pv:147-152): ROUTE = ((delta * t) mod N) << 16 | target; a route is valid iff its target field is < H
                 // (pv:127-129 via DROP, pv:150-152, negative index); bits above the 10 rotation bits are don't-care.
-                auto route_of = [&](int b, int prv, int nxt) -> unsigned {
-                    const int owner = (b - prv < nxt - b) ? prv : nxt;
-                    const int delta = (int)DSH[owner];
+                auto route_of = [&](int b, int pp, int pn) -> unsigned {
+                    const int own = (b - (pp >> 16) < (pn >> 16) - b) ? pp : pn;
+                    const int delta = __builtin_amdgcn_sbfe(own, 0, 16);
                     return __builtin_amdgcn_perm((unsigned)__mul24(delta, tmod), (unsigned)(b + delta), 0x05040100u);
                 };
 #pragma unroll
                 for (int i = 0; i < 8; i++) rt[i] = route_of(8 * l + i, max(lastown[i], cprev), min(firstown[i], cnext));
-                if (l == 63) rt512 = route_of(512, max(last_in, cprev), BIG);   // source bin N/2: owner is the last peak
+                if (l == 63) rt512 = route_of(512, max(last_in, cprev), POSPD);   // source bin N/2: owner is the last peak
             }
             // MAG is dead now (every lane has its 12 magnitudes in registers): ROUTE aliases it
             wave_sync();
@@ -600,10 +612,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
             if (l == 63) ROUTE[512] = rt512;
         }
         int upper_end = H;
-        if (last_peak >= 0) {
-            const int d = (int)DSH[last_peak];
-            if (d < 0) { upper_end = H - d; if (upper_end > N) upper_end = N; }      // DROP is positive
-        }
+        if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
         // ---- zero Y (pv:121); the transposes of the forward FFT are done with the scratch ----
         if (!(ablate & 8))
 #pragma unroll
