@@ -122,7 +122,7 @@ __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, s
 template <int NS>
 __device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned short *CLAIM)
 {
-    unsigned pend = 0;
+    unsigned pend = 0;                                                     // (a bool per source would be carried through the loop as 0/1 VGPRs: slower)
     unsigned tg[NS];
 #pragma unroll
     for (int r = 0; r < NS; r++) {
@@ -318,12 +318,23 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void scatter_colliding_1024(
     int id[9];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        id[r] = l + 64 * r; rt[r] = ROUTE[id[r]]; ys[r] = rotate_route<R_, 10>(rt[r], X.a[r], tw32);
-        id[4 + r] = 512 - l - 64 * r; rt[4 + r] = ROUTE[id[4 + r]]; ys[4 + r] = rotate_route<R_, 10>(rt[4 + r], X.b[r], tw32);
+        id[r] = l + 64 * r; rt[r] = ROUTE[id[r]]; ys[r] = X.a[r];
+        id[4 + r] = 512 - l - 64 * r; rt[4 + r] = ROUTE[id[4 + r]]; ys[4 + r] = X.b[r];
     }
     rt[8] = (l == 0) ? ROUTE[256] : NOROUTE;
-    ys[8] = rotate_route<R_, 10>(rt[8], X.h, tw32);
+    ys[8] = X.h;
     id[8] = 256;
+    // rotations: none when tmod = 0, signs only when tmod = N/2 (bit 25 of the route), the general form otherwise (wave-uniform)
+    if (tmod == N / 2) {
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const unsigned sg = (rt[r] << 6) & 0x80000000u;
+            ys[r] = float2{__uint_as_float(__float_as_uint(ys[r].x) ^ sg), __uint_as_float(__float_as_uint(ys[r].y) ^ sg)};
+        }
+    } else if (tmod != 0) {
+#pragma unroll
+        for (int r = 0; r < 9; r++) ys[r] = rotate_route<R_, 10>(rt[r], ys[r], tw32);
+    }
     const bool need_res = upper_end > H;
     const bool fast_res = need_res && (upper_end <= H + 128);
     if (fast_res) {                                                    // stash the fp32 spectrum for residue_fast_1024
