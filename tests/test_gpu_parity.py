@@ -218,3 +218,24 @@ def test_generic_kernel_fallback_parity(fft, hop, monkeypatch):
         assert (name == "pv_chain_kernel") == (forced == "1"), name
         assert S.rms(outs[forced].astype(np.float64) - yo) < REGRESSION_RMS
     assert S.rms(outs["0"].astype(np.float64) - outs["1"]) < 1e-7
+
+
+@pytest.mark.parametrize("fft,hop", [(1024, 256), (1024, 128), (2048, 512), (4096, 1024)])
+def test_residue_fast_and_general_paths(fft, hop):
+    """f < 1 with a strong component just below Nyquist: the last region reads the above-Nyquist residue on every frame.  f is stepped across the
+    point where the region end crosses N/2 + 1 + N/8 (fast form: decimation identity on the spectrum; beyond it: the re-run stage structure),
+    plus silence (no peak at all) and DC."""
+    T = 24
+    i = np.arange(T * hop, dtype=np.float64)
+    hi = 0.3 * np.sin(2 * np.pi * (0.488 * i)) + 0.05 * np.sin(2 * np.pi * 0.031 * i)       # peak near bin 0.976 * N/2
+    x = np.stack([(hi + S.make_signal("noise", 0, T * hop).astype(np.float64) / 256).astype(np.float32),
+                  np.zeros(T * hop, np.float32), np.full(T * hop, 0.25, np.float32)])
+    for f in (0.99, 0.9, 0.8, 0.76, 0.75, 0.745, 0.74, 0.7, 0.6, 0.5, 0.45, 0.3):
+        p = np.full(T, f, np.float32)
+        pv = _pv(fft_size=fft, hop_size=hop, max_channels=3, max_hops=T)
+        y = pv.process_batch(x, p)
+        pv.close()
+        yo = oracle_lib.Oracle(fft, hop, 3).process_planar(x, p)
+        err = S.rms(y.astype(np.float64) - yo)
+        assert np.all(np.isfinite(y)) and err < REGRESSION_RMS, f"{fft}/{hop} f={f}: {err:.3e}"
+        assert np.max(np.abs(y[1])) == 0.0, "silence stays silence"
