@@ -323,6 +323,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     const int Rrt = N / HOP;
     constexpr int LROWS = RING ? 0 : 8 - S_ROWS;
     constexpr int BIG = 1 << 30;
+    constexpr int NEGPD = -(1 << 30), POSPD = 1 << 30;                    // packed (bin << 16 | shift) sentinels: no peak on this side
     constexpr int DROP = 0x4000;                                        // shift sentinel: b + DROP >= H for every bin, above every real shift
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int ch = blockIdx.y, chunk = blockIdx.x;
@@ -521,12 +522,20 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 for (int i = 0; i < 8; i++) { p.dbg_flags[8 * t + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * t + i] = mg[i + 2]; }
                 if (t == T - 1) { p.dbg_flags[M] = 0; p.dbg_mag[M] = mg[10]; }
             }
-            int cur = -BIG;
+            // candidate peaks travel as packed words (bin << 16 | shift & 0xFFFF), see pv_wave_kernel.hip: one 16-byte read of the shift table
+            // per thread instead of a 4-way-conflicted DSH[owner] lookup per bin
+            typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
+            const v4u dq = *(lds_v4u)(&DSH[8 * t]);
+            int pd[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) { cur = fl[i] ? 8 * t + i : cur; lastown[i] = cur; }
-            int nx = BIG;
+            for (int i = 0; i < 8; i++)
+                pd[i] = (int)__builtin_amdgcn_perm((unsigned)(8 * t + i), dq[i >> 1], (i & 1) ? 0x05040302u : 0x05040100u);
+            int cur = NEGPD;
 #pragma unroll
-            for (int i = 7; i >= 0; i--) { firstown[i] = nx; nx = fl[i] ? 8 * t + i : nx; }
+            for (int i = 0; i < 8; i++) { cur = fl[i] ? pd[i] : cur; lastown[i] = cur; }
+            int nx = POSPD;
+#pragma unroll
+            for (int i = 7; i >= 0; i--) { firstown[i] = nx; nx = fl[i] ? pd[i] : nx; }
             last_in = cur; first_in = nx;
         }
         // ---- nearest peaks outside this thread's byte: per-wave occupancy ballots + per-thread last/first peak, through LDS ----
@@ -537,7 +546,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             if (l == 0) OCC[wv] = occ;
         }
         __syncthreads();                                                   // also: every MAG read is done -> ROUTE may overwrite MAG
-        int cprev = -BIG, cnext = BIG, last_peak = -1;
+        int cprev = NEGPD, cnext = POSPD, last_peak = -1, last_shift = 0;
         {
             const unsigned long long mine = OCC[wv];
             {
@@ -556,7 +565,10 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                     for (int w = wv + 1; w < G; ++w) { const unsigned long long o = OCC[w]; if (o) { srcT = w * 64 + __ffsll((long long)o) - 1; break; } }
                 if (srcT >= 0) cnext = FIRSTIN[srcT];
             }
-            for (int w = G - 1; w >= 0; --w) { const unsigned long long o = OCC[w]; if (o) { last_peak = LASTIN[w * 64 + 63 - __clzll((long long)o)]; break; } }
+            for (int w = G - 1; w >= 0; --w) {
+                const unsigned long long o = OCC[w];
+                if (o) { const int lp = LASTIN[w * 64 + 63 - __clzll((long long)o)]; last_peak = lp >> 16; last_shift = (int)(short)(lp & 0xFFFF); break; }
+            }
         }
         {
             unsigned rt[8];
@@ -567,24 +579,21 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             } else {
                 // owner rule (pv:132-141) + shift (pv:147-152): ROUTE = ((delta * t) mod N) << 16 | target; a route is valid iff its target
                 // field is < H (pv:127-129 via DROP, pv:150-152, negative index); bits above the rotation index are don't-care
-                auto route_of = [&](int b, int prv, int nxt) -> unsigned {
-                    const int owner = (b - prv < nxt - b) ? prv : nxt;      // at least one side is a real peak here
-                    const int delta = (int)DSH[owner];
+                auto route_of = [&](int b, int pp, int pn) -> unsigned {
+                    const int own = (b - (pp >> 16) < (pn >> 16) - b) ? pp : pn;     // at least one side is a real peak here
+                    const int delta = __builtin_amdgcn_sbfe(own, 0, 16);
                     return __builtin_amdgcn_perm((unsigned)__mul24(delta, tmod), (unsigned)(b + delta), 0x05040100u);
                 };
 #pragma unroll
                 for (int i = 0; i < 8; i++) rt[i] = route_of(8 * t + i, max(lastown[i], cprev), min(firstown[i], cnext));
-                if (t == T - 1) rtM = route_of(M, max(last_in, cprev), BIG);
+                if (t == T - 1) rtM = route_of(M, max(last_in, cprev), POSPD);
             }
             *reinterpret_cast<uint4 *>(&ROUTE[8 * t]) = uint4{rt[0], rt[1], rt[2], rt[3]};
             *reinterpret_cast<uint4 *>(&ROUTE[8 * t + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
             if (t == T - 1) ROUTE[M] = rtM;
         }
         int upper_end = H;
-        if (last_peak >= 0) {
-            const int d = (int)DSH[last_peak];
-            if (d < 0) { upper_end = H - d; if (upper_end > N) upper_end = N; }      // DROP is positive
-        }
+        if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
         // ---- zero Y (pv:121) ----
 #pragma unroll
         for (int r = 0; r < 8; r++) Y[t + T * r] = float2{0.f, 0.f};
