@@ -83,14 +83,20 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
     const int R = h->R;
     int best = R > 1 ? R : 1;
     double best_eff = -1.0;
-    for (int F = 48 * R; F >= (R > 1 ? R : 1); F -= (F > 8 * R ? R : 1)) {
-        if (F > nhops && F > R) continue;
-        const long chains = (long)nch * ((nhops + F - 1) / F);
+    auto consider = [&](int F) {
+        if (F < 1) return;
+        const long chunks = (nhops + F - 1) / F;
+        const long chains = (long)nch * chunks;
         const long rounds = (chains + resident - 1) / resident;
-        const double fill = (double)chains / (double)(rounds * resident);        // tail effect
-        const double halo = (double)F / (double)(F + R - 1);                     // recomputed frames
+        const double fill = (double)chains / (double)(rounds * resident);                        // tail effect
+        const double halo = (double)nhops / (double)(nhops + (chunks - 1) * (R - 1));            // recomputed frames: none for a channel's first chunk
         const double eff = fill * halo;
         if (eff > best_eff + 1e-9) { best_eff = eff; best = F; }
+    };
+    consider(nhops);                                                                             // one chain per channel: no halo at all
+    for (int F = 48 * R; F >= (R > 1 ? R : 1); F -= (F > 8 * R ? R : 1)) {
+        if (F > nhops && F > R) continue;
+        consider(F);
     }
     if (best > nhops) best = nhops;
     return best < 1 ? 1 : best;
@@ -114,7 +120,7 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     { const char *ab = getenv("PHAZE_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
     if (dbg_ch >= 0) { p.dbg_X = h->d_dbgX; p.dbg_mag = h->d_dbgMag; p.dbg_flags = h->d_dbgFlags; p.dbg_Y = h->d_dbgY; p.dbg_ch = dbg_ch; p.dbg_frame = 0; }
     const int nchunks = (nhops + p.frames_per_chunk - 1) / p.frames_per_chunk;
-    if (nch > 65535) return fail(h, PV_ERR_CAPACITY, "more than 65535 channel slots in one launch (grid.y limit): split the call");
+    if (!h->use_wave && nch > 65535) return fail(h, PV_ERR_CAPACITY, "more than 65535 channel slots in one launch (grid.y limit): split the call");
     h->last_frames_per_chunk = p.frames_per_chunk;
     hipError_t e = h->use_wave ? pv_launch_wave(p, nch, nchunks, h->stream)
                  : h->use_wg ? pv_launch_wg(h->log2n, p, nch, nchunks, h->stream)

@@ -10,7 +10,8 @@ struct PvKernelParams {
     int nhops;                // hops (= process() calls) in this launch
     int hop;
     int frames_per_chunk;     // output hops per workgroup (per wave in the wave kernel)
-    int nchunks;              // number of chunks (set by the launcher)
+    int nchunks;              // number of chunks per channel (set by the launcher)
+    int nch;                  // number of channel slots of this launch (set by the launcher; wave kernel: chains are numbered channel-major)
     const float *pitch;       // pitchFactor per hop (k-rate, phase-vocoder.js:47)
     int pitch_stride;         // 0: one row shared by all channels; else row = (c / ch_per_stream)
     int ch_per_stream;

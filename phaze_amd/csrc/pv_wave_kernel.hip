@@ -365,7 +365,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
     constexpr int DROP = 0x4000;                                          // shift sentinel: b + DROP >= H for every bin b
     const int l = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ch = blockIdx.y, chunk = blockIdx.x * WAVES + wv;
+    // chains are numbered channel-major over (channel, chunk) and packed 12 to a workgroup regardless of the channel they belong to: many short
+    // streams (one chunk per channel) fill the workgroups exactly like one long stream does
+    const long chain = (long)blockIdx.x * WAVES + wv;
+    const int ch = (int)(chain / p.nchunks), chunk = (int)(chain - (long)ch * p.nchunks);
 
     // ---- LDS carve (all dynamic, 16-byte aligned): shared tables, then one private region per wave ----
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
         }
     }
     __syncthreads();                                                     // the only workgroup-wide barrier
-    if (chunk >= p.nchunks) return;
+    if (ch >= p.nch) return;
 #ifdef PHAZE_EXP_STAGGER
     for (int i = 0; i < wv; i++) __builtin_amdgcn_s_sleep(PHAZE_EXP_STAGGER);
 #endif
@@ -763,7 +766,9 @@ hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_
     }
     PvKernelParams q = p;
     q.nchunks = nchunks;
-    hipLaunchKernelGGL(k, dim3((nchunks + WAVES - 1) / WAVES, nch, 1), dim3(64 * WAVES, 1, 1), pv_wave_lds_bytes(), st, q);
+    q.nch = nch;
+    const long chains = (long)nch * nchunks;
+    hipLaunchKernelGGL(k, dim3((unsigned)((chains + WAVES - 1) / WAVES), 1, 1), dim3(64 * WAVES, 1, 1), pv_wave_lds_bytes(), st, q);
     return hipGetLastError();
 }
 

@@ -104,3 +104,25 @@ def test_c5_sweep_prefix_parity_and_finite():
     ref = oracle_lib.Oracle(fft, hop, 2).process_planar(xs[:2, :K * hop], pitch[:K])
     assert S.rms(y[:2, :K * hop].cpu().numpy().astype(np.float64) - ref) < 2e-6
     pv.close()
+
+
+@pytest.mark.parametrize("nstreams,T", [(3000, 24), (70000, 5)])
+def test_many_short_streams_1024(nstreams, T):
+    """N = 1024: many channels with few hops each (one chain per channel, packed 12 to a workgroup across channels; > 65535 channel slots in
+    one launch).  Channels carry one of four base signals: equal inputs give bit-identical outputs, the first four match the oracle."""
+    fft, hop, cps = 1024, 256, 4
+    torch, pv, st = _setup(fft, hop, nstreams, T)
+    base = np.stack([S.make_signal("tonal" if c & 1 else "noise", c, T * hop) for c in range(cps)])
+    reps = (nstreams + cps - 1) // cps
+    x = torch.from_numpy(np.tile(base, (reps, 1))[:nstreams]).cuda()
+    y = torch.empty_like(x)
+    p = torch.full((T,), 0.9, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        pv.process_batch_device(x.data_ptr(), y.data_ptr(), nstreams, T, T * hop, p.data_ptr())
+    pv.synchronize()
+    for s in (1, reps // 2, reps - 2):
+        assert torch.equal(y[s * cps:(s + 1) * cps], y[:cps])
+    ref = oracle_lib.Oracle(fft, hop, cps).process_planar(base, np.full(T, 0.9, np.float32))
+    assert S.rms(y[:cps].cpu().numpy().astype(np.float64) - ref) < 2e-6
+    pv.close()
