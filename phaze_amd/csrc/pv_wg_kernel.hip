@@ -28,7 +28,9 @@ namespace {
 template <int G>
 struct WgCfg {
     static constexpr int T = 64 * G, M = 512 * G, N = 1024 * G, H = M + 1;
-    static constexpr int A2 = (G == 2) ? 2 : 0, P2 = 8 * (8 * G + A2) + 8;      // transpose 2: per-kA row pad, row length
+    // transpose 2: per-kA row pad, row length.  Row pad 4 (G = 2, 4) / 8 (G = 8) measured conflict-free for the writes AND the reads of both
+    // element sizes (tools/lds_microbench.hip; the earlier row pad 8 cost the reads 6.4 instead of 3.4 LDS cycles)
+    static constexpr int A2 = (G == 2) ? 2 : 0, P2 = 8 * (8 * G + A2) + (G == 8 ? 8 : 4);
     static constexpr int A3 = (G == 2) ? 4 : 1, P3 = 8 * (8 * G + A3);          // transpose 3
     static constexpr int P1 = T;                                                 // transpose 1 is conflict-free unpadded
     static constexpr int PMAX = (P2 > P3 ? (P2 > P1 ? P2 : P1) : (P3 > P1 ? P3 : P1));
