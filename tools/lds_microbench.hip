@@ -78,15 +78,13 @@ int main()
     add("wr32 contiguous", WR32, [](int l) { return 4 * l; });
     add("wr64 contiguous", WR64, [](int l) { return 8 * l; });
     add("wr128 contiguous", WR128, [](int l) { return 16 * l; });
-    // search: pv_wg_kernel transposes 2 and 3, G in {2, 4}: per-kA pad A and row length 8 * (8G + A) + RP
-    for (int G : {2, 4}) for (int E : {16, 8}) for (int A : {0, 1, 2, 3, 4, 6, 8}) for (int RP : {0, 4, 8, 12, 16, 24}) {
-        const int P = 8 * (8 * G + A) + RP;
-        std::string tag = " G" + std::to_string(G) + " E" + std::to_string(E) + " A" + std::to_string(A) + " RP" + std::to_string(RP);
+    // search: pv_wg_kernel transpose 3 with a rotation of the 8G-element block by SG * kA
+    for (int G : {2, 4}) for (int E : {16, 8}) for (int A : {0, 1, 2, 4}) for (int SG = 0; SG < 8 * G; SG++) {
+        const int P = 8 * (8 * G + A);
+        std::string tag = " G" + std::to_string(G) + " E" + std::to_string(E) + " A" + std::to_string(A) + " RP" + std::to_string(SG);
         const int WR = (E == 16) ? WR128 : WR64, RD = (E == 16) ? RD128 : RD64;
-        add("T2wr" + tag, WR, [=](int l) { int t = l, kA1 = t / (8 * G), tlo = t % (8 * G); return E * (3 * P + kA1 * (8 * G + A) + tlo) % 60000; });
-        add("T2rd" + tag, RD, [=](int l) { int t = l, kA1 = t / (8 * G), tlo = t % (8 * G), kB2 = tlo / G, ulo = tlo % G; return E * (kB2 * P + kA1 * (8 * G + A) + 3 * G + ulo) % 60000; });
-        add("T3wr" + tag, WR, [=](int l) { int t = l, kA1 = t / (8 * G), tlo = t % (8 * G), kB2 = tlo / G, ulo = tlo % G; return E * (3 * P + kA1 * (8 * G + A) + kB2 * G + ulo) % 60000; });
-        add("T3rd" + tag, RD, [=](int l) { int t = l, kA3 = t & 7, kB3 = (t >> 3) & 7, c3 = t >> 6; int q = 3; return E * ((c3 + G * (q / G)) * P + kA3 * (8 * G + A) + kB3 * G + (q % G)) % 60000; });
+        add("T3wr" + tag, WR, [=](int l) { int t = l, kA1 = t / (8 * G), tlo = t % (8 * G); return E * (3 * P + kA1 * (8 * G + A) + ((tlo + SG * kA1) % (8 * G))) % 60000; });
+        add("T3rd" + tag, RD, [=](int l) { int t = l, kA3 = t & 7, kB3 = (t >> 3) & 7; int q = 3; return E * ((0 + G * (q / G)) * P + kA3 * (8 * G + A) + ((kB3 * G + (q % G) + SG * kA3) % (8 * G))) % 60000; });
     }
     for (auto &p : pats) {
         std::vector<int> offs(64);
