@@ -10,13 +10,16 @@
 //   * forward 512-pt complex FFT in fp64 (pv:57; fp64 because the peak decisions are taken on the f32-rounded |X|^2 of an fp64
 //     spectrum): three radix-8 butterflies per lane, two conflict-free LDS transposes (layouts from tools/lds_layout_check.py),
 //     twiddles from LDS tables shared by the workgroup
-//   * split pass: partner bin fetched by ds_bpermute (lane 64-l); |X|^2 -> f32 in registers (pv:82-92)
-//   * peak flags on 8 consecutive bins per lane (pv:95-116); nearest peaks by one ballot + two bpermutes; owner rule + cached
-//     Math.round(p f) table -> one route per source bin (pv:119-152)
-//   * scatter of the register-resident source bins along their routes (pv:155-170): plain stores when f >= 1 (regions disjoint),
-//     claim rounds when f < 1; above-Nyquist residue rebuilt per quarter in an out-of-line function
-//   * c2r pre-pass + 512-pt inverse FFT in fp32 (same structure), Hann, overlap-add accumulator in registers in reference order
-//     (ola:149-157), finished hop stored coalesced, non-temporal
+//   * split pass in conjugate pairs (one twiddle product per pair k, 512-k); the partner values cross lanes through the freed transpose
+//     scratch; |X|^2 -> f32 in registers (pv:82-92)
+//   * peak flags on 8 consecutive bins per lane (pv:95-116); candidate peaks travel as packed (bin, shift) words: own shifts from one
+//     16-byte read of the cached Math.round(p f) - p table, nearest peaks by select chains + one ballot + two bpermutes; owner rule ->
+//     one route per source bin (pv:119-152)
+//   * scatter of the register-resident source bins along their routes (pv:155-170): plain stores when f >= 1 (regions disjoint; frames
+//     with t = 0 or N/2 (mod N) skip / simplify the rotation); f < 1 goes out of line: claim rounds, and the above-Nyquist residue either
+//     from the spectrum (decimation identity) or by re-running the reference's stage structure on one quarter
+//   * c2r pre-pass (conjugate pairs) + 512-pt inverse FFT in packed fp32 (pv_pk_math.h), Hann, overlap-add accumulator in registers in
+//     reference order (ola:149-157), finished hop stored coalesced, non-temporal
 //
 // Semantics are those of pv_chain_kernel (same reference citations); tests run every kernel against the oracle.
 #include <hip/hip_runtime.h>
