@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--frames-per-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also report the host-buffer (PCIe-inclusive) rate")
+    ap.add_argument("--scatter-gather", action="store_true",
+                    help="N > 1: all streams start on rank 0, are scattered over RCCL, and the results gathered back (reported separately, never in value)")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,7 +101,18 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     fft, hop, nch, T = args.fft, args.hop, args.channels, args.hops
-    x = synth_input(torch, nch, T * hop, dev, seed=rank)
+    sg_ms = None
+    if args.scatter_gather and dist is not None:
+        # the only exchange a multi-GPU job can have: whole streams out from rank 0 (and results back, below)
+        from phaze_amd import shard as _shard
+        x_all = (torch.stack([synth_input(torch, nch, T * hop, dev, seed=r) for r in range(world)]) if rank == 0
+                 else torch.empty((0, nch, T * hop), device=dev, dtype=torch.float32))
+        torch.cuda.synchronize(); dist.barrier(); t_sg = time.perf_counter()
+        x = _shard.scatter_streams(x_all, world, dist)[0].contiguous()
+        torch.cuda.synchronize(); dist.barrier(); sg_ms = (time.perf_counter() - t_sg) * 1e3
+        del x_all
+    else:
+        x = synth_input(torch, nch, T * hop, dev, seed=rank)
     y = torch.empty_like(x)
     pitch = torch.full((T,), args.pitch, device=dev, dtype=torch.float32)
     torch.cuda.synchronize()
@@ -149,6 +162,14 @@ def main():
     from phaze_amd import shard
     elapsed, kernel_ms = shard.reduce_max([elapsed, kernel_ms], dist, dev)      # MAX over ranks
 
+    if sg_ms is not None:
+        from phaze_amd import shard as _shard
+        torch.cuda.synchronize(); dist.barrier(); t_sg = time.perf_counter()
+        y_all = _shard.gather_streams(y.unsqueeze(0), world, dist)
+        torch.cuda.synchronize(); dist.barrier(); sg_ms += (time.perf_counter() - t_sg) * 1e3
+        del y_all
+        sg_ms = _shard.reduce_max([sg_ms], dist, dev)[0]
+
     info = pv.info()
     frames_per_step_rank = nch * T
     value = shard.aggregate_rate(frames_per_step_rank * args.steps, world, elapsed)
@@ -186,6 +207,8 @@ def main():
                          "note": "algorithmic bytes = 2*hop*4 B per channel-frame; the kernel is LDS/VALU-bound (fp64 FFT), see DESIGN.md"},
             "parity_rms_vs_oracle": parity,
         }
+        if sg_ms is not None:
+            out["scatter_gather_ms"] = sg_ms        # one step's input out + output back over RCCL, outside the timed region
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(fft, hop, args.pitch)
         if args.pcie:

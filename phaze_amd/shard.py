@@ -1,7 +1,9 @@
 """Multi-GPU sharding helpers (no compute): static stream -> rank partition and the max-over-ranks timing reduction.
 
 Streams are independent processors, so the data path needs no collective; torch.distributed (RCCL on the
-GPU box, gloo in the CPU tests) only carries the barrier and one all_reduce(MAX) of the timing.
+GPU box, gloo in the CPU tests) only carries the barrier and one all_reduce(MAX) of the timing.  When the streams of a job arrive on
+(and must return to) one rank, `scatter_streams` / `gather_streams` are the only exchange there is: one block of whole streams per rank,
+moved once each way (BASELINE north_star: "RCCL over xGMI only for the trivial channel scatter/gather").
 """
 from typing import List, Sequence
 
@@ -26,3 +28,65 @@ def reduce_max(values: Sequence[float], dist=None, device=None) -> List[float]:
 def aggregate_rate(units_per_rank: int, world: int, seconds_max: float) -> float:
     """Whole-job throughput: units all ranks processed / slowest rank's time."""
     return units_per_rank * world / seconds_max
+
+
+def block_partition(nstreams: int, world: int, rank: int) -> range:
+    """Contiguous block of streams for `rank` (the first `nstreams % world` ranks get one more): the layout scatter/gather move."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    q, r = divmod(nstreams, world)
+    lo = rank * q + min(rank, r)
+    return range(lo, lo + q + (1 if rank < r else 0))
+
+
+def scatter_streams(x_all, nstreams: int, dist, src: int = 0):
+    """Rank `src` holds x_all = [nstreams, ...]; every rank returns its block_partition slice (a new tensor on x_all's device / dtype).
+    Other ranks pass a tensor of the right trailing shape, dtype and device (its contents are ignored; nstreams rows are not required)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return x_all[:nstreams].clone()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = block_partition(nstreams, world, rank)
+    out = torch.empty((len(mine),) + tuple(x_all.shape[1:]), dtype=x_all.dtype, device=x_all.device)
+    pieces = None
+    if rank == src:
+        pieces = [x_all[block_partition(nstreams, world, r).start:block_partition(nstreams, world, r).stop].contiguous() for r in range(world)]
+    if nstreams % world == 0:
+        dist.scatter(out, pieces, src=src)
+    else:                                                    # unequal blocks: point-to-point (scatter wants equal sizes)
+        if rank == src:
+            for r in range(world):
+                if r == src:
+                    out.copy_(pieces[r])
+                elif pieces[r].numel():
+                    dist.send(pieces[r], dst=r)
+        elif out.numel():
+            dist.recv(out, src=src)
+    return out
+
+
+def gather_streams(y_mine, nstreams: int, dist, dst: int = 0):
+    """Inverse of scatter_streams: rank `dst` returns [nstreams, ...] in stream order, the others None."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return y_mine
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if nstreams % world == 0:
+        pieces = [torch.empty_like(y_mine) for _ in range(world)] if rank == dst else None
+        dist.gather(y_mine.contiguous(), pieces, dst=dst)
+        return torch.cat(pieces, dim=0) if rank == dst else None
+    if rank == dst:
+        pieces = []
+        for r in range(world):
+            n = len(block_partition(nstreams, world, r))
+            if r == dst:
+                pieces.append(y_mine)
+            else:
+                buf = torch.empty((n,) + tuple(y_mine.shape[1:]), dtype=y_mine.dtype, device=y_mine.device)
+                if buf.numel():
+                    dist.recv(buf, src=r)
+                pieces.append(buf)
+        return torch.cat(pieces, dim=0)
+    if y_mine.numel():
+        dist.send(y_mine.contiguous(), dst=dst)
+    return None
