@@ -1,14 +1,17 @@
-"""One-off long fuzz (GPU box): many random cases through every kernel variant vs the CPU oracle.  usage: python tools/fuzz_long.py <ncases> <seed>"""
+"""One-off long fuzz (GPU box): many random cases through every kernel variant vs the CPU oracle.  usage: python tools/fuzz_long.py <ncases> <seed> [log2n]   (log2n pins the FFT size, e.g. 10 to stress the wave kernel)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, phaze_amd, oracle_lib, signals as S
 from test_gpu_fuzz import _case
 n, seed = int(sys.argv[1]), int(sys.argv[2])
+pin = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 rng = np.random.default_rng(seed)
 worst, t0, kern = 0.0, time.time(), {}
 for i in range(n):
     N, hop, nch, T, kind, p = _case(rng)
+    if pin:
+        N = 1 << pin; hop = N >> int(rng.integers(0, 4)); nch = int(rng.integers(1, 5)); T = len(p)
     x = np.stack([S.make_signal(kind, c, T * hop, stream=i) for c in range(nch)])
     fpc = int(rng.choice([0, 0, 1, 3, 7, 16]))
     pv = phaze_amd.PhaseVocoder(fft_size=N, hop_size=hop, max_channels=nch, max_hops=T, frames_per_chunk=fpc)
