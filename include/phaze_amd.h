@@ -49,7 +49,8 @@ typedef struct pv_handle pv_handle;
 typedef struct pv_config {
     int32_t fft_size;        /* N, power of two > 1 (else PV_ERR_FFT_SIZE); kernels cover 64..8192        */
     int32_t hop_size;        /* h >= 2, divides N.  nbOverlaps R = N / h (ola-processor.js:17)           */
-    int32_t max_channels;    /* channel slots owned by this handle (streams x channels); 0 => 2         */
+    int32_t max_channels;    /* channel slots owned by this handle (streams x channels); 0 => 2.  One launch
+                              * takes any count for N = 1024 (hops 128..1024) and up to 65535 otherwise (PV_ERR_CAPACITY) */
     int32_t max_hops;        /* largest nhops of a host-buffer batch call (staging size); 0 => 1        */
     int32_t device_id;       /* HIP device ordinal                                                       */
     int32_t frames_per_chunk;/* batch kernel: output hops per workgroup (0 => auto)                      */
