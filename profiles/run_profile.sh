@@ -11,7 +11,8 @@ OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline $*"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- $BENCH > "$OUT/${TAG}_trace.log" 2>&1
+# the trace pass runs 40 steps so that its mean is dominated by steady-state dispatches (the first 4-5 of a process run at ramping clocks)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- python $ROOT/bench.py --steps 40 --warmup 5 --no-cpu-baseline $* > "$OUT/${TAG}_trace.log" 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" \
