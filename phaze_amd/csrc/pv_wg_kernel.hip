@@ -25,7 +25,9 @@
 
 namespace {
 
-template <int G>
+// CT (compact twiddles, ring kernels): pass-A twiddle rows k = 1, 2, 4 only, the other four by products -- 8 KB per workgroup at G = 2, which is
+// what lets the native 2048/128 configuration keep 4 workgroups per CU next to its overlap-add ring
+template <int G, bool CT = false>
 struct WgCfg {
     static constexpr int T = 64 * G, M = 512 * G, N = 1024 * G, H = M + 1;
     // transpose 2: per-kA row pad, row length.  Row pad 4 (G = 2, 4) / 8 (G = 8) measured conflict-free for the writes AND the reads of both
@@ -46,7 +48,8 @@ struct WgCfg {
     static constexpr int OFF_OCC = OFF_NEAR + 8 * T;                             // u64[G]
     // twiddle rows k = 1..7 only (row 0 is all ones): keeps G = 2 at 4 workgroups per CU
     static constexpr int OFF_TWA = ((OFF_OCC + 8 * G + 15) / 16) * 16;           // double2[7][T]
-    static constexpr int OFF_TWB = OFF_TWA + 16 * 7 * T;                         // double2[7][8G]
+    static constexpr int TWA_ROWS = CT ? 3 : 7;
+    static constexpr int OFF_TWB = OFF_TWA + 16 * TWA_ROWS * T;                  // double2[7][8G]
     static constexpr int OFF_TWC = OFF_TWB + 16 * 7 * 8 * G;                     // double2[7][G]
     static constexpr int LDS_BYTES = OFF_TWC + 16 * 7 * G;
     static constexpr int OFF_ACC = LDS_BYTES;                                    // f32[N - hop] overlap-add ring, only for hops below N/8 (S_ROWS = 0)
@@ -57,7 +60,7 @@ template <typename T_, bool INV>
 __device__ __forceinline__ typename v2t<T_>::type twc(double2 w) { return typename v2t<T_>::type{(T_)w.x, INV ? (T_)(-w.y) : (T_)w.y}; }
 
 // M-point complex FFT across the T threads of the workgroup: in/out layout thread t, reg r <-> element t + T r.
-template <typename T_, bool INV, int G>
+template <typename T_, bool INV, int G, bool CT>
 __device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename v2t<T_>::type *S, const double2 *TWA, const double2 *TWB,
                                        const double2 *TWC, int t)
 {
@@ -66,7 +69,15 @@ __device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename 
     // ---- pass A ----
     radix8<T_, INV>(a);
 #pragma unroll
-    for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWA[(k - 1) * C::T + t]));
+    for (int k = 1; k < 8; k++) {
+        if (!CT) {
+            a[k] = cmul(a[k], twc<T_, INV>(TWA[(k - 1) * C::T + t]));
+        } else {                                                           // rows W^1, W^2, W^4; the rest by products
+            const T2 w1 = twc<T_, INV>(TWA[t]), w2 = twc<T_, INV>(TWA[C::T + t]), w4 = twc<T_, INV>(TWA[2 * C::T + t]);
+            const T2 w = (k == 1) ? w1 : (k == 2) ? w2 : (k == 3) ? cmul(w1, w2) : (k == 4) ? w4 : (k == 5) ? cmul(w4, w1) : (k == 6) ? cmul(w4, w2) : cmul(w4, cmul(w1, w2));
+            a[k] = cmul(a[k], w);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) S[k * C::P1 + t] = a[k];
     __syncthreads();
@@ -121,13 +132,22 @@ __device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename 
 // The inverse instance in packed fp32 (pv_pk_math.h): same layouts as fft_wg<float, true, G>, twiddles conjugated and rounded from the fp64 tables.
 __device__ __forceinline__ pk::c32 twc_inv_pk(double2 w) { return pk::c32{(float)w.x, -(float)w.y}; }
 
-template <int G>
+template <int G, bool CT>
 __device__ __forceinline__ void fft_wg_inv_pk(pk::c32 (&a)[8], pk::c32 *S, const double2 *TWA, const double2 *TWB, const double2 *TWC, int t)
 {
     using C = WgCfg<G>;
     pk::radix8_inv(a);
 #pragma unroll
-    for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], twc_inv_pk(TWA[(k - 1) * C::T + t]));
+    for (int k = 1; k < 8; k++) {
+        if (!CT) {
+            a[k] = pk::cmul(a[k], twc_inv_pk(TWA[(k - 1) * C::T + t]));
+        } else {
+            const pk::c32 w1 = twc_inv_pk(TWA[t]), w2 = twc_inv_pk(TWA[C::T + t]), w4 = twc_inv_pk(TWA[2 * C::T + t]);
+            const pk::c32 w = (k == 1) ? w1 : (k == 2) ? w2 : (k == 3) ? pk::cmul(w1, w2) : (k == 4) ? w4 : (k == 5) ? pk::cmul(w4, w1) : (k == 6) ? pk::cmul(w4, w2)
+                                                                                                                               : pk::cmul(w4, pk::cmul(w1, w2));
+            a[k] = pk::cmul(a[k], w);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) S[k * C::P1 + t] = a[k];
     __syncthreads();
@@ -314,7 +334,7 @@ template <int LOG2N, int S_ROWS, bool AUX>
 __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_kernel(const PvKernelParams p)
 {
     constexpr int G = 1 << (LOG2N - 10);
-    using C = WgCfg<G>;
+    using C = WgCfg<G, (S_ROWS == 0)>;
     constexpr int N = C::N, M = C::M, H = C::H, T = C::T;
     // S_ROWS = hop / (2T) in {1,2,4,8}: the frame advances by whole register rows -> overlap-add accumulator and input window live in
     // registers.  S_ROWS = 0: any other (even) hop dividing N, e.g. the reference's native 2048/128 (R = 16): accumulator ring in LDS
@@ -348,7 +368,10 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
 
     // ---- tables: W_M^{t k} = tw[2 t k], W_T^{q k} = tw[16 q k], W_{8G}^{q k} = tw[128 q k]  (tw[i] = exp(-2 pi j i / N)) ----
 #pragma unroll
-    for (int k = 1; k < 8; k++) TWA[(k - 1) * T + t] = p.tw64[(2 * t * k) & (N - 1)];
+    for (int k = 1; k < 8; k++) {
+        if (!RING) TWA[(k - 1) * T + t] = p.tw64[(2 * t * k) & (N - 1)];
+        else if (k == 1 || k == 2 || k == 4) TWA[(k == 4 ? 2 : k - 1) * T + t] = p.tw64[(2 * t * k) & (N - 1)];
+    }
     for (int i = t; i < 7 * 8 * G; i += T) TWB[i] = p.tw64[(16 * (i % (8 * G)) * (i / (8 * G) + 1)) & (N - 1)];
     for (int i = t; i < 7 * G; i += T) TWC[i] = p.tw64[(128 * (i % G) * (i / G + 1)) & (N - 1)];
 
@@ -412,7 +435,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         double2 z[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) z[r] = double2{(double)(raw[r].x * (0.5f * hw[r].x)), (double)(raw[r].y * (0.5f * hw[r].y))};
-        fft_wg<double, false, G>(z, S64, TWA, TWB, TWC, t);
+        fft_wg<double, false, G, RING>(z, S64, TWA, TWB, TWC, t);
 
         // ---- split pass in conjugate pairs (see pv_wave_kernel.hip): thread t owns the pairs k = t + T r, r < 4, i.e. bins XA[r] = X[k] and
         //      XB[r] = X[M - k]; thread 0 also the self-paired bin M/2.  The partner values Z[M - k] are rows 4..7 of other threads -> LDS ----
@@ -702,7 +725,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             if (t == 0) zi[4] = pk::c32{2.0f * yH.x * sc, -2.0f * yH.y * sc};   // the self-paired bin M/2
         }
         __syncthreads();
-        fft_wg_inv_pk<G>(zi, reinterpret_cast<pk::c32 *>(S32), TWA, TWB, TWC, t);
+        fft_wg_inv_pk<G, RING>(zi, reinterpret_cast<pk::c32 *>(S32), TWA, TWB, TWC, t);
         // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
         {
             const bool emit_out = (m >= first_out);
@@ -784,13 +807,14 @@ hipError_t launch_wg(const PvKernelParams &p, int nch, int nchunks, hipStream_t 
     auto k = pv_wg_kernel<LOG2N, S_ROWS, AUX>;
     int dev = 0;
     hipGetDevice(&dev);
+    using CR = WgCfg<G, true>;
+    constexpr int lds_bytes = S_ROWS ? WgCfg<G>::LDS_BYTES : CR::LDS_BYTES_RING;
     if (!attr_done[dev & 15]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           S_ROWS ? WgCfg<G>::LDS_BYTES : WgCfg<G>::LDS_BYTES_RING);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 15] = true;
     }
-    hipLaunchKernelGGL(k, dim3(nchunks, nch, 1), dim3(64 * G, 1, 1), S_ROWS ? WgCfg<G>::LDS_BYTES : WgCfg<G>::LDS_BYTES_RING, st, p);
+    hipLaunchKernelGGL(k, dim3(nchunks, nch, 1), dim3(64 * G, 1, 1), lds_bytes, st, p);
     return hipGetLastError();
 }
 
@@ -825,9 +849,9 @@ size_t pv_wg_lds_bytes(int log2n, int hop)
     const int N = 1 << log2n;
     const bool ring = !(hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N);
     switch (log2n) {
-    case 11: return ring ? WgCfg<2>::LDS_BYTES_RING : WgCfg<2>::LDS_BYTES;
-    case 12: return ring ? WgCfg<4>::LDS_BYTES_RING : WgCfg<4>::LDS_BYTES;
-    case 13: return ring ? WgCfg<8>::LDS_BYTES_RING : WgCfg<8>::LDS_BYTES;
+    case 11: return ring ? WgCfg<2, true>::LDS_BYTES_RING : WgCfg<2>::LDS_BYTES;
+    case 12: return ring ? WgCfg<4, true>::LDS_BYTES_RING : WgCfg<4>::LDS_BYTES;
+    case 13: return ring ? WgCfg<8, true>::LDS_BYTES_RING : WgCfg<8>::LDS_BYTES;
     default: return 0;
     }
 }
