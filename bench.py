@@ -1,22 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- headline measurement of the phaze hot path on MI355X.
 
-A "step" = one pass of the hot path (one pv_process_batch_device launch) over one batch of synthetic
-input that is already resident in HBM.  Workload at N=1 is BASELINE.json configs[1]: mono 48 kHz,
-FFT=1024, hop=256, pitchFactor=1.5, run in throughput mode: one long stream (HOPS hops per step) is
-processed frame-parallel (chunks of frames with an (R-1)-frame halo).  With --gpus N every
-rank owns an independent stream of the same size on its own GPU (weak scaling, no data-path collective;
-RCCL is only used for the barrier / max-over-ranks reduction of the timing).
+A "step" = one pass of the hot path (one pv_process_batch_device launch) over one batch of synthetic input that is already
+resident in HBM.  The default workload is BASELINE.json configs[1]: mono 48 kHz, FFT=1024, hop=256, pitchFactor=1.5, run in
+throughput mode: one long stream (HOPS hops per step) is processed frame-parallel (chunks of frames with an (R-1)-frame halo, see
+DESIGN.md).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: every rank owns an independent stream of the same size on its own GPU (weak scaling, no data-path collective; RCCL only
+carries the barrier and the max-over-ranks reduction of the timing).  Under `torch.distributed.run` the ranks come from the
+environment; a plain `python bench.py --gpus N` spawns the N ranks itself (one process per GPU).  On a box with fewer than N GPUs
+only the available devices are measured and the line says so (`requested_gpus`, `replicas_measured`).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline":     algorithmic HBM bytes per launch / measured launch duration vs the 8 TB/s peak
-  "cpu_baseline": the CPU oracle (a C port of the reference JS, kind "port") timed on ONE host core on a
-                  bounded sample of the same workload.
+  "roofline":     algorithmic HBM bytes per launch / measured launch duration vs the 8 TB/s peak (HIP events on the launch stream)
+  "cpu_baseline": the CPU oracle (a C port of the reference JS, kind "port") timed on ONE host core on a bounded sample of the same
+                  workload, plus the estimate for the reference's own Node.js path (ratio measured by tools/time_reference.js)
+  "configs":      one short measured line per other BASELINE config (C3, a C4 share, C5 with its pitch sweep, the 8-channel form of the
+                  headline shape) and "latency_us": the streaming-quantum histogram of C5 -- N = 1 only, skipped with --no-extras
 """
 import argparse
-import ctypes
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,6 +33,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+DTYPE = "f64+f32"           # forward FFT and peak decisions in f64 (decision parity), shift / inverse FFT / overlap-add in f32, I/O f32
 
 
 def synth_input(torch, nch, nsamples, device, seed):
@@ -33,17 +42,37 @@ def synth_input(torch, nch, nsamples, device, seed):
     g.manual_seed(1234 + seed)
     n = torch.arange(nsamples, device=device, dtype=torch.float32)
     x = torch.empty((nch, nsamples), device=device, dtype=torch.float32)
+    base = 2 * 3.14159265358979 / 48000.0
     for c in range(nch):
-        base = 2 * 3.14159265358979 / 48000.0
-        s = 0.25 * torch.sin(n * (base * (220.0 + 17 * c))) + 0.125 * torch.sin(n * (base * (1375.0 + 5 * c))) \
+        s = 0.25 * torch.sin(n * (base * (220.0 + 17 * (c % 97)))) + 0.125 * torch.sin(n * (base * (1375.0 + 5 * (c % 89)))) \
             + 0.0625 * torch.sin(n * (base * 6857.0))
         s += (torch.rand(nsamples, device=device, generator=g) - 0.5) * (2.0 / 64)
         x[c] = s
     return x
 
 
+def csrc_sha16():
+    """Identity of the kernel sources: profiles/hbm_traffic.json entries are only reported for the build they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "phaze_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(fft, hop, pitch, target_seconds=12.0):
-    """Times the CPU oracle (oracle/pv_oracle.c -- the checker, used here only as the reported baseline)."""
+    """Times the CPU oracle (oracle/pv_oracle.c -- the checker, used here only as the reported baseline) on one core."""
     import numpy as np
     import oracle_lib
     import signals as S
@@ -61,9 +90,130 @@ def cpu_baseline(fft, hop, pitch, target_seconds=12.0):
     t0 = time.perf_counter()
     o.process_planar(x, p)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} frames of mono {fft}/{hop} pf={pitch} tonal+noise input, single thread, {dt:.1f} s",
-            "host_cpus": os.cpu_count()}
+    out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"{n} frames of mono {fft}/{hop} pf={pitch} tonal+noise input, single thread, {dt:.1f} s",
+           "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
+    # the reference itself (unmodified JS bundle under Node, one thread) cannot travel to the GPU box; tools/time_reference.js timed it
+    # next to this port on the same core of the build container -> port/reference ratio -> estimate for this host
+    rpath = os.path.join(ROOT, "profiles", "cpu_reference_ratio.json")
+    if os.path.exists(rpath):
+        try:
+            rj = json.load(open(rpath))
+            key = f"{fft}/{hop}"
+            ent = next((c for c in rj["configs"] if c["shape"] == key and abs(c["pitch"] - pitch) < 1e-6), None) or \
+                next((c for c in rj["configs"] if c["shape"] == key), None)
+            if ent:
+                out["reference_ratio"] = ent["port_over_reference"]
+                out["reference_frames_per_s_est"] = out["value"] / ent["port_over_reference"]
+                out["reference_ratio_source"] = f"profiles/cpu_reference_ratio.json ({rj.get('node_version', 'node')}, {rj.get('cpu_model', '?')}; tools/time_reference.js)"
+        except Exception:
+            pass
+    return out
+
+
+def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmup, label, local_rank, frames_per_chunk=0,
+            pitch_stride=0, ch_per_stream=1, parity_hops=0, seed=0):
+    """One workload: resident input, `warmup` + `steps` launches bracketed by HIP events on the launch stream.  Returns a dict."""
+    import numpy as np
+    from phaze_amd import shard
+    x = synth_input(torch, nch, T * hop, dev, seed)
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, device_id=local_rank, frames_per_chunk=frames_per_chunk)
+    stream = torch.cuda.Stream(device=dev)        # a real (non-null) torch stream: the library launches on it, so HIP events bracket the kernels
+    assert stream.cuda_stream != 0
+    pv.set_stream(stream.cuda_stream)
+
+    def step():
+        pv.process_batch_device(x.data_ptr(), y.data_ptr(), nch, T, T * hop, pitch_t.data_ptr(), pitch_stride, ch_per_stream)
+
+    parity = None
+    if parity_hops:
+        import oracle_lib
+        K = min(parity_hops, T)
+        pv.reset()
+        step()
+        pv.synchronize()
+        got = y[:, :K * hop].cpu().numpy().astype(np.float64)
+        ph = pitch_t.cpu().numpy()
+        nstreams = nch // ch_per_stream
+        err2, cnt = 0.0, 0
+        for s in range(nstreams):          # one oracle instance per stream (streams are independent processors with their own pitch row)
+            rows = slice(s * ch_per_stream, (s + 1) * ch_per_stream)
+            prow = ph[s * pitch_stride:s * pitch_stride + K] if pitch_stride else ph[:K]
+            ref = oracle_lib.Oracle(fft, hop, ch_per_stream).process_planar(x[rows, :K * hop].cpu().numpy(), np.ascontiguousarray(prow))
+            err2 += float(np.sum((got[rows] - ref) ** 2)); cnt += ref.size
+            if s >= 3:
+                break                       # a few streams are enough for a spot check
+        parity = float(np.sqrt(err2 / cnt))
+    pv.reset()
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(steps):
+            step()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / steps                 # HIP events on the launch stream: average launch duration
+    elapsed, kernel_ms = shard.reduce_max([elapsed, kernel_ms], dist, dev)      # MAX over ranks
+    info = pv.info()
+    pv.close()
+    frames = nch * T
+    alg_bytes = frames * 2 * hop * 4                          # SURVEY 8d: 2*hop*4 B per channel-frame
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    del x, y
+    return {"label": label, "frames_per_step_rank": frames, "elapsed": elapsed, "kernel_ms": kernel_ms, "info": info,
+            "alg_bytes": alg_bytes, "achieved_gbs": achieved, "parity": parity}
+
+
+def latency_histogram(phaze_amd, fft, hop, nch, calls, local_rank, sweep):
+    """Streaming form (one render quantum per call): per-call wall latency of pv_process through the C ABI."""
+    import ctypes as C
+    import numpy as np
+    import signals as S
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, device_id=local_rank)
+    L = pv._L
+    x = np.stack([S.make_signal("tonal", c, 64 * hop) for c in range(nch)])
+    fpt = C.POINTER(C.c_float)
+    outs = [np.zeros(hop, np.float32) for _ in range(nch)]
+    op = (fpt * nch)(*[o.ctypes.data_as(fpt) for o in outs])
+    blocks = [[np.ascontiguousarray(x[c, m * hop:(m + 1) * hop]) for c in range(nch)] for m in range(64)]
+    ips = [(fpt * nch)(*[b.ctypes.data_as(fpt) for b in blocks[m]]) for m in range(64)]
+    lat = np.empty(calls, np.float64)
+    for m in range(calls + 30):
+        pf = (0.5 + 1.5 * ((m % 64) / 63.0)) if sweep else 1.5        # the config's sweep, one value per hop
+        t0 = time.perf_counter_ns()
+        rc = L.pv_process(pv._h, ips[m % 64], op, nch, hop, C.c_float(pf))
+        t1 = time.perf_counter_ns()
+        assert rc == 0
+        if m >= 30:
+            lat[m - 30] = (t1 - t0) * 1e-3
+    pv.close()
+    return {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max()), "calls": calls,
+            "form": f"pv_process through the C ABI (ctypes), {nch}-ch {fft}/{hop} @ 96 kHz, pitchFactor swept per hop, one hop per call "
+                    "(launch + stream sync, zero-copy pinned staging)", "realtime_budget_us": hop / 96000.0 * 1e6}
+
+
+def spawn_ranks(args, n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run (one process per GPU)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:]]
+    env = dict(os.environ)
+    env["PHAZE_BENCH_REQUESTED_GPUS"] = str(args.gpus)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -78,20 +228,38 @@ def main():
     ap.add_argument("--pitch", type=float, default=1.5)
     ap.add_argument("--frames-per-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-config lines and the latency histogram (profiling runs)")
+    ap.add_argument("--allow-lib-override", action="store_true", help="accept PHAZE_LIB (A/B builds of the same ABI); recorded in the line")
     ap.add_argument("--pcie", action="store_true", help="also report the host-buffer (PCIe-inclusive) rate")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="N > 1: all streams start on rank 0, are scattered over RCCL, and the results gathered back (reported separately, never in value)")
     args = ap.parse_args()
 
+    # the library reads no environment; PHAZE_* variables only exist for this harness (PHAZE_LIB = A/B build, explicit opt-in)
+    stray = sorted(k for k in os.environ if k.startswith("PHAZE_") and k not in ("PHAZE_LIB", "PHAZE_BENCH_REQUESTED_GPUS", "PHAZE_NO_TORCH_PRELOAD"))
+    if stray:
+        raise SystemExit(f"bench.py refuses to run with {stray} set: the product has no environment switches")
+    if os.environ.get("PHAZE_LIB") and not args.allow_lib_override:
+        raise SystemExit("PHAZE_LIB is set: pass --allow-lib-override to bench a non-default build (it is recorded in the output)")
+
     import numpy as np
     import torch
-    import phaze_amd
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    requested = int(os.environ.get("PHAZE_BENCH_REQUESTED_GPUS", args.gpus))
+    if "RANK" not in os.environ and args.gpus > 1:
+        # self-spawn: one rank per available GPU; fewer devices than requested -> measure what exists and say so
+        n = min(args.gpus, ndev)
+        if n > 1:
+            sys.exit(spawn_ranks(args, n))
+        os.environ["PHAZE_BENCH_REQUESTED_GPUS"] = str(args.gpus)
+        requested = args.gpus
+
+    import phaze_amd
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -101,119 +269,103 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     fft, hop, nch, T = args.fft, args.hop, args.channels, args.hops
+    from phaze_amd import shard
+    pitch = torch.full((T,), args.pitch, device=dev, dtype=torch.float32)
+    head = measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch, args.steps, args.warmup, "headline", local_rank,
+                   frames_per_chunk=args.frames_per_chunk, parity_hops=96 if rank == 0 else 0, seed=rank)
+
     sg_ms = None
-    if args.scatter_gather and dist is not None:
-        # the only exchange a multi-GPU job can have: whole streams out from rank 0 (and results back, below)
-        from phaze_amd import shard as _shard
+    if args.scatter_gather and dist is not None and world > 1:
+        # the only exchange a multi-GPU job can have: whole streams out from rank 0 and results back (outside the timed region)
         x_all = (torch.stack([synth_input(torch, nch, T * hop, dev, seed=r) for r in range(world)]) if rank == 0
                  else torch.empty((0, nch, T * hop), device=dev, dtype=torch.float32))
         torch.cuda.synchronize(); dist.barrier(); t_sg = time.perf_counter()
-        x = _shard.scatter_streams(x_all, world, dist)[0].contiguous()
-        torch.cuda.synchronize(); dist.barrier(); sg_ms = (time.perf_counter() - t_sg) * 1e3
-        del x_all
-    else:
-        x = synth_input(torch, nch, T * hop, dev, seed=rank)
-    y = torch.empty_like(x)
-    pitch = torch.full((T,), args.pitch, device=dev, dtype=torch.float32)
-    torch.cuda.synchronize()
+        xs = shard.scatter_streams(x_all, world, dist)
+        ys = shard.gather_streams(xs, world, dist)
+        torch.cuda.synchronize(); dist.barrier()
+        sg_ms = shard.reduce_max([(time.perf_counter() - t_sg) * 1e3], dist, dev)[0]
+        del x_all, xs, ys
 
-    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, device_id=local_rank,
-                                frames_per_chunk=args.frames_per_chunk)
-    # a real (non-null) torch stream: the library launches on it, so torch.cuda.Event brackets the kernels
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    pv.set_stream(stream.cuda_stream)
-
-    def step():
-        pv.process_batch_device(x.data_ptr(), y.data_ptr(), nch, T, T * hop, pitch.data_ptr(), 0, 1)
-
-    # ---- in-bench parity spot check: first hops of the resident batch vs the CPU oracle ----
-    parity = None
-    if rank == 0:
-        import oracle_lib
-        K = 96
-        pv.reset()
-        step()
-        torch.cuda.synchronize()
-        got = y[:, :K * hop].cpu().numpy()
-        ref = oracle_lib.Oracle(fft, hop, nch).process_planar(x[:, :K * hop].cpu().numpy(), np.full(K, args.pitch, np.float32))
-        parity = float(np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)))
-    pv.reset()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps            # HIP events on the launch stream: avg launch duration
-    from phaze_amd import shard
-    elapsed, kernel_ms = shard.reduce_max([elapsed, kernel_ms], dist, dev)      # MAX over ranks
-
-    if sg_ms is not None:
-        from phaze_amd import shard as _shard
-        torch.cuda.synchronize(); dist.barrier(); t_sg = time.perf_counter()
-        y_all = _shard.gather_streams(y.unsqueeze(0), world, dist)
-        torch.cuda.synchronize(); dist.barrier(); sg_ms += (time.perf_counter() - t_sg) * 1e3
-        del y_all
-        sg_ms = _shard.reduce_max([sg_ms], dist, dev)[0]
-
-    info = pv.info()
-    frames_per_step_rank = nch * T
-    value = shard.aggregate_rate(frames_per_step_rank * args.steps, world, elapsed)
-    alg_bytes_per_launch = frames_per_step_rank * 2 * hop * 4          # 2*hop*4 B per channel-frame
-    achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9          # GB/s, per GPU
-    traffic = None
+    info = head["info"]
+    value = shard.aggregate_rate(head["frames_per_step_rank"] * args.steps, world, head["elapsed"])
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            key = f"{fft}/{hop}/ch{nch}/hops{T}"
-            if key in tj:
-                traffic = tj[key]["bytes_per_launch"]
+            ent = tj.get(f"{fft}/{hop}/ch{nch}/hops{T}")
+            if ent and ent.get("csrc_sha16") == csrc_sha16():
+                traffic = ent["bytes_per_launch"]
+                traffic_src = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, measured on this build of the kernels)"
+            elif ent:
+                traffic_src = "profiles/hbm_traffic.json holds a figure for an OLDER build of the kernels: not reported"
         except Exception:
             traffic = None
 
     out = None
     if rank == 0:
+        chs = "mono" if nch == 1 else "stereo" if nch == 2 else f"{nch}-ch"
+        is_c1 = (fft, hop, nch) == (1024, 256, 1) and abs(args.pitch - 1.5) < 1e-9
         out = {
             "metric": "stft_frames_per_sec_1024pt_hop256_48k" if (fft, hop) == (1024, 256) else f"stft_frames_per_sec_{fft}pt_hop{hop}",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "dtype_note": "forward FFT and peak decisions in f64 (decision parity), shift / inverse FFT / overlap-add in f32, I/O f32",
+            "ms_per_step": head["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": DTYPE,
+            "dtype_note": "forward FFT and peak decisions in f64 (decision parity), shift / inverse FFT / overlap-add in f32, I/O f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {'mono' if nch == 1 else str(nch) + '-ch'} 48 kHz FFT={fft} hop={hop} pitchFactor={args.pitch}, "
-                                   f"throughput mode, one resident stream of {T} hops per GPU per step",
+            "config": {"workload": ("BASELINE configs[1]: " if is_c1 else "") + f"{chs} 48 kHz FFT={fft} hop={hop} pitchFactor={args.pitch}, throughput mode, "
+                                   f"{nch} resident channel(s) x {T} hops per GPU per step",
                        "fft": fft, "hop": hop, "channels": nch, "hops_per_step": T, "pitch_factor": args.pitch,
                        "frames_per_chunk": info["frames_per_chunk"], "threads_per_workgroup": info["threads_per_workgroup"],
                        "lds_bytes_per_workgroup": info["lds_bytes_per_workgroup"], "parallelism": f"streams x{world} (independent, no collective)",
                        "device": info["device_name"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": info["kernel_name"], "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
-                         "note": "algorithmic bytes = 2*hop*4 B per channel-frame; the kernel is LDS/VALU-bound (fp64 FFT), see DESIGN.md"},
-            "parity_rms_vs_oracle": parity,
+            "roofline": {"bound": "hbm", "achieved": head["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["achieved_gbs"] / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": info["kernel_name"], "kernel_ms": head["kernel_ms"],
+                         "algorithmic_bytes_per_launch": head["alg_bytes"], "traffic_source": traffic_src,
+                         "note": "algorithmic bytes = 2*hop*4 B per channel-frame; the kernel is issue/LDS-bound (fp64 FFT), see DESIGN.md"},
+            "parity_rms_vs_oracle": head["parity"],
         }
+        if requested != world:
+            out["requested_gpus"] = requested
+            out["replicas_measured"] = world
+            out["note_gpus"] = (f"{requested} GPUs requested, {ndev} visible: {world} replica(s) measured; streams are independent shards with no "
+                                "inter-GPU dependency (SURVEY 8e), nothing is extrapolated")
+        if os.environ.get("PHAZE_LIB"):
+            out["lib_override"] = os.environ["PHAZE_LIB"]
         if sg_ms is not None:
-            out["scatter_gather_ms"] = sg_ms        # one step's input out + output back over RCCL, outside the timed region
+            out["scatter_gather_ms"] = sg_ms        # one step's input out + back over RCCL, outside the timed region
+
+    if world == 1 and not args.no_extras:
+        # ---- the other BASELINE configs, each a short measured line (same harness, same timing method) ----
+        extras = []
+        def add(label, workload, f2, h2, c2, T2, pt, **kw):
+            r = measure(torch, phaze_amd, dev, None, f2, h2, c2, T2, pt, 5, 2, label, local_rank, parity_hops=12, **kw)
+            extras.append({"workload": workload, "value": r["frames_per_step_rank"] * 5 / r["elapsed"], "unit": "frames/s",
+                           "ms_per_step": r["elapsed"] / 5 * 1e3, "kernel_ms": r["kernel_ms"], "kernel": r["info"]["kernel_name"],
+                           "roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS, "parity_rms_vs_oracle": r["parity"],
+                           "frames_per_chunk": r["info"]["frames_per_chunk"]})
+        T3 = 1 << 18
+        add("C3", f"BASELINE configs[2]: stereo 48 kHz FFT=2048 hop=512 pitchFactor=f32(0.8), 2 ch x {T3} hops resident", 2048, 512, 2, T3,
+            torch.full((T3,), 0.8, device=dev, dtype=torch.float32))
+        add("C4", "BASELINE configs[3], one GPU's share: 8-ch 48 kHz FFT=4096 hop=1024, 128 streams x 8 ch = 1024 channel slots x 64 hops, pitchFactor=1.25",
+            4096, 1024, 1024, 64, torch.full((64,), 1.25, device=dev, dtype=torch.float32), ch_per_stream=8)
+        T5 = 1 << 14
+        sweep = (0.5 + 1.5 * (torch.arange(T5, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
+        add("C5", f"BASELINE configs[4]: 8-ch 96 kHz FFT=8192 hop=2048, pitchFactor swept 0.5->2.0 per hop (period 64 hops), 8 ch x {T5} hops resident",
+            8192, 2048, 8, T5, sweep)
+        T8 = 1 << 17
+        add("8ch", f"8-ch 48 kHz FFT=1024 hop=256 pitchFactor=1.5 (the target's phrasing), 8 ch x {T8} hops resident", 1024, 256, 8, T8,
+            torch.full((T8,), 1.5, device=dev, dtype=torch.float32))
+        out["configs"] = extras
+        out["latency_us"] = latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True)
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(fft, hop, args.pitch)
         if args.pcie:
-            xh = x[:, :min(T, 1 << 14) * hop].cpu().numpy()
-            Tp = xh.shape[1] // hop
+            import signals as S
+            Tp = min(T, 1 << 14)
+            xh = np.stack([S.make_signal("tonal", c, Tp * hop) for c in range(nch)])
             pv2 = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=Tp, device_id=local_rank)
             pv2.process_batch(xh, np.full(Tp, args.pitch, np.float32))
             t1 = time.perf_counter()
@@ -222,7 +374,6 @@ def main():
             out["pcie_inclusive_frames_per_s"] = 3 * nch * Tp / (time.perf_counter() - t1)
             pv2.close()
         print(json.dumps(out), flush=True)
-    pv.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -54,14 +54,24 @@ typedef struct pv_config {
     int32_t max_hops;        /* largest nhops of a host-buffer batch call (staging size); 0 => 1        */
     int32_t device_id;       /* HIP device ordinal                                                       */
     int32_t frames_per_chunk;/* batch kernel: output hops per workgroup (0 => auto)                      */
+    int32_t flags;           /* PV_FLAG_* bits, 0 for production use                                     */
 } pv_config;
+
+/* pv_config.flags: explicit A/B switches for tests and measurements (the library reads NO environment
+ * variables).  Both select complete, parity-tested implementations of the same path. */
+enum {
+    PV_FLAG_GENERIC_KERNEL = 1, /* always launch the LDS-staged fallback kernel (pv_chain_kernel)        */
+    PV_FLAG_STREAM_COPY = 2     /* streaming quantum through H2D + kernel + D2H copies instead of the
+                                 * zero-copy mapping of the pinned staging buffer                         */
+};
 
 typedef struct pv_info {
     int32_t fft_size, hop_size, overlaps, max_channels, max_hops;
     int32_t threads_per_workgroup, lds_bytes_per_workgroup, frames_per_chunk;
     int32_t compute_units, device_id;
     char device_name[64];
-    char kernel_name[32];    /* "pv_wave_kernel_1024" (N = 1024, hop in {128,256,512,1024}) or "pv_chain_kernel" (generic)  */
+    char kernel_name[32];    /* "pv_wave_kernel_1024" (N = 1024, hop in {128,256,512,1024}), "pv_wg_kernel" (N = 2048..8192,
+                              * even hops that fit LDS) or "pv_chain_kernel" (everything else / PV_FLAG_GENERIC_KERNEL) */
 } pv_info;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
@@ -81,7 +91,9 @@ PV_API int pv_reset(pv_handle *h);
 /* Zero history + accumulator of channel slots [first, first+count): what allocateInputChannels /
  * allocateOutputChannels do when a channel count changes (ola-processor.js:38-52,54-88).  timeCursor kept. */
 PV_API int pv_reset_channels(pv_handle *h, int32_t first, int32_t count);
-/* timeCursor (phase-vocoder.js:31,71): samples consumed so far = hops * hop_size. */
+/* timeCursor (phase-vocoder.js:31,71): samples consumed so far = hops * hop_size.  The reference only ever
+ * advances it by hop_size (pv:71), so a value that is negative or not a multiple of hop_size is rejected
+ * with PV_ERR_ARGUMENT (the register kernels rely on t = m * hop for their exact rotations). */
 PV_API int pv_get_time_cursor(const pv_handle *h, int64_t *out);
 PV_API int pv_set_time_cursor(pv_handle *h, int64_t value);
 

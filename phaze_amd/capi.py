@@ -31,7 +31,11 @@ class PvError(RuntimeError):
 
 
 class _Config(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("fft_size", "hop_size", "max_channels", "max_hops", "device_id", "frames_per_chunk")]
+    _fields_ = [(n, C.c_int32) for n in ("fft_size", "hop_size", "max_channels", "max_hops", "device_id", "frames_per_chunk", "flags")]
+
+
+# pv_config.flags (include/phaze_amd.h): explicit A/B switches; the library reads no environment variables
+FLAG_GENERIC_KERNEL, FLAG_STREAM_COPY = 1, 2
 
 
 class _Info(C.Structure):
@@ -105,10 +109,10 @@ class PhaseVocoder:
 
     parameter_descriptors = [{"name": "pitchFactor", "defaultValue": 1.0}]   # phase-vocoder.js:17-22
 
-    def __init__(self, fft_size=2048, hop_size=128, max_channels=2, max_hops=1, device_id=0, frames_per_chunk=0):
+    def __init__(self, fft_size=2048, hop_size=128, max_channels=2, max_hops=1, device_id=0, frames_per_chunk=0, flags=0):
         self._L = load_library()
         self._h = C.c_void_p()
-        cfg = _Config(fft_size, hop_size, max_channels, max_hops, device_id, frames_per_chunk)
+        cfg = _Config(fft_size, hop_size, max_channels, max_hops, device_id, frames_per_chunk, flags)
         rc = self._L.pv_create(C.byref(cfg), C.byref(self._h))
         if rc != PV_OK:
             msg = self._L.pv_last_error(None).decode()

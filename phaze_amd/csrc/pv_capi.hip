@@ -76,7 +76,7 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
     // Trade-off: long chains amortise the (R-1)-frame halo, but the last partial round of workgroups idles the chip.
     // resident = chains the GPU runs concurrently (wave kernel: 8 per CU; generic: LDS-limited workgroups per CU).
     long per_cu;
-    if (h->use_wave) per_cu = 12;
+    if (h->use_wave) per_cu = pv_wave_threads() / 64;
     else if (h->use_wg) { per_cu = (160 * 1024) / (long)pv_wg_lds_bytes(h->log2n, h->hop); if (per_cu < 1) per_cu = 1; }
     else { per_cu = (160 * 1024) / (long)pv_kernel_lds_bytes(h->log2n, h->hop); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1; }
     const long resident = per_cu * h->cus;
@@ -117,7 +117,6 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     p.t0_mod_n = (int)(h->time_cursor & (int64_t)(h->N - 1));
     p.tw64 = h->d_tw64; p.tw32 = h->d_tw32; p.hann = h->d_hann;
     p.dbg_ch = -1; p.dbg_frame = -1;
-    { const char *ab = getenv("PHAZE_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
     if (dbg_ch >= 0) { p.dbg_X = h->d_dbgX; p.dbg_mag = h->d_dbgMag; p.dbg_flags = h->d_dbgFlags; p.dbg_Y = h->d_dbgY; p.dbg_ch = dbg_ch; p.dbg_frame = 0; }
     const int nchunks = (nhops + p.frames_per_chunk - 1) / p.frames_per_chunk;
     if (!h->use_wave && nch > 65535) return fail(h, PV_ERR_CAPACITY, "more than 65535 channel slots in one launch (grid.y limit): split the call");
@@ -189,9 +188,9 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     h->frames_per_chunk_cfg = cfg->frames_per_chunk;
     h->active_nch = -1;
     {
-        const char *g = getenv("PHAZE_GENERIC_KERNEL");      // A/B switch for tests and profiling
-        h->use_wave = pv_wave_supported(log2n, hop) && !(g && g[0] == '1');
-        h->use_wg = pv_wg_supported(log2n, hop) && !(g && g[0] == '1');
+        const bool generic = (cfg->flags & PV_FLAG_GENERIC_KERNEL) != 0;      // explicit A/B switch (tests, measurements); no environment is read
+        h->use_wave = pv_wave_supported(log2n, hop) && !generic;
+        h->use_wg = pv_wg_supported(log2n, hop) && !generic;
     }
 #define CHK(call)                                                          \
     do {                                                                   \
@@ -246,10 +245,9 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     CHK(hipHostMalloc((void **)&h->h_pin, quantum, hipHostMallocMapped));
     {
         // streaming quantum: the kernel reads the hop straight from / writes it straight to pinned host memory (one launch + one sync,
-        // no copy nodes).  PHAZE_STREAM_COPY=1 restores H2D + kernel + D2H staging.
-        const char *sc = getenv("PHAZE_STREAM_COPY");
+        // no copy nodes).  PV_FLAG_STREAM_COPY restores H2D + kernel + D2H staging.
         void *dp = nullptr;
-        if (!(sc && sc[0] == '1') && hipHostGetDevicePointer(&dp, h->h_pin, 0) == hipSuccess) h->d_pin_mapped = (float *)dp;
+        if (!(cfg->flags & PV_FLAG_STREAM_COPY) && hipHostGetDevicePointer(&dp, h->h_pin, 0) == hipSuccess) h->d_pin_mapped = (float *)dp;
         (void)hipGetLastError();
     }
     CHK(hipMalloc(&h->d_quantum, quantum));
@@ -330,6 +328,7 @@ int pv_set_time_cursor(pv_handle *h, int64_t value)
 {
     if (!live(h)) return PV_ERR_DESTROYED;
     if (value < 0) return fail(h, PV_ERR_ARGUMENT, "pv_set_time_cursor: negative");
+    if (value % h->hop != 0) return fail(h, PV_ERR_ARGUMENT, "pv_set_time_cursor: not a multiple of hop_size (the reference only advances it by hop_size, pv:71)");
     h->time_cursor = value;
     return PV_OK;
 }
@@ -394,7 +393,9 @@ int pv_process_batch_device(pv_handle *h, const float *d_in, float *d_out, int32
     if (!live(h)) return PV_ERR_DESTROYED;
     if (!d_in || !d_out || !d_pitch || nch <= 0 || nhops <= 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: bad arguments");
     if (nch > h->max_channels) return fail(h, PV_ERR_CAPACITY, "pv_process_batch_device: nch exceeds max_channels");
-    if (ch_stride < (int64_t)nhops * h->hop && nch > 1) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: ch_stride smaller than nhops*hop");
+    if (ch_stride < (int64_t)nhops * h->hop) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: ch_stride smaller than nhops*hop");
+    if (pitch_stride != 0 && pitch_stride < nhops) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: pitch_stride smaller than nhops");
+    if (pitch_stride < 0 || channels_per_stream < 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: negative stride");
     HIPCHK(h, hipSetDevice(h->device));
     return run_chain(h, d_in, d_out, nch, nhops, (long)ch_stride, d_pitch, pitch_stride, channels_per_stream, true, -1);
 }
@@ -406,7 +407,8 @@ int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int
     if (!in || !out || !pitch || nch <= 0 || nhops <= 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: bad arguments");
     if (nch > h->max_channels || nhops > h->max_hops) return fail(h, PV_ERR_CAPACITY, "pv_process_batch: nch/nhops exceed the handle's capacity");
     const size_t row = (size_t)nhops * h->hop;
-    if (ch_stride < (int64_t)row && nch > 1) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: ch_stride smaller than nhops*hop");
+    if (ch_stride < (int64_t)row) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: ch_stride smaller than nhops*hop");
+    if (pitch_stride < 0 || channels_per_stream < 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: negative stride");
     HIPCHK(h, hipSetDevice(h->device));
     const int cps = channels_per_stream > 0 ? channels_per_stream : 1;
     const int nrows = pitch_stride ? (nch + cps - 1) / cps : 1;

@@ -17,6 +17,7 @@ namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));   // clang vector type (the nontemporal builtins need one)
 
 template <typename T> struct v2t;

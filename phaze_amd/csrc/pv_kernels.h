@@ -29,7 +29,6 @@ struct PvKernelParams {
     int *dbg_flags;
     float *dbg_Y;
     int dbg_ch, dbg_frame;
-    int ablate;               // profiling only (env PHAZE_ABLATE): bit mask of pipeline phases to skip; 0 in production
 };
 
 int pv_kernel_threads(int log2n);

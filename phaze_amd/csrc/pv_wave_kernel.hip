@@ -32,16 +32,28 @@
 
 namespace {
 
-constexpr int WAVES = 12;                        // independent frame chains per workgroup (they only share the LDS tables)
+#ifndef PV_WAVES
+#define PV_WAVES 12
+#endif
+#ifndef PV_WAVES_PER_SIMD
+#define PV_WAVES_PER_SIMD 3
+#endif
+constexpr int WAVES = PV_WAVES;                  // independent frame chains per workgroup (they only share the LDS tables)
 constexpr int TAB_TW1 = 0;                       // double2[8*64]  W_512^{l k}
 constexpr int TAB_TW2 = TAB_TW1 + 8 * 64 * 16;   // double2[8*8]   W_64^{n0 k}
-constexpr int TAB_TW1F = TAB_TW2 + 8 * 8 * 16;   // float2[8*64]   conj, fp32 (inverse)
-constexpr int TAB_TW2F = TAB_TW1F + 8 * 64 * 8;  // float2[8*8]
-constexpr int TAB_HANN = TAB_TW2F + 8 * 8 * 8;   // float2[512]    0.5 * Hann at samples 2n, 2n+1 (analysis; 1/2 of the split pass folded in, exact)
-constexpr int TAB_HANNI = TAB_HANN + 512 * 8;    // float2[512]    Hann / R (synthesis; the 1/R of the overlap-add folded in, exact: R = 2^k)
-constexpr int TAB_BYTES = TAB_HANNI + 512 * 8;   // 22016
+// The fp32 tables are stored in PAIRS of rows (a ds_read costs the LDS pipe the same ~3 cycles whether it returns 8 or 16 bytes per lane,
+// tools/valu_microbench2.hip): one ds_read_b128 fetches the entries of two consecutive k (twiddles) / two consecutive register rows (Hann).
+constexpr int TAB_TW1F = TAB_TW2 + 8 * 8 * 16;   // float4[4*64]   conj(W_512^{l k}), fp32 (inverse): entry [j*64 + l] = (k = 2j, k = 2j+1)
+constexpr int TAB_TW2F = TAB_TW1F + 4 * 64 * 16; // float4[4*8]    conj(W_64^{n0 k}): entry [j*8 + n0] = (k = 2j, k = 2j+1)
+constexpr int TAB_HANN = TAB_TW2F + 4 * 8 * 16;  // float4[4*64]   0.5 * Hann at samples 2n, 2n+1 for n = l + 64 r: entry [j*64 + l] = (r = 2j, r = 2j+1).
+                                                 //                ONE table serves both windows: the 1/2 of the split pass is folded in for the analysis
+                                                 //                window, and the synthesis side folds 2/R into the scale of the c2r pass (all exact)
+constexpr int TAB_BYTES = TAB_HANN + 4 * 64 * 16;  // 17920
 
-constexpr int TP = 72;   // padded row of the transpose scratch (elements); conflict-free with the skew below
+#ifndef PV_TP
+#define PV_TP 72
+#endif
+constexpr int TP = PV_TP;   // padded row of the transpose scratch (elements); 72 is conflict-free with the skew below
 
 // 512-point complex FFT across one wave: in/out layout lane l, reg r <-> element l + 64 r.
 // TW1[k*64 + l] = W_512^{l k}, TW2[k*8 + n0] = W_64^{n0 k} (k = 1..7) live in LDS, shared by the waves of the workgroup,
@@ -78,29 +90,53 @@ __device__ __forceinline__ void fft512_wave(typename v2t<T>::type (&a)[8], typen
 }
 
 
-// The inverse instance in packed fp32 (pv_pk_math.h): same layouts and tables, 106 packed instructions instead of ~210.
-__device__ __forceinline__ void fft512_wave_inv_pk(pk::c32 (&a)[8], pk::c32 *S, const pk::c32 *TW1, const pk::c32 *TW2, int l)
+// The inverse instance in packed fp32 (pv_pk_math.h): 106 packed instructions instead of ~210.  Its LDS traffic is organised around the
+// measured costs of the LDS pipe (tools/valu_microbench2.hip: a read costs ~3 cycles per wave-instruction whatever its width, ds_write_b64
+// ~5.8, ds_write_b128 ~9.1): the twiddles of two consecutive k come from ONE ds_read_b128 of a pair-interleaved table, and the transposes
+// write register PAIRS (4 ds_write_b128 instead of 8 ds_write_b64); a reader picks the half it needs with the address.  Rows of 64 pair slots
+// are padded to TPP = 72 slots (1152 B = 128 mod 256): the four rows a read touches fall on alternating halves of the 64 banks -> 2 passes,
+// the minimum for 512 bytes (checked with tools/lds_layout_check.py pairs).
+constexpr int TPP = 72;
+__device__ __forceinline__ void fft512_wave_inv_pk(pk::c32 (&a)[8], pk::c32 *S, const v4f *TW1F4, const v4f *TW2F4, int l)
 {
     const int lh = l >> 3, ll = l & 7;
+    v4f *S4 = reinterpret_cast<v4f *>(S);
     pk::radix8_inv(a);
 #pragma unroll
-    for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], TW1[k * 64 + l]);
+    for (int j = 0; j < 4; j++) {
+        const v4f t = TW1F4[j * 64 + l];
+        if (j) a[2 * j] = pk::cmul(a[2 * j], pk::c32{t.x, t.y});
+        a[2 * j + 1] = pk::cmul(a[2 * j + 1], pk::c32{t.z, t.w});
+    }
+    // transpose 1: [reg k0][lane (n1,n0)] -> [reg n1][lane (k0,n0)]; pair row k0 >> 1, half k0 & 1
 #pragma unroll
-    for (int k = 0; k < 8; k++) S[k * TP + l] = a[k];
+    for (int j = 0; j < 4; j++) S4[j * TPP + l] = v4f{a[2 * j].x, a[2 * j].y, a[2 * j + 1].x, a[2 * j + 1].y};
     wave_sync();
 #pragma unroll
-    for (int n = 0; n < 8; n++) a[n] = S[lh * TP + 8 * n + ll];
-    wave_sync();
-    pk::radix8_inv(a);
-#pragma unroll
-    for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], TW2[k * 8 + ll]);
-#pragma unroll
-    for (int k = 0; k < 8; k++) S[k * TP + lh * 8 + ((ll + lh) & 7)] = a[k];
-    wave_sync();
-#pragma unroll
-    for (int n = 0; n < 8; n++) a[n] = S[lh * TP + ll * 8 + ((n + ll) & 7)];
+    for (int n = 0; n < 8; n++) a[n] = S[2 * ((lh >> 1) * TPP + 8 * n + ll) + (lh & 1)];
     wave_sync();
     pk::radix8_inv(a);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const v4f t = TW2F4[j * 8 + ll];
+        if (j) a[2 * j] = pk::cmul(a[2 * j], pk::c32{t.x, t.y});
+        a[2 * j + 1] = pk::cmul(a[2 * j + 1], pk::c32{t.z, t.w});
+    }
+    // transpose 2: [reg k1][lane (k0,n0)] -> [reg n0][lane (k1,k0)], skewed columns
+#pragma unroll
+    for (int j = 0; j < 4; j++) S4[j * TPP + lh * 8 + ((ll + lh) & 7)] = v4f{a[2 * j].x, a[2 * j].y, a[2 * j + 1].x, a[2 * j + 1].y};
+    wave_sync();
+#pragma unroll
+    for (int n = 0; n < 8; n++) a[n] = S[2 * ((lh >> 1) * TPP + ll * 8 + ((n + ll) & 7)) + (lh & 1)];
+    wave_sync();
+    pk::radix8_inv(a);
+}
+
+// conj(W_512^{l k}) in fp32 from the pair-interleaved table (residue paths)
+__device__ __forceinline__ float2 tw1f_at(int k, int l)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    return reinterpret_cast<const float2 *>(smem_all + TAB_TW1F)[2 * ((k >> 1) * 64 + l) + (k & 1)];
 }
 
 // o * exp(+2 pi j r / 16), r = 0..3 (compile-time): the wave-uniform part of the c2r twiddle, packed
@@ -180,7 +216,6 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_fast_1024(const
     float2 *Y = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_Y);
     unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + OFF_ROUTE);
     const float2 *XS = reinterpret_cast<const float2 *>(smem_all + wave_off + OFF_XS);
-    const float2 *TW1F = reinterpret_cast<const float2 *>(smem_all + TAB_TW1F);    // conj(W_512^{l k}), fp32
     unsigned rt[2];
     float2 ys[2];
     int id[2];
@@ -191,7 +226,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_fast_1024(const
         const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
         // W^{-2k} = conj(W_512^k) = conj(W_512^{k & 63}) * conj(W_8^{k >> 6}) from the LDS table (a global table load would sit, exposed, on the
         // critical path of every f < 1 frame)
-        float2 w = TW1F[64 + (k & 63)];
+        float2 w = tw1f_at(1, k & 63);
         const int k6 = k >> 6;                                             // 0, 1 or 2
         const float hh = 0.70710678118654752440f;
         if (k6 == 1) w = float2{(w.x - w.y) * hh, (w.x + w.y) * hh};      // * (h + j h)
@@ -219,8 +254,9 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(co
     float2 *Y = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_Y);
     unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + OFF_ROUTE);
     float2 *Q = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_RESQ);
-    const float *HWf = reinterpret_cast<const float *>(smem_all + TAB_HANN);       // 0.5 * Hann, shared table
-    const float2 *TW1F = reinterpret_cast<const float2 *>(smem_all + TAB_TW1F);    // conj(W_512^{l k}) = conj(W_1024^{2 l k}), fp32
+    // 0.5 * Hann of sample s = 2n + c, n = ln + 64 r, from the pair-interleaved shared table (entry [(r >> 1) * 64 + ln] = rows 2j, 2j+1)
+    const float *HWf = reinterpret_cast<const float *>(smem_all + TAB_HANN);
+    auto hw_at = [&](int smp) { const int n = smp >> 1, ln = n & 63, r = n >> 6; return HWf[4 * ((r >> 1) * 64 + ln) + 2 * (r & 1) + (smp & 1)]; };
     (void)hann;
     const WaveSrc src{in, hist, hist_len};
     for (int base = N / 2; base < N && base < upper_end; base += N / 4) {
@@ -228,10 +264,10 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(co
             const int t = base / 4 + l;
             const unsigned rv = __brev((unsigned)t) >> (32 - 8);
             const int off = (int)(((rv & 0x55555555u) << 1) | ((rv >> 1) & 0x55555555u));
-            const float a = src.at(s0 + off) * (2.0f * HWf[off]);                       // Hann from the LDS table (2 * 0.5 w: exact)
-            const float b = src.at(s0 + off + N / 4) * (2.0f * HWf[off + N / 4]);
-            const float c = src.at(s0 + off + N / 2) * (2.0f * HWf[off + N / 2]);
-            const float d = src.at(s0 + off + 3 * N / 4) * (2.0f * HWf[off + 3 * N / 4]);
+            const float a = src.at(s0 + off) * (2.0f * hw_at(off));                     // Hann from the LDS table (2 * 0.5 w: exact)
+            const float b = src.at(s0 + off + N / 4) * (2.0f * hw_at(off + N / 4));
+            const float c = src.at(s0 + off + N / 2) * (2.0f * hw_at(off + N / 2));
+            const float d = src.at(s0 + off + 3 * N / 4) * (2.0f * hw_at(off + 3 * N / 4));
             const float t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
             Q[4 * l] = float2{t0 + t2, 0.f};
             Q[4 * l + 1] = float2{t1, -t3};
@@ -250,9 +286,9 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(co
                 if (it < nblocks * hq) { blk = it / hq; i = it - blk * hq; } else { blk = it - nblocks * hq; i = hq; }
                 const int o = blk << log2m;
                 const float2 A = Q[o + i];
-                const float2 Bv = cmul(Q[o + q + i], cconj(TW1F[2 * 64 + i * step]));
-                const float2 C = cmul(Q[o + 2 * q + i], cconj(TW1F[4 * 64 + i * step]));
-                const float2 D = cmul(Q[o + 3 * q + i], cconj(TW1F[6 * 64 + i * step]));
+                const float2 Bv = cmul(Q[o + q + i], cconj(tw1f_at(2, i * step)));
+                const float2 C = cmul(Q[o + 2 * q + i], cconj(tw1f_at(4, i * step)));
+                const float2 D = cmul(Q[o + 3 * q + i], cconj(tw1f_at(6, i * step)));
                 const float2 T0 = cadd(A, C), T1 = csub(A, C), T2 = cadd(Bv, D), T3 = csub(Bv, D);
                 Q[o + i] = cadd(T0, T2);
                 Q[o + q + i] = float2{T1.x + T3.y, T1.y - T3.x};          // T1 - j T3
@@ -357,11 +393,10 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void scatter_colliding_1024(
 }
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
-// AUX = true: test-tap / phase-ablation build (pv_debug_frame, PHAZE_ABLATE); the production instance carries neither.
+// AUX = true: test-tap instance (pv_debug_frame); the production instance carries no tap code.
 template <int S_ROWS, bool AUX>
-__global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1024(const PvKernelParams p)
+__global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void pv_wave_kernel_1024(const PvKernelParams p)
 {
-    const int ablate = AUX ? p.ablate : 0;                                // phase-ablation build (profiling only); folds away otherwise
     constexpr int N = 1024, M = 512, H = 513;
     constexpr int HOP = 128 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;    // LROWS rows of carried accumulator
     constexpr int BIG = 1 << 30;
@@ -377,37 +412,31 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const double2 *TW1 = reinterpret_cast<const double2 *>(smem_all + TAB_TW1);
     const double2 *TW2 = reinterpret_cast<const double2 *>(smem_all + TAB_TW2);
-    const float2 *TW1F = reinterpret_cast<const float2 *>(smem_all + TAB_TW1F);
-    const float2 *TW2F = reinterpret_cast<const float2 *>(smem_all + TAB_TW2F);
-    const float2 *HW = reinterpret_cast<const float2 *>(smem_all + TAB_HANN);
-    const float2 *HWI = reinterpret_cast<const float2 *>(smem_all + TAB_HANNI);
+    const v4f *TW1F4 = reinterpret_cast<const v4f *>(smem_all + TAB_TW1F);
+    const v4f *TW2F4 = reinterpret_cast<const v4f *>(smem_all + TAB_TW2F);
+    const v4f *HW4 = reinterpret_cast<const v4f *>(smem_all + TAB_HANN);
     {
         double2 *t1 = reinterpret_cast<double2 *>(smem_all + TAB_TW1);
         double2 *t2 = reinterpret_cast<double2 *>(smem_all + TAB_TW2);
-        float2 *t1f = reinterpret_cast<float2 *>(smem_all + TAB_TW1F);
-        float2 *t2f = reinterpret_cast<float2 *>(smem_all + TAB_TW2F);
-        float2 *hh = reinterpret_cast<float2 *>(smem_all + TAB_HANN);
-        float2 *hi = reinterpret_cast<float2 *>(smem_all + TAB_HANNI);
-        const float invRt = 1.0f / (float)R;
+        float2 *t1f = reinterpret_cast<float2 *>(smem_all + TAB_TW1F);     // pair-interleaved: [((k >> 1) * 64 + l) * 2 + (k & 1)]
+        float2 *t2f = reinterpret_cast<float2 *>(smem_all + TAB_TW2F);     // [((k >> 1) * 8 + n0) * 2 + (k & 1)]
+        float2 *hh = reinterpret_cast<float2 *>(smem_all + TAB_HANN);      // [((r >> 1) * 64 + l) * 2 + (r & 1)]
         for (int i = threadIdx.x; i < 512; i += 64 * WAVES) {
             const int k = i >> 6, ln = i & 63;
             const double2 w = p.tw64[(2 * ln * k) & (N - 1)];
             t1[i] = w;
-            t1f[i] = float2{(float)w.x, -(float)w.y};
-            hh[i] = float2{0.5f * p.hann[2 * i], 0.5f * p.hann[2 * i + 1]};
-            hi[i] = float2{p.hann[2 * i] * invRt, p.hann[2 * i + 1] * invRt};
+            t1f[2 * ((k >> 1) * 64 + ln) + (k & 1)] = float2{(float)w.x, -(float)w.y};
+            hh[2 * ((k >> 1) * 64 + ln) + (k & 1)] = float2{0.5f * p.hann[2 * i], 0.5f * p.hann[2 * i + 1]};   // n = i = ln + 64 k: row k
             if (i < 64) {
-                const double2 w2 = p.tw64[(16 * (i & 7) * (i >> 3)) & (N - 1)];
+                const int k2 = i >> 3, n0 = i & 7;
+                const double2 w2 = p.tw64[(16 * n0 * k2) & (N - 1)];
                 t2[i] = w2;
-                t2f[i] = float2{(float)w2.x, -(float)w2.y};
+                t2f[2 * ((k2 >> 1) * 8 + n0) + (k2 & 1)] = float2{(float)w2.x, -(float)w2.y};
             }
         }
     }
     __syncthreads();                                                     // the only workgroup-wide barrier
     if (ch >= p.nch) return;
-#ifdef PHAZE_EXP_STAGGER
-    for (int i = 0; i < wv; i++) __builtin_amdgcn_s_sleep(PHAZE_EXP_STAGGER);
-#endif
 
     const unsigned wave_off = TAB_BYTES + wv * WAVE_LDS;
     unsigned char *smem = smem_all + wave_off;
@@ -418,7 +447,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
     unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + OFF_ROUTE);    // aliases MAG once the flags are taken: route of source bin b
     unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + OFF_ROUTE);   // aliases ROUTE once the routes are in registers (f < 1)
     short *DSH = reinterpret_cast<short *>(smem + OFF_PSH);              // shift Math.round(p * f) - p per candidate peak bin p (DROP: peak dropped)
-    unsigned psh_key = 0x7FC12345u;                                      // bit pattern of the f the table was built for (starts invalid)
+    unsigned psh_key = 0u;                                               // bit pattern of the f the table was built for
+    bool psh_valid = false;                                              // ... once one has been built (any bit pattern, NaNs included, is a legal f)
 
     const int first_out = chunk * p.frames_per_chunk;
     int last_out = first_out + p.frames_per_chunk;
@@ -436,7 +466,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
 
     const double2 wl = p.tw64[l];          // split pass: W_1024^{l + 64 r} = wl * W_16^r (W_16^r is wave-uniform)
     const float2 wlf = cconj(p.tw32[l]);
-    const pk::c32 wlfs{wlf.x * (1.0f / (float)N), wlf.y * (1.0f / (float)N)};   // c2r twiddle with the 1/N of the inverse folded in (exact)
+    // c2r scale: the 1/N of the inverse (bundle:110-111) times 2/R -- the 1/R of the overlap-add (ola:149-157) and the factor 2 that turns the
+    // shared 0.5 * Hann table into the synthesis window (pv:67).  All powers of two: every product below is the reference's, bit for bit.
+    constexpr float SC = 2.0f / ((float)N * (float)R);
+    const pk::c32 wlfs{wlf.x * SC, wlf.y * SC};                           // c2r twiddle with the scale folded in (exact)
 
     // ---- carried overlap-add accumulator in registers: row r <-> samples 2l + 128 r (+1) ----
     float2 acc[8];
@@ -463,18 +496,32 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
     };
     float2 raw[8];
     load_rows(raw, 8, 0, first_frame);
+    // Every global access of a frame is issued one frame ahead, in ONE place (after the split pass), and the stores of a frame are
+    // exec-masked straight-line code (emit_v is a per-lane value on purpose): the only vector-memory wait of the loop is then an exact
+    // s_waitcnt vmcnt(#stores) at the top of the next frame.  A load in mid-frame (the pitch row used to be read where it was needed) or a
+    // wave-uniform branch around the stores makes the compiler wait with vmcnt(0) -- for the prefetch it has just issued and for the
+    // acknowledgement of the stores -- and every frame of every wave then sits out two exposed HBM round trips.
+    float pf_next = pitch_row[first_frame];
+    int emit_v = first_out;
+    asm volatile("" : "+v"(emit_v));                                     // opaque VGPR copy of first_out: keeps the store predicate divergent
+    // 0.5 * Hann rows of this lane: read at the END of a frame (4 ds_read_b128) for the synthesis window and kept across the loop edge for
+    // the analysis window of the next frame -- one table read per frame instead of two
+    pk::c32 hw[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const v4f h = HW4[j * 64 + l]; hw[2 * j] = pk::c32{h.x, h.y}; hw[2 * j + 1] = pk::c32{h.z, h.w}; }
 
     for (int m = first_frame; m < last_out; ++m) {
-        const double pf = (double)pitch_row[m];
+        const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));   // k-rate pitchFactor (pv:47), wave-uniform
+        const double pf = (double)pfm;
         const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
         const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
 
         // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded into the table (exact) ----
         double2 z[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { const float2 hwr = (ablate & 256) ? float2{0.25f, 0.25f} : HW[l + 64 * r]; const v2f xw = v2f{raw[r].x, raw[r].y} * v2f{hwr.x, hwr.y}; z[r] = double2{(double)xw.x, (double)xw.y}; }
+        for (int r = 0; r < 8; r++) { const v2f xw = v2f{raw[r].x, raw[r].y} * hw[r]; z[r] = double2{(double)xw.x, (double)xw.y}; }
 
-        if (!(ablate & 1)) fft512_wave<double, false>(z, S64, TW1, TW2, l);
+        fft512_wave<double, false>(z, S64, TW1, TW2, l);
 
         // ---- split pass in conjugate pairs: with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved),
         //      X[k] = E - j W^k O and X[512-k] = conj(E + j W^k O).  Lane l owns the pairs k = l + 64 r, r < 4 (partner value from lane
@@ -485,17 +532,13 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
             // partner values through the (now free) transpose scratch: rows 4..7 written lane-contiguous, read back reversed.  Element
             // 512 - k of the pair k = l + 64 r sits at (3 - r) * 64 + (64 - l) for every lane (lane 0: 64 (8 - r), its own register
             // 8 - r); half the LDS cycles of sixteen bpermutes.  (l = 0, r = 0) reads one element past the rows: replaced below.
-            if (!(ablate & 2)) {
 #pragma unroll
-                for (int r = 4; r < 8; r++) S64[(r - 4) * 64 + l] = z[r];
-                wave_sync();
-            }
+            for (int r = 4; r < 8; r++) S64[(r - 4) * 64 + l] = z[r];
+            wave_sync();
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 double2 xa, xb;
-                if (ablate & 2) {
-                    xa = z[r]; xb = z[7 - r];
-                } else {
+                {
                     const double2 zm = S64[(3 - r) * 64 + 64 - l];
                     const double2 E{z[r].x + zm.x, z[r].y - zm.y};
                     const double2 O{z[r].x - zm.x, z[r].y + zm.y};
@@ -509,10 +552,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
                     }
                 }
                 // ---- |X|^2 -> f32 (pv:82-92), exchanged through LDS for the neighbour tests ----
-                if (!(ablate & 512)) {
-                    MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
-                    MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
-                }
+                MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
                 XA[r] = float2{(float)xa.x, (float)xa.y};
                 XB[r] = float2{(float)xb.x, (float)xb.y};
                 if (dbg) {
@@ -531,51 +572,52 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
         // slide the window: the rows the next frame adds are issued here and land behind the shift + inverse FFT
 #pragma unroll
         for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
-        if (m + 1 < last_out) load_rows(&raw[8 - S_ROWS], S_ROWS, 8 - S_ROWS, m + 1);
+        {
+            const int mn = (m + 1 < last_out) ? m + 1 : m;                 // the last frame of a chain re-reads its own rows (unused): no branch
+            load_rows(&raw[8 - S_ROWS], S_ROWS, 8 - S_ROWS, mn);
+            pf_next = pitch_row[mn];
+        }
         // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change ----
         {
-            const unsigned pfb = __float_as_uint(pitch_row[m]);
-            if (pfb != psh_key) { psh_key = pfb; build_shift_table_1024(pitch_row[m], wave_off, l); }
+            const unsigned pfb = __float_as_uint(pfm);
+            if (!psh_valid || pfb != psh_key) { psh_key = pfb; psh_valid = true; build_shift_table_1024(pfm, wave_off, l); }
         }
         wave_sync();
         // ---- peak flags (pv:95-116) for bins 8l..8l+7, nearest peaks by wave scans, then one ROUTE word per source bin ----
         int last_peak = -1, last_shift = 0;
-        if (ablate & 4) {
-            wave_sync();
-            if (!(ablate & 2048)) {
-                *reinterpret_cast<uint4 *>(&ROUTE[8 * l]) = uint4{8u * l, 8u * l + 1, 8u * l + 2, 8u * l + 3};
-                *reinterpret_cast<uint4 *>(&ROUTE[8 * l + 4]) = uint4{8u * l + 4, 8u * l + 5, 8u * l + 6, 8u * l + 7};
-                if (l == 63) ROUTE[512] = 512u;
-            }
-        } else {
-            float mg[12];
-            // volatile vector loads: otherwise the optimizer re-pairs the 12 floats into five misaligned ds_read2_b32 (8 LDS cycles each)
-            typedef const volatile __attribute__((address_space(3))) v2f *lds_v2f;
-            typedef const volatile __attribute__((address_space(3))) v4f *lds_v4f;
-            const v2f q0 = *(lds_v2f)(&MAG[4 + 8 * l - 2]);
-            const v4f q1 = *(lds_v4f)(&MAG[4 + 8 * l]);
-            const v4f q2 = *(lds_v4f)(&MAG[4 + 8 * l + 4]);
-            const v2f q3 = *(lds_v2f)(&MAG[4 + 8 * l + 8]);
+        {
+            // |X|^2 >= 0, so the fp32 order of two magnitudes is the order of their bit patterns as unsigned integers: the strict test
+            // "greater than all four neighbours" (pv:100-110, `>=` rejects) becomes c > max(neighbours) with v_max3_u32 -- two instructions per
+            // bin plus eight shared pair maxima, instead of four compares and three mask ANDs.
+            unsigned mg[12];
+            // volatile vector loads: otherwise the optimizer re-pairs the 12 words into five misaligned ds_read2_b32 (8 LDS cycles each)
+            typedef const volatile __attribute__((address_space(3))) v2u *lds_v2u;
+            typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
+            const v2u q0 = *(lds_v2u)(&MAG[4 + 8 * l - 2]);
+            const v4u q1 = *(lds_v4u)(&MAG[4 + 8 * l]);
+            const v4u q2 = *(lds_v4u)(&MAG[4 + 8 * l + 4]);
+            const v2u q3 = *(lds_v2u)(&MAG[4 + 8 * l + 8]);
             mg[0] = q0.x; mg[1] = q0.y; mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w;
             mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w; mg[10] = q3.x; mg[11] = q3.y;
-            // flags as lane masks; the nearest own peak at or below / above each of the 8 bins by two select chains
+            unsigned pm[11];
+#pragma unroll
+            for (int j = 3; j < 11; j++) pm[j] = max(mg[j], mg[j + 1]);
             bool fl[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const int k = 8 * l + i;
-                const float c = mg[i + 2];
-                fl[i] = (k >= 2) & (k < H - 2) & (mg[i + 1] < c) & (mg[i] < c) & (mg[i + 3] < c) & (mg[i + 4] < c);      // & not &&: no branches
+                // bin k = 8l + i, candidates are 2 <= k < H - 2 = 511 (pv:97-100): lane 0 drops i < 2, lane 63 drops i = 7
+                const bool in_range = (i < 2) ? (l != 0) : (i == 7) ? (l != 63) : true;
+                fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
             }
             if (dbg) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) { p.dbg_flags[8 * l + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * l + i] = mg[i + 2]; }
-                if (l == 63) { p.dbg_flags[512] = 0; p.dbg_mag[512] = mg[10]; }
+                for (int i = 0; i < 8; i++) { p.dbg_flags[8 * l + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * l + i] = __uint_as_float(mg[i + 2]); }
+                if (l == 63) { p.dbg_flags[512] = 0; p.dbg_mag[512] = __uint_as_float(mg[10]); }
             }
             // Every candidate peak travels as one packed word (bin << 16 | shift & 0xFFFF): the shifts of the lane's own 8 bins come from ONE
             // 16-byte read of the shift table (a per-bin DSH[owner] lookup is a 4-way bank conflict by construction: lanes l and l + 16 sit
             // 256 bytes apart), and the neighbour lanes' peaks bring their shift along in the same bpermute.  Packed words order like bins.
             constexpr int NEGPD = -(2048 << 16), POSPD = 4096 << 16;        // "no peak on this side"
-            typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
             const v4u dq = *(lds_v4u)(&DSH[8 * l]);
             int pd[8];
 #pragma unroll
@@ -630,17 +672,17 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
         }
         int upper_end = H;
         if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
-        // ---- zero Y (pv:121); the transposes of the forward FFT are done with the scratch ----
-        if (!(ablate & 8))
+        // ---- zero Y (pv:121); the transposes of the forward FFT are done with the scratch.  16 bytes per lane and store: four
+        //      ds_write_b128 (+ bin 512) instead of eight ds_write_b64 ----
 #pragma unroll
-        for (int r = 0; r < 8; r++) Y[l + 64 * r] = float2{0.f, 0.f};
+        for (int r = 0; r < 4; r++) *reinterpret_cast<v4f *>(&Y[2 * l + 128 * r]) = v4f{0.f, 0.f, 0.f, 0.f};
         if (l == 0) Y[512] = float2{0.f, 0.f};
         // ---- residue above Nyquist only when the last region reads it ----
         wave_sync();
         // ---- shiftPeaks (pv:119-173): each lane moves its own source bins (registers) along the precomputed routes ----
         {
             // For f >= 1, delta_i = round(p_i f) - p_i is non-decreasing in i, so the shifted regions stay disjoint: plain stores.
-            const bool disjoint = (pf >= 1.0) || (ablate & 64);
+            const bool disjoint = (pf >= 1.0);
             if (disjoint) {
                 // every rotation of this frame is exp(2 pi j delta (m mod R) / R) and m mod R is wave-uniform: a frame with m = 0 (mod R) moves its
                 // bins unrotated, m = R/2 (mod R) only flips signs (bit 9 of the rotation index = bit 25 of the route)
@@ -654,7 +696,6 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
                         }
                         return rotate_route<R, 10>(rt, v, p.tw32);
                     };
-                    if (!(ablate & 8))
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const unsigned ra = ROUTE[l + 64 * r], ta = ra & 0xFFFFu;
@@ -669,8 +710,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
                 else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
                 else scatter(std::integral_constant<int, 1>{});
             } else {
-                const int ue = (ablate & 32) ? H : upper_end;
-                scatter_colliding_1024<R>(Spectrum9{{XA[0], XA[1], XA[2], XA[3]}, {XB[0], XB[1], XB[2], XB[3]}, x256f}, wave_off, l, tmod, last_peak, ue,
+                scatter_colliding_1024<R>(Spectrum9{{XA[0], XA[1], XA[2], XA[3]}, {XB[0], XB[1], XB[2], XB[3]}, x256f}, wave_off, l, tmod, last_peak, upper_end,
                                           src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, dbg ? p.dbg_X : nullptr);
             }
         }
@@ -680,16 +720,13 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
             for (int r = 0; r < 8; r++) { const int k = l + 64 * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
             if (l == 0) { p.dbg_Y[1024] = Y[512].x; p.dbg_Y[1025] = Y[512].y; }
         }
-        // ---- c2r pre-pass (bundle:69-76,102-114 folded): Z[k] = ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)) / N, packed fp32 ----
+        // ---- c2r pre-pass (bundle:69-76,102-114 folded): Z[k] = SC ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)), packed fp32 ----
         pk::c32 zi[8];
         {
-            const float sc = 1.0f / (float)N;
+            const float sc = SC;
             const pk::c32 scsc{sc, sc};
             const pk::c32 *Yc = reinterpret_cast<const pk::c32 *>(Y);
-            if (ablate & 8) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) zi[r] = pk::c32{XA[r & 3].x * sc, XB[r & 3].y * sc};
-            } else {
+            {
                 // conjugate pairs again: with E = Yk + conj(Ym), O = Yk - conj(Ym), c = e^{+2 pi j k/N} O / N (m = 512 - k):
                 // Z[k] = E / N + j c and Z[m] = conj(E / N - j c); lane l computes k = l + 64 r, r < 4, and hands Z[m] to lane 64-l, register 7-r
                 pk::c32 zb[4];
@@ -717,13 +754,15 @@ __global__ __launch_bounds__(64 * WAVES, 3) PV_NO_DS_MERGE void pv_wave_kernel_1
             }
         }
         wave_sync();
-        if (!(ablate & 16)) fft512_wave_inv_pk(zi, reinterpret_cast<pk::c32 *>(S32), reinterpret_cast<const pk::c32 *>(TW1F), reinterpret_cast<const pk::c32 *>(TW2F), l);
+        fft512_wave_inv_pk(zi, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l);
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         {
-            const bool emit_out = (m >= first_out);
+            const bool emit_out = (m >= emit_v);
             float2 fr[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) { const float2 hwr = (ablate & 1024) ? float2{0.25f, 0.25f} : HWI[l + 64 * r]; fr[r] = float2{zi[r].x * hwr.x, zi[r].y * hwr.y}; }
+            for (int j = 0; j < 4; j++) { const v4f h = HW4[j * 64 + l]; hw[2 * j] = pk::c32{h.x, h.y}; hw[2 * j + 1] = pk::c32{h.z, h.w}; }   // stays live for the next frame
+#pragma unroll
+            for (int r = 0; r < 8; r++) { const pk::c32 f = zi[r] * hw[r]; fr[r] = float2{f.x, f.y}; }
 #pragma unroll
             for (int r = 0; r < S_ROWS; r++) {
                 const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
@@ -777,7 +816,10 @@ hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_
 
 }  // namespace
 
-size_t pv_wave_lds_bytes() { return TAB_BYTES + WAVES * WAVE_LDS; }
+#ifndef PV_LDS_PAD
+#define PV_LDS_PAD 0        // occupancy experiments only: extra bytes that keep a second workgroup off the CU
+#endif
+size_t pv_wave_lds_bytes() { return TAB_BYTES + WAVES * WAVE_LDS + PV_LDS_PAD; }
 
 int pv_wave_threads() { return 64 * WAVES; }
 
@@ -785,7 +827,7 @@ bool pv_wave_supported(int log2n, int hop) { return log2n == 10 && (hop == 128 |
 
 hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
-    const bool aux = (p.ablate != 0) || (p.dbg_mag != nullptr);
+    const bool aux = (p.dbg_mag != nullptr);
     switch (p.hop) {
     case 128: return aux ? launch_wave<1, true>(p, nch, nchunks, st) : launch_wave<1, false>(p, nch, nchunks, st);
     case 256: return aux ? launch_wave<2, true>(p, nch, nchunks, st) : launch_wave<2, false>(p, nch, nchunks, st);

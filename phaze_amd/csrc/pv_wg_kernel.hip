@@ -349,8 +349,6 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     constexpr int DROP = 0x4000;                                        // shift sentinel: b + DROP >= H for every bin, above every real shift
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int ch = blockIdx.y, chunk = blockIdx.x;
-    const int ablate = AUX ? p.ablate : 0;
-    (void)ablate;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2 *S64 = reinterpret_cast<double2 *>(smem);
@@ -392,7 +390,8 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     float *ACC = reinterpret_cast<float *>(smem + C::OFF_ACC);          // RING only
     const int Lr = N - HOP;
     int ring = 0;
-    unsigned psh_key = 0x7FC12345u;
+    unsigned psh_key = 0u;                                 // bit pattern of the f the shift table was built for, valid once psh_valid
+    bool psh_valid = false;
 
     const double2 wl = p.tw64[t];                          // split pass: W_N^{t + T r} = wl * W_16^r  (N = 16 T)
     const float2 wlf = cconj(p.tw32[t]);
@@ -424,10 +423,16 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     };
     float2 raw[8];
     load_rows(raw, 8, 0, first_frame);
+    // all global accesses of a frame are issued one frame ahead in one place, and the stores are exec-masked straight-line code (emit_v is a
+    // per-lane value on purpose): no s_waitcnt vmcnt(0) behind a just-issued load or store (see pv_wave_kernel.hip)
+    float pf_next = pitch_row[first_frame];
+    int emit_v = first_out;
+    asm volatile("" : "+v"(emit_v));
     __syncthreads();
 
     for (int m = first_frame; m < last_out; ++m) {
-        const double pf = (double)pitch_row[m];
+        const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));   // k-rate pitchFactor (pv:47), uniform
+        const double pf = (double)pfm;
         const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
         const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
 
@@ -486,18 +491,23 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             }
         }
         // slide the raw window; the rows the next frame adds are issued here
-        if (RING) {
-            if (m + 1 < last_out) load_rows(raw, 8, 0, m + 1);
-        } else {
+        {
+            const int mn = (m + 1 < last_out) ? m + 1 : m;                 // the last frame re-reads its own rows (unused): no branch
+            if (RING) {
+                load_rows(raw, 8, 0, mn);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
-            if (m + 1 < last_out) load_rows(&raw[8 - (RING ? 8 : S_ROWS)], S_ROWS, 8 - S_ROWS, m + 1);
+                for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
+                load_rows(&raw[8 - (RING ? 8 : S_ROWS)], S_ROWS, 8 - S_ROWS, mn);
+            }
+            pf_next = pitch_row[mn];
         }
         // ---- shift table Math.round(peak * f) - peak (pv:125,147), rebuilt only when f changes ----
         {
-            const unsigned pfb = __float_as_uint(pitch_row[m]);
-            if (pfb != psh_key) {
+            const unsigned pfb = __float_as_uint(pfm);
+            if (!psh_valid || pfb != psh_key) {
                 psh_key = pfb;
+                psh_valid = true;
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const int pk = t + T * r;
@@ -728,7 +738,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         fft_wg_inv_pk<G, RING>(zi, reinterpret_cast<pk::c32 *>(S32), TWA, TWB, TWC, t);
         // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
         {
-            const bool emit_out = (m >= first_out);
+            const bool emit_out = (m >= emit_v);
             float2 fr[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) fr[r] = float2{zi[r].x * (hw[r].x * invR), zi[r].y * (hw[r].y * invR)};
@@ -822,7 +832,7 @@ template <int LOG2N>
 hipError_t launch_wg_n(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
     const int N = 1 << LOG2N;
-    const bool aux = (p.ablate != 0) || (p.dbg_mag != nullptr);
+    const bool aux = (p.dbg_mag != nullptr);
     const int rows = (8 * p.hop % N == 0) ? 8 * p.hop / N : 0;
     switch (rows) {
     case 0: return aux ? launch_wg<LOG2N, 0, true>(p, nch, nchunks, st) : launch_wg<LOG2N, 0, false>(p, nch, nchunks, st);

@@ -19,6 +19,12 @@
 
 #define MAX_CH 64
 
+/* what a JS "handle" external points to: the C handle plus the constants process() needs per quantum (no pv_get_info on the hot call) */
+typedef struct pv_slot {
+    pv_handle *h;
+    int32_t hop;
+} pv_slot;
+
 #define NAPI_OK_OR_THROW(env, call, msg)                         \
     do {                                                         \
         if ((call) != napi_ok) {                                 \
@@ -40,9 +46,9 @@ static napi_value throw_status(napi_env env, pv_handle *h, int rc)
 static void finalize_handle(napi_env env, void *data, void *hint)
 {
     (void)env; (void)hint;
-    pv_handle **slot = (pv_handle **)data;
+    pv_slot *slot = (pv_slot *)data;
     if (slot) {
-        if (*slot) pv_destroy(*slot);
+        if (slot->h) pv_destroy(slot->h);
         free(slot);
     }
 }
@@ -60,22 +66,22 @@ static int get_i32_prop(napi_env env, napi_value obj, const char *name, int32_t 
     return out;
 }
 
-static pv_handle **unwrap(napi_env env, napi_value v)
+static pv_slot *unwrap(napi_env env, napi_value v)
 {
     void *p = NULL;
     if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
         napi_throw_type_error(env, NULL, "expected a phaze handle");
         return NULL;
     }
-    pv_handle **slot = (pv_handle **)p;
-    if (!*slot) {
+    pv_slot *slot = (pv_slot *)p;
+    if (!slot->h) {
         napi_throw_error(env, "PV_6", pv_status_string(PV_ERR_DESTROYED));
         return NULL;
     }
     return slot;
 }
 
-/* create({fftSize, hopSize, maxChannels, maxHops, deviceId, framesPerChunk}) -> external */
+/* create({fftSize, hopSize, maxChannels, maxHops, deviceId, framesPerChunk, flags}) -> external */
 static napi_value js_create(napi_env env, napi_callback_info info)
 {
     size_t argc = 1;
@@ -90,11 +96,13 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     cfg.max_hops = get_i32_prop(env, argv[0], "maxHops", 1);
     cfg.device_id = get_i32_prop(env, argv[0], "deviceId", 0);
     cfg.frames_per_chunk = get_i32_prop(env, argv[0], "framesPerChunk", 0);
+    cfg.flags = get_i32_prop(env, argv[0], "flags", 0);                  /* PV_FLAG_* (tests / measurements only) */
     pv_handle *h = NULL;
     const int rc = pv_create(&cfg, &h);
     if (rc != PV_OK) return throw_status(env, NULL, rc);
-    pv_handle **slot = (pv_handle **)malloc(sizeof(pv_handle *));
-    *slot = h;
+    pv_slot *slot = (pv_slot *)malloc(sizeof(pv_slot));
+    slot->h = h;
+    slot->hop = cfg.hop_size;
     napi_value ext;
     NAPI_OK_OR_THROW(env, napi_create_external(env, slot, finalize_handle, NULL, &ext), "napi_create_external failed");
     return ext;
@@ -107,8 +115,8 @@ static napi_value js_destroy(napi_env env, napi_callback_info info)
     NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
     void *p = NULL;
     if (argc >= 1 && napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
-        pv_handle **slot = (pv_handle **)p;
-        if (*slot) { pv_destroy(*slot); *slot = NULL; }
+        pv_slot *slot = (pv_slot *)p;
+        if (slot->h) { pv_destroy(slot->h); slot->h = NULL; }
     }
     return NULL;
 }
@@ -143,7 +151,7 @@ static napi_value js_process(napi_env env, napi_callback_info info)
     napi_value argv[4];
     NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
     if (argc < 4) { napi_throw_type_error(env, NULL, "process(handle, inputs, outputs, pitchFactor)"); return NULL; }
-    pv_handle **slot = unwrap(env, argv[0]);
+    pv_slot *slot = unwrap(env, argv[0]);
     if (!slot) return NULL;
     float *in[MAX_CH], *out[MAX_CH];
     size_t inlen[MAX_CH], outlen[MAX_CH];
@@ -152,9 +160,7 @@ static napi_value js_process(napi_env env, napi_callback_info info)
     if (nin < 0 || nout < 0) { napi_throw_type_error(env, NULL, "inputs/outputs must be arrays of Float32Array (<= 64 channels)"); return NULL; }
     double pf = 1.0;
     napi_get_value_double(env, argv[3], &pf);
-    pv_info inf;
-    pv_get_info(*slot, &inf);
-    const int hop = inf.hop_size;
+    const int hop = slot->hop;
     /* paused: inputs[0][0].length == 0 (ola-processor.js:93) */
     int nsamples = hop;
     if (nin > 0 && inlen[0] == 0) nsamples = 0;
@@ -163,8 +169,8 @@ static napi_value js_process(napi_env env, napi_callback_info info)
         if (nsamples && inlen[c] != (size_t)hop) { napi_throw_range_error(env, NULL, "input block length must equal hopSize"); return NULL; }
         outp[c] = (c < nout && outlen[c] >= (size_t)hop) ? out[c] : NULL;   /* "output is symetric to input" (phase-vocoder.js:51) */
     }
-    const int rc = pv_process(*slot, (const float *const *)in, outp, nin, nsamples, (float)pf);
-    if (rc != PV_OK) return throw_status(env, *slot, rc);
+    const int rc = pv_process(slot->h, (const float *const *)in, outp, nin, nsamples, (float)pf);
+    if (rc != PV_OK) return throw_status(env, slot->h, rc);
     napi_value t;
     napi_get_boolean(env, true, &t);
     return t;                                                               /* ola-processor.js:170 */
@@ -177,7 +183,7 @@ static napi_value js_process_batch(napi_env env, napi_callback_info info)
     napi_value argv[8];
     NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
     if (argc < 6) { napi_throw_type_error(env, NULL, "processBatch(handle, in, out, nch, nhops, pitch[, pitchStride, channelsPerStream])"); return NULL; }
-    pv_handle **slot = unwrap(env, argv[0]);
+    pv_slot *slot = unwrap(env, argv[0]);
     if (!slot) return NULL;
     napi_typedarray_type ty;
     size_t nin = 0, nout = 0, npitch = 0, off;
@@ -194,16 +200,14 @@ static napi_value js_process_batch(napi_env env, napi_callback_info info)
     napi_get_value_int32(env, argv[4], &nhops);
     if (argc > 6) napi_get_value_int32(env, argv[6], &pstride);
     if (argc > 7) napi_get_value_int32(env, argv[7], &cps);
-    pv_info inf;
-    pv_get_info(*slot, &inf);
-    const size_t need = (size_t)nch * (size_t)nhops * (size_t)inf.hop_size;
+    const size_t need = (size_t)nch * (size_t)nhops * (size_t)slot->hop;
     const size_t rows = pstride ? (size_t)((nch + (cps > 0 ? cps : 1) - 1) / (cps > 0 ? cps : 1)) : 1;
     if (nch <= 0 || nhops <= 0 || nin < need || nout < need || npitch < (pstride ? (rows - 1) * (size_t)pstride + (size_t)nhops : (size_t)nhops)) {
         napi_throw_range_error(env, NULL, "buffer sizes do not match nch*nhops*hopSize");
         return NULL;
     }
-    const int rc = pv_process_batch(*slot, (const float *)din, (float *)dout, nch, nhops, (int64_t)nhops * inf.hop_size, (const float *)dp, pstride, cps);
-    if (rc != PV_OK) return throw_status(env, *slot, rc);
+    const int rc = pv_process_batch(slot->h, (const float *)din, (float *)dout, nch, nhops, (int64_t)nhops * slot->hop, (const float *)dp, pstride, cps);
+    if (rc != PV_OK) return throw_status(env, slot->h, rc);
     napi_value t;
     napi_get_boolean(env, true, &t);
     return t;
@@ -214,18 +218,18 @@ static napi_value js_reset(napi_env env, napi_callback_info info)
     size_t argc = 3;
     napi_value argv[3];
     NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
-    pv_handle **slot = unwrap(env, argv[0]);
+    pv_slot *slot = unwrap(env, argv[0]);
     if (!slot) return NULL;
     int rc;
     if (argc >= 3) {
         int32_t first = 0, count = 0;
         napi_get_value_int32(env, argv[1], &first);
         napi_get_value_int32(env, argv[2], &count);
-        rc = pv_reset_channels(*slot, first, count);     /* ola-processor.js:54-88 */
+        rc = pv_reset_channels(slot->h, first, count);     /* ola-processor.js:54-88 */
     } else {
-        rc = pv_reset(*slot);
+        rc = pv_reset(slot->h);
     }
-    if (rc != PV_OK) return throw_status(env, *slot, rc);
+    if (rc != PV_OK) return throw_status(env, slot->h, rc);
     return NULL;
 }
 
@@ -234,16 +238,16 @@ static napi_value js_time_cursor(napi_env env, napi_callback_info info)
     size_t argc = 2;
     napi_value argv[2];
     NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
-    pv_handle **slot = unwrap(env, argv[0]);
+    pv_slot *slot = unwrap(env, argv[0]);
     if (!slot) return NULL;
     if (argc >= 2) {
         int64_t v = 0;
         napi_get_value_int64(env, argv[1], &v);
-        const int rc = pv_set_time_cursor(*slot, v);
-        if (rc != PV_OK) return throw_status(env, *slot, rc);
+        const int rc = pv_set_time_cursor(slot->h, v);
+        if (rc != PV_OK) return throw_status(env, slot->h, rc);
     }
     int64_t t = 0;
-    pv_get_time_cursor(*slot, &t);
+    pv_get_time_cursor(slot->h, &t);
     napi_value out;
     napi_create_int64(env, t, &out);
     return out;
@@ -254,10 +258,10 @@ static napi_value js_info(napi_env env, napi_callback_info info)
     size_t argc = 1;
     napi_value argv[1];
     NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
-    pv_handle **slot = unwrap(env, argv[0]);
+    pv_slot *slot = unwrap(env, argv[0]);
     if (!slot) return NULL;
     pv_info inf;
-    pv_get_info(*slot, &inf);
+    pv_get_info(slot->h, &inf);
     napi_value o, v;
     napi_create_object(env, &o);
 #define SETI(name, val) do { napi_create_int32(env, (val), &v); napi_set_named_property(env, o, name, v); } while (0)

@@ -46,12 +46,12 @@ def test_errors_without_device():
     from phaze_amd import capi
     L = _lib()
     h = C.c_void_p()
-    cfg = capi._Config(1000, 250, 1, 1, 0, 0)
+    cfg = capi._Config(1000, 250, 1, 1, 0, 0, 0)
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_FFT_SIZE
     assert L.pv_last_error(None).decode() == "FFT size must be a power of two and bigger than 1"     # bundle:6-7
-    cfg = capi._Config(1024, 300, 1, 1, 0, 0)
+    cfg = capi._Config(1024, 300, 1, 1, 0, 0, 0)
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_ARGUMENT
-    cfg = capi._Config(16384, 4096, 1, 1, 0, 0)
+    cfg = capi._Config(16384, 4096, 1, 1, 0, 0, 0)
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_UNSUPPORTED
     assert L.pv_status_string(capi.PV_ERR_DEVICE).decode() == "HIP device error"
     try:
@@ -60,7 +60,7 @@ def test_errors_without_device():
     except Exception:
         has_gpu = False
     if not has_gpu:
-        cfg = capi._Config(1024, 256, 1, 1, 0, 0)
+        cfg = capi._Config(1024, 256, 1, 1, 0, 0, 0)
         assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_DEVICE                           # fails loudly: no CPU fallback
         with pytest.raises(phaze_amd.PvError):
             phaze_amd.PhaseVocoder(fft_size=1024, hop_size=256)
@@ -72,3 +72,19 @@ def test_product_sources_do_not_reference_the_oracle():
             if f.endswith((".hip", ".h", ".c", ".py", ".js")):
                 txt = open(os.path.join(base, f), errors="ignore").read()
                 assert "pv_oracle" not in txt and "oracle_lib" not in txt and "libpv_oracle" not in txt, os.path.join(base, f)
+
+
+def test_no_environment_switches_in_the_product_library():
+    """Round-1 builds read PHAZE_ABLATE / PHAZE_GENERIC_KERNEL / PHAZE_STREAM_COPY from the environment; a stray variable could select a
+    work-skipping kernel instance.  The shipped library contains no ablation code and never calls getenv: A/B switches are explicit
+    pv_config.flags bits."""
+    lib = os.path.join(ROOT, "phaze_amd", "lib", "libphaze_amd.so")
+    _lib()
+    strings = subprocess.run(["strings", "-a", lib], capture_output=True, text=True).stdout
+    assert "PHAZE_" not in strings
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
+    assert "getenv" not in undefined
+    for base, _, files in os.walk(os.path.join(ROOT, "phaze_amd", "csrc")):
+        for f in files:
+            txt = open(os.path.join(base, f), errors="ignore").read()
+            assert "getenv" not in txt and "ablate" not in txt, f

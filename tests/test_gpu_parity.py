@@ -201,17 +201,16 @@ def test_errors_match_reference_behaviour():
 
 
 @pytest.mark.parametrize("fft,hop", [(1024, 256), (2048, 512), (4096, 1024), (8192, 2048)])
-def test_generic_kernel_fallback_parity(fft, hop, monkeypatch):
+def test_generic_kernel_fallback_parity(fft, hop):
     """The LDS-staged generic kernel stays the fallback for the shapes the register-resident kernels cover; keep it honest.
-    PHAZE_GENERIC_KERNEL=1 (read at pv_create) forces it; the two kernels must agree with the oracle and with each other."""
+    pv_config.flags = PV_FLAG_GENERIC_KERNEL forces it; the two kernels must agree with the oracle and with each other."""
     T = 20
     x = np.stack([S.make_signal("tonal", c, T * hop, stream=1) for c in range(2)])
     p = (0.6 + 1.2 * np.arange(T) / (T - 1)).astype(np.float32)
     yo = oracle_lib.Oracle(fft, hop, 2).process_planar(x, p)
     outs = {}
     for forced in ("0", "1"):
-        monkeypatch.setenv("PHAZE_GENERIC_KERNEL", forced)
-        pv = _pv(fft_size=fft, hop_size=hop, max_channels=2, max_hops=T)
+        pv = _pv(fft_size=fft, hop_size=hop, max_channels=2, max_hops=T, flags=1 if forced == "1" else 0)     # PV_FLAG_GENERIC_KERNEL
         outs[forced] = pv.process_batch(x, p)
         name = pv.info()["kernel_name"]
         pv.close()
