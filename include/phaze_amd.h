@@ -97,6 +97,17 @@ PV_API int pv_reset_channels(pv_handle *h, int32_t first, int32_t count);
 PV_API int pv_get_time_cursor(const pv_handle *h, int64_t *out);
 PV_API int pv_set_time_cursor(pv_handle *h, int64_t value);
 
+/* State export / import of ONE channel slot: everything the reference keeps between process() calls for a channel --
+ * hist[N - hop] = the newest N - hop input samples (inputBuffers, ola-processor.js:59,121-127), acc[N - hop] = the pending
+ * overlap-add sums (outputBuffers, ola-processor.js:77,130-137) -- plus the processor-wide timeCursor (phase-vocoder.js:31).
+ * Checkpoint / resume, moving a stream to another handle or GPU, and splitting ONE stream along the time axis all reduce to
+ * this: a handle that imports the state another one exported continues bit for bit.  (Time-sharding needs no hand-over at all:
+ * hist is plain input, and the accumulator only depends on the last R - 1 frames, so a span can import {input tail, acc = 0,
+ * cursor} R - 1 hops early and recompute its halo; see bench.py --time-shard.)  Synchronous.  hist / acc may be NULL (skipped);
+ * pv_import_state sets the handle's timeCursor when time_cursor >= 0 (multiple of hop_size) and leaves it when negative. */
+PV_API int pv_export_state(pv_handle *h, int32_t ch, float *hist, float *acc, int64_t *time_cursor);
+PV_API int pv_import_state(pv_handle *h, int32_t ch, const float *hist, const float *acc, int64_t time_cursor);
+
 /* ---- the hot call, streaming form (one render quantum) ------------------------------------------- */
 /* Replaces OLAProcessor.process(inputs, outputs, parameters) (ola-processor.js:159-171) for ONE input /
  * ONE output with nch channels:  in[c] -> nsamples (== hop_size) host floats, valid only during the call;

@@ -20,7 +20,7 @@ PV_OK, PV_ERR_FFT_SIZE, PV_ERR_ARGUMENT, PV_ERR_UNSUPPORTED, PV_ERR_CAPACITY, PV
 EXPORTS = [
     "pv_create", "pv_destroy", "pv_last_error", "pv_status_string", "pv_get_info", "pv_reset", "pv_reset_channels",
     "pv_get_time_cursor", "pv_set_time_cursor", "pv_process", "pv_process_batch", "pv_process_batch_device",
-    "pv_set_stream", "pv_synchronize", "pv_debug_frame",
+    "pv_set_stream", "pv_synchronize", "pv_debug_frame", "pv_export_state", "pv_import_state",
 ]
 
 
@@ -93,6 +93,8 @@ def load_library():
     L.pv_set_stream.argtypes = [vp, vp]
     L.pv_synchronize.argtypes = [vp]
     L.pv_debug_frame.argtypes = [vp, C.c_int32, fp, C.c_float, C.POINTER(C.c_double), fp, C.POINTER(C.c_int32), fp]
+    L.pv_export_state.argtypes = [vp, C.c_int32, fp, fp, C.POINTER(C.c_int64)]
+    L.pv_import_state.argtypes = [vp, C.c_int32, fp, fp, C.c_int64]
     for n in EXPORTS:
         if n not in ("pv_last_error", "pv_status_string"):
             getattr(L, n).restype = C.c_int
@@ -155,6 +157,26 @@ class PhaseVocoder:
     @time_cursor.setter
     def time_cursor(self, value):
         self._check(self._L.pv_set_time_cursor(self._h, int(value)))
+
+    def export_state(self, ch):
+        """(hist[N-hop], acc[N-hop], time_cursor) of channel slot `ch`: ola-processor.js:59,77 + phase-vocoder.js:31."""
+        L = self.fft_size - self.hop_size
+        hist, acc, tc = np.zeros(max(L, 1), np.float32), np.zeros(max(L, 1), np.float32), C.c_int64()
+        self._check(self._L.pv_export_state(self._h, ch, _fp(hist), _fp(acc), C.byref(tc)))
+        return hist[:L], acc[:L], tc.value
+
+    def import_state(self, ch, hist=None, acc=None, time_cursor=-1):
+        L = self.fft_size - self.hop_size
+        def chk(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.size != L:
+                raise ValueError(f"state arrays hold N - hop = {L} floats")
+            return a
+        hist, acc = chk(hist), chk(acc)
+        self._check(self._L.pv_import_state(self._h, ch, _fp(hist) if hist is not None and L else None,
+                                            _fp(acc) if acc is not None and L else None, C.c_int64(int(time_cursor))))
 
     def info(self):
         i = _Info()

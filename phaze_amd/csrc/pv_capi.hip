@@ -171,8 +171,12 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     while ((1 << log2n) < N) log2n++;
     if (log2n < 6 || log2n > 13) return fail(nullptr, PV_ERR_UNSUPPORTED, "fft_size must be within 64..8192 for the gfx950 kernels");
     if (hop < 2) return fail(nullptr, PV_ERR_UNSUPPORTED, "hop_size must be >= 2");
-    if (pv_kernel_lds_bytes(log2n, hop) > 160 * 1024)
-        return fail(nullptr, PV_ERR_UNSUPPORTED, "fft_size/hop_size combination exceeds the 160 KiB LDS of a CU");
+    {
+        const bool generic = (cfg->flags & PV_FLAG_GENERIC_KERNEL) != 0;
+        const bool reg_kernel = !generic && (pv_wave_supported(log2n, hop) || pv_wg_supported(log2n, hop));
+        if (!reg_kernel && pv_kernel_lds_bytes(log2n, hop) > 160 * 1024 - 512)
+            return fail(nullptr, PV_ERR_UNSUPPORTED, "fft_size/hop_size combination exceeds the 160 KiB LDS of a CU");
+    }
     const int maxch = cfg->max_channels > 0 ? cfg->max_channels : 2;
     const int maxhops = cfg->max_hops > 0 ? cfg->max_hops : 1;
 
@@ -192,6 +196,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         h->use_wave = pv_wave_supported(log2n, hop) && !generic;
         h->use_wg = pv_wg_supported(log2n, hop) && !generic;
     }
+
 #define CHK(call)                                                          \
     do {                                                                   \
         hipError_t e2_ = (call);                                           \
@@ -264,15 +269,15 @@ int pv_destroy(pv_handle *h)
 {
     if (!h) return PV_OK;
     if (h->magic != kMagic) return PV_ERR_DESTROYED;
-    hipSetDevice(h->device);
-    if (h->own_stream) hipStreamSynchronize(h->own_stream);
-    hipFree(h->d_tw64); hipFree(h->d_tw32); hipFree(h->d_hann);
-    for (int i = 0; i < 2; i++) { hipFree(h->d_hist[i]); hipFree(h->d_acc[i]); }
-    hipFree(h->d_stage_in); hipFree(h->d_stage_out); hipFree(h->d_pitch);
-    if (h->h_pin) hipHostFree(h->h_pin);
-    hipFree(h->d_quantum);
-    hipFree(h->d_dbgX); hipFree(h->d_dbgMag); hipFree(h->d_dbgFlags); hipFree(h->d_dbgY);
-    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    (void)hipFree(h->d_tw64); (void)hipFree(h->d_tw32); (void)hipFree(h->d_hann);
+    for (int i = 0; i < 2; i++) { (void)hipFree(h->d_hist[i]); (void)hipFree(h->d_acc[i]); }
+    (void)hipFree(h->d_stage_in); (void)hipFree(h->d_stage_out); (void)hipFree(h->d_pitch);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
+    (void)hipFree(h->d_quantum);
+    (void)hipFree(h->d_dbgX); (void)hipFree(h->d_dbgMag); (void)hipFree(h->d_dbgFlags); (void)hipFree(h->d_dbgY);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     h->magic = 0;
     free(h);
     return PV_OK;
@@ -330,6 +335,33 @@ int pv_set_time_cursor(pv_handle *h, int64_t value)
     if (value < 0) return fail(h, PV_ERR_ARGUMENT, "pv_set_time_cursor: negative");
     if (value % h->hop != 0) return fail(h, PV_ERR_ARGUMENT, "pv_set_time_cursor: not a multiple of hop_size (the reference only advances it by hop_size, pv:71)");
     h->time_cursor = value;
+    return PV_OK;
+}
+
+int pv_export_state(pv_handle *h, int32_t ch, float *hist, float *acc, int64_t *time_cursor)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    if (ch < 0 || ch >= h->max_channels) return fail(h, PV_ERR_ARGUMENT, "pv_export_state: channel out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t bytes = sizeof(float) * (size_t)h->L;
+    if (hist && h->L) HIPCHK(h, hipMemcpyAsync(hist, h->d_hist[h->cur] + (size_t)ch * h->L, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (acc && h->L) HIPCHK(h, hipMemcpyAsync(acc, h->d_acc[h->cur] + (size_t)ch * h->L, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (time_cursor) *time_cursor = h->time_cursor;
+    return PV_OK;
+}
+
+int pv_import_state(pv_handle *h, int32_t ch, const float *hist, const float *acc, int64_t time_cursor)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    if (ch < 0 || ch >= h->max_channels) return fail(h, PV_ERR_ARGUMENT, "pv_import_state: channel out of range");
+    if (time_cursor >= 0 && time_cursor % h->hop != 0) return fail(h, PV_ERR_ARGUMENT, "pv_import_state: time_cursor is not a multiple of hop_size");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t bytes = sizeof(float) * (size_t)h->L;
+    if (hist && h->L) HIPCHK(h, hipMemcpyAsync(h->d_hist[h->cur] + (size_t)ch * h->L, hist, bytes, hipMemcpyHostToDevice, h->stream));
+    if (acc && h->L) HIPCHK(h, hipMemcpyAsync(h->d_acc[h->cur] + (size_t)ch * h->L, acc, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));              // the host buffers are the caller's again on return
+    if (time_cursor >= 0) h->time_cursor = time_cursor;
     return PV_OK;
 }
 

@@ -186,6 +186,8 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
     float *magv = reinterpret_cast<float *>(B);                           // alias: mags die before Y is zeroed
     float2 *Zb = reinterpret_cast<float2 *>(A);                           // alias: inverse FFT runs where X lived
     const float *frame = reinterpret_cast<const float *>(A);              // real output of the c2r transform
+    float2 *Af = reinterpret_cast<float2 *>(A);                           // X[0..M] rounded to fp32, in place over the first half of A (after the decisions)
+    unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + 8 * (M + 1) + 8);   // [H] claim words of the f < 1 scatter, in the half of A the rounding frees
     constexpr int BIG = 1 << 30;
 
     const int first_out = chunk * p.frames_per_chunk;
@@ -236,10 +238,25 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
             }
         }
         __syncthreads();
-        // ---- 4. |X|^2 in fp64, rounded once to f32 (pv:82-92) ----
-        for (int k = tid; k < H; k += THREADS) {
-            const double2 v = A[k];
-            magv[k] = (float)(v.x * v.x + v.y * v.y);
+        // ---- 4. |X|^2 in fp64, rounded once to f32 (pv:82-92).  X itself is then rounded to fp32 IN PLACE (the shift only moves fp32 values):
+        //          the half of A this frees holds the claim words of the f < 1 scatter ----
+        {
+            constexpr int XPT = (H + THREADS - 1) / THREADS;
+            float2 xf[XPT];
+            const bool dbgf = p.dbg_mag && ch == p.dbg_ch && m == p.dbg_frame;
+#pragma unroll
+            for (int i = 0; i < XPT; i++) {
+                const int k = tid + i * THREADS;
+                if (k < H) {
+                    const double2 v = A[k];
+                    magv[k] = (float)(v.x * v.x + v.y * v.y);
+                    xf[i] = float2{(float)v.x, (float)v.y};
+                    if (dbgf) { p.dbg_X[2 * k] = v.x; p.dbg_X[2 * k + 1] = v.y; }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < XPT; i++) { const int k = tid + i * THREADS; if (k < H) Af[k] = xf[i]; }
         }
         __syncthreads();
         // ---- 5. strict +-2 local maxima (pv:95-116) as a local predicate -> bit masks via ballot ----
@@ -282,8 +299,6 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
             for (int k = tid; k < H; k += THREADS) {
                 p.dbg_mag[k] = magv[k];
                 p.dbg_flags[k] = (int)((masks[k >> 6] >> (k & 63)) & 1ull);
-                p.dbg_X[2 * k] = A[k].x;
-                p.dbg_X[2 * k + 1] = A[k].y;
             }
         }
         // ---- 7. residue above Nyquist, only when the last region reads it ----
@@ -295,9 +310,23 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
         // ---- 8. zero the shifted spectrum (pv:121) ----
         for (int k = tid; k < H; k += THREADS) B[k] = float2{0.f, 0.f};
         __syncthreads();
-        // ---- 9. shiftPeaks (pv:119-173) as a per-source-bin rule + LDS scatter (atomic only when regions can collide) ----
+        // ---- 9. shiftPeaks (pv:119-173) as a per-source-bin rule + LDS scatter.  f >= 1: the shifted regions are disjoint -> plain stores.
+        //          f < 1: regions compress and `+=` collisions happen (pv:169-170).  They are resolved in CLAIM ROUNDS: every pending source
+        //          posts its bin with an LDS atomic MIN on the claim word of its target, the smallest bin wins the round and does a plain
+        //          read-modify-write.  Each target therefore accumulates its contributions in ascending source order -- the order of the
+        //          reference's loops (pv:122,146) -- whatever the timing of the waves: chunked, unchunked and call-split runs agree bit for
+        //          bit for every f (float atomics, used here before, add in arrival order) ----
         const bool disjoint = (pf >= 1.0);
-        for (int b = tid; b < upper_end; b += THREADS) {
+        constexpr int SPT = (N + THREADS - 1) / THREADS;                  // sources per thread (<= 32)
+        float2 ys[SPT];
+        unsigned short tg[SPT];
+        unsigned pend = 0;
+#pragma unroll
+        for (int i = 0; i < SPT; i++) {
+            const int b = tid + i * THREADS;
+            ys[i] = float2{0.f, 0.f};
+            tg[i] = 0;
+            if (b >= upper_end) continue;
             int prv, nxt;
             if (b < H) {
                 const int w = b >> 6, bit = b & 63;
@@ -322,14 +351,27 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
             if (tgt < 0 || tgt >= H) continue;                             // pv:150-152; negative index: named property
             const int ridx = ((delta & (N - 1)) * tmod) & (N - 1);         // (delta * t) mod N  (pv:155-157)
             const float2 rot = cconj(p.tw32[ridx]);                        // exp(+2 pi j ridx / N)
-            float2 v;
-            if (b < H) { const double2 xv = A[b]; v = float2{(float)xv.x, (float)xv.y}; } else v = B[b];
-            const float2 y = cmul(v, rot);
-            if (disjoint) {
-                B[tgt] = y;                                                // f >= 1: delta_i non-decreasing => shifted regions never overlap
-            } else {
-                atomicAdd(&B[tgt].x, y.x);                                 // f < 1: regions compress, += collisions (pv:169-170)
-                atomicAdd(&B[tgt].y, y.y);
+            const float2 v = (b < H) ? Af[b] : B[b];
+            ys[i] = cmul(v, rot);
+            tg[i] = (unsigned short)tgt;
+            if (disjoint) B[tgt] = ys[i];                                  // f >= 1: delta_i non-decreasing => shifted regions never overlap
+            else pend |= 1u << i;
+        }
+        if (!disjoint) {
+            for (int k = tid; k < H; k += THREADS) CLAIM[k] = 0xFFFFFFFFu;
+            while (__syncthreads_or(pend != 0u)) {
+#pragma unroll
+                for (int i = 0; i < SPT; i++) if (pend & (1u << i)) atomicMin(&CLAIM[tg[i]], (unsigned)(tid + i * THREADS));
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < SPT; i++) {
+                    if ((pend & (1u << i)) && CLAIM[tg[i]] == (unsigned)(tid + i * THREADS)) {
+                        const float2 o = B[tg[i]];
+                        B[tg[i]] = float2{o.x + ys[i].x, o.y + ys[i].y};
+                        CLAIM[tg[i]] = 0xFFFFFFFFu;                        // only the winner touches the word; losers re-post after the barrier
+                        pend &= ~(1u << i);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -393,9 +435,9 @@ hipError_t launch_one(const PvKernelParams &p, int nch, int nchunks, size_t lds,
     static bool attr_done[16] = {};
     auto k = pv_chain_kernel<LOG2N, THREADS>;
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     if (!attr_done[dev & 15]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);   // __syncthreads_or keeps a few static bytes
         if (e != hipSuccess) return e;
         attr_done[dev & 15] = true;
     }

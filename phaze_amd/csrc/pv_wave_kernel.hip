@@ -399,8 +399,6 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
 {
     constexpr int N = 1024, M = 512, H = 513;
     constexpr int HOP = 128 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;    // LROWS rows of carried accumulator
-    constexpr int BIG = 1 << 30;
-    constexpr int DROP = 0x4000;                                          // shift sentinel: b + DROP >= H for every bin b
     const int l = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // chains are numbered channel-major over (channel, chunk) and packed 12 to a workgroup regardless of the channel they belong to: many short
@@ -445,7 +443,6 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
     float2 *Y = reinterpret_cast<float2 *>(smem + OFF_Y);                // shifted spectrum Y[0..512], between the FFTs
     float *MAG = reinterpret_cast<float *>(smem + OFF_ROUTE);            // MAG[4 + k], k in [-4, 524): |X|^2 exchange
     unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + OFF_ROUTE);    // aliases MAG once the flags are taken: route of source bin b
-    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + OFF_ROUTE);   // aliases ROUTE once the routes are in registers (f < 1)
     short *DSH = reinterpret_cast<short *>(smem + OFF_PSH);              // shift Math.round(p * f) - p per candidate peak bin p (DROP: peak dropped)
     unsigned psh_key = 0u;                                               // bit pattern of the f the table was built for
     bool psh_valid = false;                                              // ... once one has been built (any bit pattern, NaNs included, is a legal f)
@@ -800,7 +797,7 @@ hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_
     static bool attr_done[16] = {};
     auto k = pv_wave_kernel_1024<S_ROWS, AUX>;
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     if (!attr_done[dev & 15]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_wave_lds_bytes());
         if (e != hipSuccess) return e;

@@ -39,7 +39,7 @@ struct WgCfg {
     static constexpr int SCRATCH = 8 * PMAX * 16;                                // bytes (fp64 complex)
     // inside the scratch, between the two FFTs:
     static constexpr int OFF_Y = 0;                                              // float2[H]
-    static constexpr int OFF_ROUTE = ((8 * H + 15) / 16) * 16;                   // u32[M + 16] routes | f32 mags | u16 claim ids (aliases)
+    static constexpr int OFF_ROUTE = ((8 * H + 15) / 16) * 16;                   // u32[M + 16] routes | f32 mags | u32 claim words (aliases)
     static constexpr int OFF_RESQ = OFF_ROUTE + 4 * (M + 16);                    // float2[N / 4] one residue quarter
     static_assert(OFF_RESQ + 8 * (N / 4) <= SCRATCH, "scratch too small");
     // after the scratch:
@@ -208,9 +208,12 @@ __device__ __forceinline__ pk::c32 mul_w16_inv_pk_wg(pk::c32 o, int r)
     }
 }
 
-// Workgroup-wide claim rounds (see claim_rounds in pv_wave_kernel.hip): the loop condition is reduced over the workgroup.
+// Workgroup-wide claim rounds (see claim_rounds in pv_wave_kernel.hip): the loop condition is reduced over the workgroup, and -- because
+// several waves race for a claim word here -- a source posts its bin with an LDS atomic MIN: the smallest pending source bin wins the round,
+// so every target accumulates its contributions in ascending source order (the order of the reference's loops, pv:122,146) whatever the
+// timing of the waves; results are reproducible bit for bit for every f.  CLAIM[0..H) must be all-ones on entry and is all-ones on exit.
 template <int NS, int H_>
-__device__ __forceinline__ void claim_rounds_wg(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned short *CLAIM)
+__device__ __forceinline__ void claim_rounds_wg(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned *CLAIM)
 {
     unsigned pend = 0;
     unsigned tg[NS];
@@ -223,9 +226,9 @@ __device__ __forceinline__ void claim_rounds_wg(const unsigned (&rt)[NS], const 
     }
     while (__syncthreads_or(pend != 0u)) {
 #pragma unroll
-        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[tg[r]] = (unsigned short)id[r];
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) atomicMin(&CLAIM[tg[r]], (unsigned)id[r]);
         __syncthreads();
-        unsigned short c[NS];
+        unsigned c[NS];
         float2 o[NS];
 #pragma unroll
         for (int r = 0; r < NS; r++) c[r] = CLAIM[tg[r]];                   // independent reads first, then the winners' stores (see pv_wave_kernel.hip)
@@ -233,8 +236,9 @@ __device__ __forceinline__ void claim_rounds_wg(const unsigned (&rt)[NS], const 
         for (int r = 0; r < NS; r++) o[r] = Y[tg[r]];
 #pragma unroll
         for (int r = 0; r < NS; r++) {
-            if ((pend & (1u << r)) && c[r] == (unsigned short)id[r]) {
+            if ((pend & (1u << r)) && c[r] == (unsigned)id[r]) {
                 Y[tg[r]] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
+                CLAIM[tg[r]] = 0xFFFFFFFFu;                                // only the winner touches the word; losers re-post after the barrier
                 pend &= ~(1u << r);
             }
         }
@@ -261,7 +265,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(cons
     constexpr bool BASE4 = (LOG2N % 2) == 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *Y = reinterpret_cast<float2 *>(smem + C::OFF_Y);
-    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + C::OFF_ROUTE);
+    unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);             // aliases ROUTE once the routes are in registers (f < 1)
     float2 *Q = reinterpret_cast<float2 *>(smem + C::OFF_RESQ);
     const WaveSrc src{in, hist, hist_len};
     for (int base = N / 2; base < N && base < upper_end; base += QN) {
@@ -323,7 +327,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(cons
             const int b = base + t + T * j, tgt = b + up_delta;
             rt[j] = (b >= H && b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
             ys[j] = rotate_route<R_, LOG2N>(rt[j], Q[t + T * j], tw32);
-            id[j] = b - N / 2;                                             // unique within a round, fits 16 bits for N = 8192
+            id[j] = b - N / 2;                                             // ascending with the source bin; regular sources are done by now
         }
         claim_rounds_wg<4, (1 << (LOG2N - 1)) + 1>(rt, ys, id, Y, CLAIM);
         __syncthreads();
@@ -344,7 +348,6 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     constexpr int R = RING ? 0 : N / (2 * T * (S_ROWS ? S_ROWS : 1));    // compile-time R (4 => exact j^q rotations); 0 = run time
     const int Rrt = N / HOP;
     constexpr int LROWS = RING ? 0 : 8 - S_ROWS;
-    constexpr int BIG = 1 << 30;
     constexpr int NEGPD = -(1 << 30), POSPD = 1 << 30;                    // packed (bin << 16 | shift) sentinels: no peak on this side
     constexpr int DROP = 0x4000;                                        // shift sentinel: b + DROP >= H for every bin, above every real shift
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     float2 *Y = reinterpret_cast<float2 *>(smem + C::OFF_Y);
     float *MAG = reinterpret_cast<float *>(smem + C::OFF_ROUTE);
     unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);
-    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + C::OFF_ROUTE);
+    unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);             // aliases ROUTE once the routes are in registers (f < 1)
     short *DSH = reinterpret_cast<short *>(smem + C::OFF_PSH);          // shift per candidate peak bin (DROP: peak dropped)
     int *LASTIN = reinterpret_cast<int *>(smem + C::OFF_NEAR), *FIRSTIN = LASTIN + T;
     unsigned long long *OCC = reinterpret_cast<unsigned long long *>(smem + C::OFF_OCC);
@@ -675,7 +678,11 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 rt[8] = (t == 0) ? ROUTE[M / 2] : NOROUTE;
                 ys[8] = rotate_route<R, LOG2N>(rt[8], xHf, p.tw32);
                 id[8] = M / 2;
-                claim_rounds_wg<9, H>(rt, ys, id, Y, CLAIM);                  // its first barrier also separates the ROUTE reads from CLAIM writes
+                __syncthreads();                                            // every ROUTE read is done: the region becomes the claim words
+#pragma unroll
+                for (int r = 0; r < 8; r++) CLAIM[t + T * r] = 0xFFFFFFFFu;
+                if (t == 0) CLAIM[M] = 0xFFFFFFFFu;
+                claim_rounds_wg<9, H>(rt, ys, id, Y, CLAIM);                  // (its first barrier orders the fill before the first claims)
                 if (need_res) {
                     __syncthreads();
                     const int up_delta = (int)DSH[last_peak];
@@ -816,7 +823,7 @@ hipError_t launch_wg(const PvKernelParams &p, int nch, int nchunks, hipStream_t 
     static bool attr_done[16] = {};
     auto k = pv_wg_kernel<LOG2N, S_ROWS, AUX>;
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     using CR = WgCfg<G, true>;
     constexpr int lds_bytes = S_ROWS ? WgCfg<G>::LDS_BYTES : CR::LDS_BYTES_RING;
     if (!attr_done[dev & 15]) {

@@ -118,10 +118,48 @@ function runCase(c) {
   return { sig, pitch, out, dumps, maxCh };
 }
 
+/* numberOfInputs > 1 (src/ola-processor.js:10-11,24-33): every input has its own channel list, channel-count changes reallocate
+ * only that input (src/ola-processor.js:38-52), timeCursor is shared (src/phase-vocoder.js:71).  Signals: channel c of input i uses
+ * seed channel 10*i + c.  Output layout: input-major, each input padded to its largest channel count, store_hops hops per channel. */
+function runMultiCase(c) {
+  const N = c.fft, h = c.hop, T = c.nhops, nin = c.inputs.length;
+  const Cls = loadProcessorClass(N, h);
+  const proc = new Cls({ numberOfInputs: nin, numberOfOutputs: nin });
+  const maxCh = c.inputs.map(inp => Math.max(inp.nch, ...(inp.events || []).filter(e => e.type === 'channels').map(e => e.nch)));
+  const sig = c.inputs.map((inp, i) => { const a = []; for (let ch = 0; ch < maxCh[i]; ch++) a.push(makeSignal(c.signal, 10 * i + ch, T * h, N)); return a; });
+  const out = c.inputs.map((inp, i) => { const a = []; for (let ch = 0; ch < maxCh[i]; ch++) a.push(new Float32Array(T * h)); return a; });
+  const pitch = pitchSchedule(c.pitch, T);
+  const nch = c.inputs.map(inp => inp.nch);
+  for (let m = 0; m < T; m++) {
+    const inputs = [], outputs = [];
+    for (let i = 0; i < nin; i++) {
+      for (const e of (c.inputs[i].events || [])) if (e.hop === m && e.type === 'channels') nch[i] = e.nch;
+      const ins = [], outs = [];
+      for (let ch = 0; ch < nch[i]; ch++) { ins.push(Float32Array.from(sig[i][ch].subarray(m * h, (m + 1) * h))); outs.push(new Float32Array(h)); }
+      inputs.push(ins); outputs.push(outs);
+    }
+    if (proc.process(inputs, outputs, { pitchFactor: Float32Array.of(pitch[m]) }) !== true) throw new Error('process() did not return true');
+    for (let i = 0; i < nin; i++) for (let ch = 0; ch < nch[i]; ch++) out[i][ch].set(outputs[i][ch], m * h);
+  }
+  const total = maxCh.reduce((a, b) => a + b, 0);
+  const stored = new Float32Array(total * c.store_hops * h);
+  let k = 0;
+  for (let i = 0; i < nin; i++) for (let ch = 0; ch < maxCh[i]; ch++) stored.set(out[i][ch].subarray(0, c.store_hops * h), (k++) * c.store_hops * h);
+  return { stored, pitch, maxCh, sig0: sig[0][0] };
+}
+
 function main() {
   const spec = JSON.parse(fs.readFileSync(path.join(HERE, 'cases.json'), 'utf8'));
   const manifest = { generator: 'tests/golden/gen_golden.js', node: process.version, reference_bundle_sha256: sha(fs.readFileSync(REF)), cases: [] };
   for (const c of spec.cases) {
+    if (c.inputs) {
+      const r = runMultiCase(c);
+      fs.writeFileSync(path.join(HERE, c.name + '.out.f32'), Buffer.from(r.stored.buffer));
+      manifest.cases.push(Object.assign({}, c, { out_file: c.name + '.out.f32', out_sha256: sha(r.stored), full_out_sha256: sha(r.stored), full_out_rms: rms(r.stored),
+                                                  in_sha256_ch0: sha(r.sig0), pitch_sha256: sha(r.pitch), max_channels_per_input: r.maxCh, dumps: [] }));
+      console.log(c.name.padEnd(40), 'out.sha', sha(r.stored).slice(0, 24), 'rms', rms(r.stored).toExponential(4));
+      continue;
+    }
     const r = runCase(c);
     const h = c.hop;
     // full-output fingerprint: all channels, all hops, channel-major (SURVEY.md section 4 convention)

@@ -124,3 +124,24 @@ def run_case(case: dict, signals, pitch, collect_dumps=False):
             dumps[m] = o.debug()
     o.close()
     return out, dumps
+
+
+def run_multi_case(case: dict, signals, pitch):
+    """numberOfInputs > 1 (ola-processor.js:10-11,24-33): one processor state per input, each with its own channel list; a channel-count
+    change reallocates only that input (ola:38-52).  Returns a list (per input) of out[maxch_i, nhops*hop]."""
+    N, h, T = case["fft"], case["hop"], case["nhops"]
+    nin = len(case["inputs"])
+    nch = [inp["nch"] for inp in case["inputs"]]
+    procs = [Oracle(N, h, n) for n in nch]
+    outs = [np.zeros((len(signals[i]), T * h), dtype=np.float32) for i in range(nin)]
+    for m in range(T):
+        for i in range(nin):
+            for e in case["inputs"][i].get("events", []):
+                if e["hop"] == m and e["type"] == "channels":
+                    nch[i] = e["nch"]
+            res = procs[i].process([signals[i][c][m * h:(m + 1) * h] for c in range(nch[i])], pitch[m])
+            for c in range(nch[i]):
+                outs[i][c, m * h:(m + 1) * h] = res[c]
+    for p_ in procs:
+        p_.close()
+    return outs

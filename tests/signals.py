@@ -77,8 +77,29 @@ def sha256_hex(a: np.ndarray) -> str:
 
 
 def load_manifest() -> dict:
+    """Single-input cases under "cases" (what most tests iterate over); numberOfInputs > 1 cases under "multi_cases"."""
     with open(os.path.join(GOLDEN_DIR, "manifest.json")) as f:
-        return json.load(f)
+        m = json.load(f)
+    m["multi_cases"] = [c for c in m["cases"] if "inputs" in c]
+    m["cases"] = [c for c in m["cases"] if "inputs" not in c]
+    return m
+
+
+def multi_case_signals(case: dict):
+    """signals[i][c]: channel c of input i uses seed channel 10*i + c (tests/golden/gen_golden.js runMultiCase)."""
+    n = case["nhops"] * case["hop"]
+    return [[make_signal(case["signal"], 10 * i + c, n) for c in range(mc)] for i, mc in enumerate(case["max_channels_per_input"])]
+
+
+def load_golden_multi(case: dict):
+    """Returns a list (per input) of [max channels of that input, store_hops*hop] float32."""
+    a = np.fromfile(os.path.join(GOLDEN_DIR, case["out_file"]), dtype="<f4")
+    n = case["store_hops"] * case["hop"]
+    out, pos = [], 0
+    for mc in case["max_channels_per_input"]:
+        out.append(a[pos:pos + mc * n].reshape(mc, n))
+        pos += mc * n
+    return out
 
 
 def load_golden_out(case: dict) -> np.ndarray:

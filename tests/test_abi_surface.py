@@ -26,7 +26,8 @@ def _lib():
 def test_header_declares_the_documented_surface():
     names = _declared()
     for must in ("pv_create", "pv_destroy", "pv_process", "pv_process_batch", "pv_process_batch_device", "pv_reset", "pv_reset_channels",
-                 "pv_last_error", "pv_get_info", "pv_set_stream", "pv_synchronize", "pv_get_time_cursor", "pv_debug_frame"):
+                 "pv_last_error", "pv_get_info", "pv_set_stream", "pv_synchronize", "pv_get_time_cursor", "pv_debug_frame", "pv_export_state",
+                 "pv_import_state"):
         assert must in names
     assert "/root/reference/src/ola-processor.js:159-171" in open(HEADER).read()      # every entry point cites what it replaces
 

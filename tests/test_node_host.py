@@ -94,6 +94,30 @@ def test_node_process_matches_reference_golden(name, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", MAN["multi_cases"], ids=lambda c: c["name"])
+def test_node_two_inputs_match_reference_golden(case, tmp_path):
+    """numberOfInputs: 2 -- two inputs with different channel counts, one changing mid-stream (ola-processor.js:24-33,38-52): the host keeps
+    one native handle per input; the reference's outputs for BOTH inputs are the golden."""
+    _build()
+    h, T = case["hop"], case["store_hops"]
+    sig = S.multi_case_signals(case)
+    pitch = S.pitch_schedule(case["pitch"], case["nhops"])[:T]
+    pitch.astype("<f4").tofile(tmp_path / "pitch.f32")
+    inputs = []
+    for i, inp in enumerate(case["inputs"]):
+        np.stack([s[:T * h] for s in sig[i]]).astype("<f4").tofile(tmp_path / f"in{i}.f32")
+        inputs.append({"nch": inp["nch"], "events": inp.get("events", []), "max_ch": case["max_channels_per_input"][i], "in_file": str(tmp_path / f"in{i}.f32")})
+    spec = {"fft": case["fft"], "hop": h, "nhops": T, "inputs": inputs, "pitch_file": str(tmp_path / "pitch.f32"), "out_file": str(tmp_path / "out.f32")}
+    (tmp_path / "spec.json").write_text(json.dumps(spec))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node", "run_multi.js"), str(tmp_path / "spec.json")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = np.fromfile(tmp_path / "out.f32", dtype="<f4")
+    gold = np.concatenate([g.ravel() for g in S.load_golden_multi(case)])
+    assert got.shape == gold.shape and np.all(np.isfinite(got))
+    assert S.rms(got.astype(np.float64) - gold) < 2e-6
+
+
+@pytest.mark.gpu
 def test_wav_cli_shifts_pitch(tmp_path):
     """Node WAV-in/WAV-out CLI (counterpart of src/main.js): a 440 Hz tone at pitch 1.5 comes out near 660 Hz, same length and level;
     the streaming (process() per quantum) and batch entry points agree bit for bit."""

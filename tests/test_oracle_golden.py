@@ -43,6 +43,20 @@ def test_oracle_matches_reference_output(name):
     assert S.sha256_hex(gold) == case["out_sha256"]
 
 
+@pytest.mark.parametrize("case", MAN["multi_cases"], ids=lambda c: c["name"])
+def test_oracle_matches_reference_multi_input(case):
+    """numberOfInputs = 2 with different channel counts, one input changing its count mid-stream (ola-processor.js:24-33,38-52)."""
+    sig = S.multi_case_signals(case)
+    pitch = S.pitch_schedule(case["pitch"], case["nhops"])
+    assert S.sha256_hex(sig[0][0]) == case["in_sha256_ch0"] and S.sha256_hex(pitch) == case["pitch_sha256"]
+    outs = oracle_lib.run_multi_case(case, sig, pitch)
+    gold = S.load_golden_multi(case)
+    n = case["store_hops"] * case["hop"]
+    for i, g in enumerate(gold):
+        err = S.rms(outs[i][:, :n].astype(np.float64) - g.astype(np.float64))
+        assert err <= ORACLE_TOL_RMS, f"{case['name']} input {i}: rms err {err:.3e}"
+
+
 @pytest.mark.parametrize("name", sorted(n for n, c in CASES.items() if c.get("dumps")))
 def test_oracle_intermediates_match_reference(name):
     case = CASES[name]
