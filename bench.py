@@ -177,6 +177,93 @@ def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmu
             "alg_bytes": alg_bytes, "achieved_gbs": achieved, "parity": parity}
 
 
+def synth_stream(torch, nch, n0, n1, device):
+    """Samples [n0, n1) of ONE deterministic stream (a function of the absolute sample index only), so that every rank of a
+    time-sharded run cuts its span out of the same signal: the partials of synth_input + an index-hashed noise floor."""
+    n = torch.arange(n0, n1, device=device, dtype=torch.float64)
+    base = 2 * 3.14159265358979 / 48000.0
+    x = torch.empty((nch, n1 - n0), device=device, dtype=torch.float32)
+    for c in range(nch):
+        s = 0.25 * torch.sin(n * (base * (220.0 + 17 * c))) + 0.125 * torch.sin(n * (base * (1375.0 + 5 * c))) + 0.0625 * torch.sin(n * (base * 6857.0))
+        h = torch.frac(torch.sin(n * 12.9898 + 78.233 * (c + 1)) * 43758.5453)
+        x[c] = (s + (h - 0.5) * (2.0 / 64)).to(torch.float32)
+    return x
+
+
+def measure_time_shard(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_value, steps, warmup, local_rank, rank, world):
+    """ONE stream of T hops split along the time axis over the ranks: rank r owns hops [r T / W, (r + 1) T / W), imports
+    {input tail, acc = 0, timeCursor} R - 1 hops before its span (pv_import_state) and recomputes that halo -- no hand-over between ranks.
+    Parity: the first hops of every span against the oracle fed the same stream prefix is too slow for spans deep in the stream, so each rank
+    checks its span start against a handle that ran a longer lead-in (state reached by processing, not by import)."""
+    import numpy as np
+    from phaze_amd import shard
+    R, L = fft // hop, fft - hop
+    lo, hi = rank * T // world, (rank + 1) * T // world
+    start = max(lo - (R - 1), 0)
+    x = synth_stream(torch, nch, start * hop, hi * hop, dev)
+    y = torch.empty_like(x)
+    Ts = hi - start
+    pitch = torch.full((Ts,), pitch_value, device=dev, dtype=torch.float32)
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, device_id=local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    pv.set_stream(stream.cuda_stream)
+
+    def import_span_state():
+        pv.reset()
+        if start > 0:
+            tail = synth_stream(torch, nch, start * hop - L, start * hop, dev).cpu().numpy()
+            for c in range(nch):
+                pv.import_state(c, hist=tail[c], acc=np.zeros(L, np.float32), time_cursor=start * hop)
+
+    def step():
+        pv.process_batch_device(x.data_ptr(), y.data_ptr(), nch, Ts, Ts * hop, pitch.data_ptr(), 0, 1)
+
+    # parity of the hand-over-free start: a second handle reaches hop `lo` by PROCESSING a lead-in of 64 hops (no import of the
+    # accumulator), and must produce the same first hops of the span bit for bit
+    import_span_state()
+    step()
+    pv.synchronize()
+    K = min(32, hi - lo)
+    got = y[:, (lo - start) * hop:(lo - start + K) * hop].cpu().numpy()
+    lead = min(lo, 64 + R)
+    chk = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=lead + K, device_id=local_rank)
+    if lo - lead > 0:
+        tail = synth_stream(torch, nch, (lo - lead) * hop - L, (lo - lead) * hop, dev).cpu().numpy()
+        for c in range(nch):
+            chk.import_state(c, hist=tail[c], acc=np.zeros(L, np.float32), time_cursor=(lo - lead) * hop)
+    xs = synth_stream(torch, nch, (lo - lead) * hop, (lo + K) * hop, dev).cpu().numpy()
+    ref = chk.process_batch(xs, np.full(lead + K, pitch_value, np.float32))[:, lead * hop:]
+    chk.close()
+    # (with lo - lead > 0 the lead-in itself starts from an imported input tail with acc = 0: its first R - 1 hops are a halo, discarded here)
+    span_equal = bool(np.array_equal(got, ref)) if lead >= R - 1 or lo == 0 else None
+    import_span_state()
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(steps):
+            step()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / steps
+    elapsed, kernel_ms = shard.reduce_max([elapsed, kernel_ms], dist, dev)
+    ok = shard.reduce_max([0.0 if span_equal in (True, None) else 1.0], dist, dev)[0] == 0.0
+    info = pv.info()
+    pv.close()
+    return {"elapsed": elapsed, "kernel_ms": kernel_ms, "info": info, "span": [lo, hi], "halo_hops": lo - start, "spans_bit_exact": ok,
+            "alg_bytes": nch * (hi - lo) * 2 * hop * 4, "achieved_gbs": nch * (hi - lo) * 2 * hop * 4 / (kernel_ms * 1e-3) / 1e9}
+
+
 def latency_histogram(phaze_amd, fft, hop, nch, calls, local_rank, sweep):
     """Streaming form (one render quantum per call): per-call wall latency of pv_process through the C ABI."""
     import ctypes as C
@@ -219,8 +306,8 @@ def spawn_ranks(args, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--fft", type=int, default=1024)
     ap.add_argument("--hop", type=int, default=256)
     ap.add_argument("--channels", type=int, default=1)
@@ -231,6 +318,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the per-config lines and the latency histogram (profiling runs)")
     ap.add_argument("--allow-lib-override", action="store_true", help="accept PHAZE_LIB (A/B builds of the same ABI); recorded in the line")
     ap.add_argument("--pcie", action="store_true", help="also report the host-buffer (PCIe-inclusive) rate")
+    ap.add_argument("--time-shard", action="store_true",
+                    help="ONE stream of --hops hops split along the time axis over the ranks (strong scaling; single-stream configs C2 / C3 on N GPUs)")
+    ap.add_argument("--simulate-shard", default="", help="with --time-shard on ONE GPU: measure the span of rank r of w ('r/w') without a process group")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="N > 1: all streams start on rank 0, are scattered over RCCL, and the results gathered back (reported separately, never in value)")
     args = ap.parse_args()
@@ -270,6 +360,33 @@ def main():
 
     fft, hop, nch, T = args.fft, args.hop, args.channels, args.hops
     from phaze_amd import shard
+    if args.time_shard:
+        sr, sw = rank, world
+        if args.simulate_shard and world == 1:
+            sr, sw = (int(v) for v in args.simulate_shard.split("/"))
+        r = measure_time_shard(torch, phaze_amd, dev, dist, fft, hop, nch, T, args.pitch, args.steps, args.warmup, local_rank, sr, sw)
+        if args.simulate_shard and world == 1:
+            r["elapsed"] *= 1.0        # one span measured; the line below still divides the WHOLE stream by it: only meaningful as a per-span time
+        if rank == 0:
+            chs = "mono" if nch == 1 else "stereo" if nch == 2 else f"{nch}-ch"
+            print(json.dumps({
+                "metric": "stft_frames_per_sec_1024pt_hop256_48k" if (fft, hop) == (1024, 256) else f"stft_frames_per_sec_{fft}pt_hop{hop}",
+                "value": nch * T * args.steps / r["elapsed"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": r["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE,
+                "data": "synthetic",
+                "config": {"workload": f"ONE {chs} 48 kHz stream, FFT={fft} hop={hop} pitchFactor={args.pitch}, {T} hops per step split along the time axis "
+                                       f"over {world} GPU(s): every span imports its input tail + acc = 0 + timeCursor {fft // hop - 1} hops early and "
+                                       "recomputes the halo (pv_import_state; no hand-over between ranks, no collective)",
+                           "fft": fft, "hop": hop, "channels": nch, "hops_per_step": T, "pitch_factor": args.pitch, "rank0_span": r["span"],
+                           "halo_hops": r["halo_hops"], "parallelism": f"time-shard x{world}" + (f" (simulated span {args.simulate_shard}: value is NOT a job rate)" if args.simulate_shard else ""),
+                           "device": r["info"]["device_name"]},
+                "roofline": {"bound": "hbm", "achieved": r["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["achieved_gbs"] / HBM_PEAK_GBS,
+                             "traffic": None, "kernel": r["info"]["kernel_name"], "kernel_ms": r["kernel_ms"], "algorithmic_bytes_per_launch": r["alg_bytes"]},
+                "span_starts_bit_exact_vs_processed_lead_in": r["spans_bit_exact"]}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     pitch = torch.full((T,), args.pitch, device=dev, dtype=torch.float32)
     head = measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch, args.steps, args.warmup, "headline", local_rank,
                    frames_per_chunk=args.frames_per_chunk, parity_hops=96 if rank == 0 else 0, seed=rank)

@@ -72,3 +72,13 @@ def test_bench_gpus_flag_degrades_explicitly_on_a_smaller_box():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["n_gpus"] == ndev and j["requested_gpus"] == ndev + 1 and j["replicas_measured"] == ndev
+
+
+def test_bench_time_shard_span_is_bit_exact():
+    """bench.py --time-shard: a span deep inside ONE stream started from {input tail, acc = 0, cursor} R - 1 hops early equals the same hops of a
+    handle that reached them by processing a long lead-in (rank 3 of 4 simulated on this GPU)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--time-shard", "--simulate-shard", "3/4", "--steps", "2", "--warmup", "1",
+                        "--hops", "65536", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["span_starts_bit_exact_vs_processed_lead_in"] is True and j["config"]["rank0_span"] == [49152, 65536] and j["config"]["halo_hops"] == 3
