@@ -37,17 +37,21 @@ DTYPE = "f64+f32"           # forward FFT and peak decisions in f64 (decision pa
 
 
 def synth_input(torch, nch, nsamples, device, seed):
-    """Tonal partials + a -36 dB noise floor (always keep a noise floor, K12), generated on device."""
+    """Tonal partials + a -36 dB noise floor (always keep a noise floor, K12), generated on device (a handful of launches
+    whatever the channel count: the profiles stay small)."""
     g = torch.Generator(device=device)
     g.manual_seed(1234 + seed)
-    n = torch.arange(nsamples, device=device, dtype=torch.float32)
-    x = torch.empty((nch, nsamples), device=device, dtype=torch.float32)
     base = 2 * 3.14159265358979 / 48000.0
-    for c in range(nch):
-        s = 0.25 * torch.sin(n * (base * (220.0 + 17 * (c % 97)))) + 0.125 * torch.sin(n * (base * (1375.0 + 5 * (c % 89)))) \
+    c = torch.arange(nch, device=device, dtype=torch.float32)[:, None]
+    x = torch.empty((nch, nsamples), device=device, dtype=torch.float32)
+    blk = max(1, (1 << 26) // max(nsamples, 1))                    # channels per block: bounds the temporaries to ~256 MB each
+    for c0 in range(0, nch, blk):
+        cc = c[c0:c0 + blk]
+        n = torch.arange(nsamples, device=device, dtype=torch.float32)[None, :]
+        s = 0.25 * torch.sin(n * (base * (220.0 + 17 * (cc % 97)))) + 0.125 * torch.sin(n * (base * (1375.0 + 5 * (cc % 89)))) \
             + 0.0625 * torch.sin(n * (base * 6857.0))
-        s += (torch.rand(nsamples, device=device, generator=g) - 0.5) * (2.0 / 64)
-        x[c] = s
+        s += (torch.rand(s.shape, device=device, generator=g) - 0.5) * (2.0 / 64)
+        x[c0:c0 + blk] = s
     return x
 
 

@@ -91,11 +91,13 @@ __device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename 
     for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWB[(k - 1) * 8 * G + tlo]));
 #pragma unroll
     for (int k = 0; k < 8; k++) S[k * C::P2 + kA1 * (8 * G + C::A2) + tlo] = a[k];
-    __syncthreads();
+    // transpose 2 stays inside the group of 8G <= 64 threads that share kA1, i.e. inside ONE wave: the LDS traffic of a wave executes in
+    // order, so a compiler fence replaces the two workgroup barriers (4 of the ~21 barriers of a frame)
+    wave_sync();
     const int kB2 = tlo / G, ulo = tlo % G;               // destination role of this thread: (kA1, kB2, ulo)
 #pragma unroll
     for (int n = 0; n < 8; n++) a[n] = S[kB2 * C::P2 + kA1 * (8 * G + C::A2) + n * G + ulo];
-    __syncthreads();
+    __syncthreads();                                      // the next transpose writes rows other waves still read here
     // ---- pass C ----
     radix8<T_, INV>(a);
 #pragma unroll
@@ -160,7 +162,7 @@ __device__ __forceinline__ void fft_wg_inv_pk(pk::c32 (&a)[8], pk::c32 *S, const
     for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], twc_inv_pk(TWB[(k - 1) * 8 * G + tlo]));
 #pragma unroll
     for (int k = 0; k < 8; k++) S[k * C::P2 + kA1 * (8 * G + C::A2) + tlo] = a[k];
-    __syncthreads();
+    wave_sync();                                          // wave-local exchange (see fft_wg)
     const int kB2 = tlo / G, ulo = tlo % G;
 #pragma unroll
     for (int n = 0; n < 8; n++) a[n] = S[kB2 * C::P2 + kA1 * (8 * G + C::A2) + n * G + ulo];
