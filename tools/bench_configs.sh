@@ -2,10 +2,10 @@
 # The other BASELINE shapes (profiles/*_other_configs.md): one bench.py line each, condensed.  usage (GPU box): tools/bench_configs.sh
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 run() {
-  python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" | python -c "
+  python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras "$@" | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('| %-58s | %.3g | %.2f | %.2f %% | %s | parity %.2g' % ('$*', d['value'], d['ms_per_step'], 100*d['roofline']['frac'], d.get('kernel','?'), d['parity_rms_vs_oracle']))"
+print('| %-58s | %.3g | %.2f | %.2f %% | %s | parity %.2g' % ('$*', d['value'], d['ms_per_step'], 100*d['roofline']['frac'], d['roofline'].get('kernel','?'), d['parity_rms_vs_oracle']))"
 }
 run --fft 1024 --hop 256 --channels 1 --hops 1048576 --pitch 1.5
 run --fft 1024 --hop 256 --channels 1 --hops 1048576 --pitch 0.8

@@ -15,21 +15,8 @@ except Exception as e:
     print("$n FAILED", e, open("$OUT/$n.err").read()[-600:])
 PY
 }
+# example body (edit per experiment): builds live under build/exp/ (git-ignored, shipped by gpurun)
 E=$ROOT/build/exp
-python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; tail -4 $OUT/pytest.log
 run new ""
-run old $E/libphaze_old.so
-run new2 ""
-run new_pf08 "" --pitch 0.8
-run old_pf08 $E/libphaze_old.so --pitch 0.8
-run new_h128 "" --hop 128 --hops 524288
-run old_h128 $E/libphaze_old.so --hop 128 --hops 524288
-run new_h512 "" --hop 512 --hops 524288
-run old_h512 $E/libphaze_old.so --hop 512 --hops 524288
-run new_8ch "" --channels 8 --hops 131072
-python bench.py --steps 5 --warmup 2 > $OUT/full.json 2> $OUT/full.err; python -c "
-import json; j=json.loads(open('$OUT/full.json').read().strip().splitlines()[-1])
-print('FULL', j['value'], j['roofline']['frac'], j['dtype'])
-for c in j.get('configs',[]): print('  ', c['workload'][:60], '%.4g'%c['value'], '%.4f'%c['roofline_frac'], c['parity_rms_vs_oracle'], c['kernel'])
-print('  latency', j.get('latency_us')); print('  cpu', j.get('cpu_baseline'))
-" || tail -5 $OUT/full.err
+for lib in $E/libphaze_*.so; do [ -f "$lib" ] && run $(basename $lib .so) $lib; done
+run new_again ""

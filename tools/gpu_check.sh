@@ -1,6 +1,8 @@
 #!/bin/bash
+# One GPU-box call that checks everything the driver will run: pytest -m gpu, the default bench line (with the per-config lines, latency and
+# cpu_baseline), the --gpus degradation and a simulated time-shard span.  usage: gpurun -- bash tools/gpu_check.sh
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r02f; mkdir -p $OUT
+OUT=$ROOT/gpurun_out/check; mkdir -p $OUT
 cd $ROOT
 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; python -c "
