@@ -566,6 +566,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
                 if (dbg) { p.dbg_X[2 * 256] = x256.x; p.dbg_X[2 * 256 + 1] = x256.y; }
             }
         }
+#ifndef PV_RELOAD_ROWS
         // slide the window: the rows the next frame adds are issued here and land behind the shift + inverse FFT
 #pragma unroll
         for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
@@ -574,6 +575,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
             load_rows(&raw[8 - S_ROWS], S_ROWS, 8 - S_ROWS, mn);
             pf_next = pitch_row[mn];
         }
+#endif
         // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change ----
         {
             const unsigned pfb = __float_as_uint(pfm);
@@ -751,6 +753,13 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
             }
         }
         wave_sync();
+#ifdef PV_RELOAD_ROWS
+        {   // experiment: no rows carried through the forward FFT (its register peak): the whole window of the next frame is (re)loaded here
+            const int mn = (m + 1 < last_out) ? m + 1 : m;
+            load_rows(raw, 8, 0, mn);
+            pf_next = pitch_row[mn];
+        }
+#endif
         fft512_wave_inv_pk(zi, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l);
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         {
