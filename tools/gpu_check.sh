@@ -15,3 +15,6 @@ python bench.py --gpus 2 --steps 5 --warmup 2 --no-extras --no-cpu-baseline 2>/d
 import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('GPUS2', j['n_gpus'], j.get('requested_gpus'), j.get('replicas_measured'))"
 python bench.py --time-shard --simulate-shard 2/4 --steps 5 --warmup 2 2>/dev/null | python -c "
 import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('TSHARD', j['span_starts_bit_exact_vs_processed_lead_in'], j['config']['rank0_span'], j['roofline']['kernel_ms'])"
+# the RCCL branch of bench.py (process group, barrier, all_reduce(MAX)) at world size 1, launched the way the driver launches N ranks
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('TORCHRUN1', j['n_gpus'], '%.4g'%j['value'], j['config']['parallelism'])"
