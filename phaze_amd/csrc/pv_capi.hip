@@ -94,6 +94,11 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
         if (eff > best_eff + 1e-9) { best_eff = eff; best = F; }
     };
     consider(nhops);                                                                             // one chain per channel: no halo at all
+    // chain lengths that fill exactly r rounds of the resident chains (r = 1: every CU starts once, the halo is the smallest a full chip allows)
+    for (long r = 1; r <= 8; r++) {
+        const long chunks = (r * resident) / (nch > 0 ? nch : 1);
+        if (chunks >= 1) { consider((int)((nhops + chunks - 1) / chunks)); consider((int)((nhops + chunks - 1) / chunks) + 1); }
+    }
     for (int F = 48 * R; F >= (R > 1 ? R : 1); F -= (F > 8 * R ? R : 1)) {
         if (F > nhops && F > R) continue;
         consider(F);

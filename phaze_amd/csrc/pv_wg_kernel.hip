@@ -541,30 +541,34 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         int lastown[8], firstown[8];                                      // last own peak <= bin i / first own peak > bin i
         int last_in, first_in;
         {
-            float mg[12];
-            // LDS-address-space vector loads: otherwise the optimizer re-pairs the 12 floats into misaligned ds_read2_b32 (8 LDS cycles each)
-            typedef const volatile __attribute__((address_space(3))) v2f *lds_v2f;
-            typedef const volatile __attribute__((address_space(3))) v4f *lds_v4f;
-            const v2f q0 = *(lds_v2f)(&MAG[4 + 8 * t - 2]);
-            const v4f q1 = *(lds_v4f)(&MAG[4 + 8 * t]);
-            const v4f q2 = *(lds_v4f)(&MAG[4 + 8 * t + 4]);
-            const v2f q3 = *(lds_v2f)(&MAG[4 + 8 * t + 8]);
+            // |X|^2 >= 0: fp32 order = order of the bit patterns as unsigned integers, so "strictly greater than all four neighbours" is
+            // c > max(neighbours) with v_max3_u32 (see pv_wave_kernel.hip): two instructions per bin + eight shared pair maxima
+            unsigned mg[12];
+            // LDS-address-space vector loads: otherwise the optimizer re-pairs the 12 words into misaligned ds_read2_b32 (8 LDS cycles each)
+            typedef const volatile __attribute__((address_space(3))) v2u *lds_v2u;
+            typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
+            const v2u q0 = *(lds_v2u)(&MAG[4 + 8 * t - 2]);
+            const v4u q1 = *(lds_v4u)(&MAG[4 + 8 * t]);
+            const v4u q2 = *(lds_v4u)(&MAG[4 + 8 * t + 4]);
+            const v2u q3 = *(lds_v2u)(&MAG[4 + 8 * t + 8]);
             mg[0] = q0.x; mg[1] = q0.y; mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w;
             mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w; mg[10] = q3.x; mg[11] = q3.y;
+            unsigned pm[11];
+#pragma unroll
+            for (int j = 3; j < 11; j++) pm[j] = max(mg[j], mg[j + 1]);
             bool fl[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const int k = 8 * t + i;
-                const float c = mg[i + 2];
-                fl[i] = (k >= 2) & (k < H - 2) & (mg[i + 1] < c) & (mg[i] < c) & (mg[i + 3] < c) & (mg[i + 4] < c);      // & not &&: no branches
+                // bin k = 8t + i, candidates are 2 <= k < H - 2 (pv:97-100): thread 0 drops i < 2, the last thread drops i = 7
+                const bool in_range = (i < 2) ? (t != 0) : (i == 7) ? (t != T - 1) : true;
+                fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
             }
             if (dbg) {
-                for (int i = 0; i < 8; i++) { p.dbg_flags[8 * t + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * t + i] = mg[i + 2]; }
-                if (t == T - 1) { p.dbg_flags[M] = 0; p.dbg_mag[M] = mg[10]; }
+                for (int i = 0; i < 8; i++) { p.dbg_flags[8 * t + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * t + i] = __uint_as_float(mg[i + 2]); }
+                if (t == T - 1) { p.dbg_flags[M] = 0; p.dbg_mag[M] = __uint_as_float(mg[10]); }
             }
             // candidate peaks travel as packed words (bin << 16 | shift & 0xFFFF), see pv_wave_kernel.hip: one 16-byte read of the shift table
             // per thread instead of a 4-way-conflicted DSH[owner] lookup per bin
-            typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
             const v4u dq = *(lds_v4u)(&DSH[8 * t]);
             int pd[8];
 #pragma unroll
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
         // ---- zero Y (pv:121) ----
 #pragma unroll
-        for (int r = 0; r < 8; r++) Y[t + T * r] = float2{0.f, 0.f};
+        for (int r = 0; r < 4; r++) *reinterpret_cast<v4f *>(&Y[2 * t + 2 * T * r]) = v4f{0.f, 0.f, 0.f, 0.f};      // four ds_write_b128 instead of eight ds_write_b64
         if (t == 0) Y[M] = float2{0.f, 0.f};
         const bool need_res = upper_end > H;
         __syncthreads();
