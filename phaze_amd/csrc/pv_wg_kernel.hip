@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     constexpr int LROWS = RING ? 0 : 8 - S_ROWS;
     constexpr int NEGPD = -(1 << 30), POSPD = 1 << 30;                    // packed (bin << 16 | shift) sentinels: no peak on this side
     constexpr int DROP = 0x4000;                                        // shift sentinel: b + DROP >= H for every bin, above every real shift
-    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int t = threadIdx.x;
     const int ch = blockIdx.y, chunk = blockIdx.x;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -436,6 +436,11 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     __syncthreads();
 
     for (int m = first_frame; m < last_out; ++m) {
+        // the thread id is made opaque once per frame: LDS addresses are recomputed from it instead of being hoisted into registers that
+        // stay live across the whole frame (see pv_wave_kernel.hip experiments): the loop then fits its register budget without spills
+        int tq = t;
+        asm volatile("" : "+v"(tq));
+        const int l = tq & 63, wv = __builtin_amdgcn_readfirstlane(tq >> 6);
         const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));   // k-rate pitchFactor (pv:47), uniform
         const double pf = (double)pfm;
         const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
@@ -445,19 +450,19 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         double2 z[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) z[r] = double2{(double)(raw[r].x * (0.5f * hw[r].x)), (double)(raw[r].y * (0.5f * hw[r].y))};
-        fft_wg<double, false, G, RING>(z, S64, TWA, TWB, TWC, t);
+        fft_wg<double, false, G, RING>(z, S64, TWA, TWB, TWC, tq);
 
-        // ---- split pass in conjugate pairs (see pv_wave_kernel.hip): thread t owns the pairs k = t + T r, r < 4, i.e. bins XA[r] = X[k] and
+        // ---- split pass in conjugate pairs (see pv_wave_kernel.hip): thread tq owns the pairs k = tq + T r, r < 4, i.e. bins XA[r] = X[k] and
         //      XB[r] = X[M - k]; thread 0 also the self-paired bin M/2.  The partner values Z[M - k] are rows 4..7 of other threads -> LDS ----
         float2 XA[4], XB[4], xHf{0.f, 0.f};
         {
 #pragma unroll
-            for (int r = 4; r < 8; r++) S64[t + T * (r - 4)] = z[r];
+            for (int r = 4; r < 8; r++) S64[tq + T * (r - 4)] = z[r];
             __syncthreads();
             double2 xa[4], xb[4], xH{0.0, 0.0};
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int k = t + T * r;
+                const int k = tq + T * r;
                 const double2 zm = (k == 0) ? z[0] : S64[4 * T - k];          // element M - k sits at (M - k) - 4T of the four stored rows
                 const double2 E{z[r].x + zm.x, z[r].y - zm.y};
                 const double2 O{z[r].x - zm.x, z[r].y + zm.y};
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 xa[r] = double2{E.x + WO.y, E.y - WO.x};
                 xb[r] = double2{E.x - WO.y, -(E.y + WO.x)};
             }
-            if (t == 0) {
+            if (tq == 0) {
                 xa[0] = double2{2.0 * (z[0].x + z[0].y), 0.0};                // X[0], X[M]: both real (bundle:447-508 keep Im = 0)
                 xb[0] = double2{2.0 * (z[0].x - z[0].y), 0.0};
                 xH = double2{2.0 * z[4].x, -2.0 * z[4].y};                    // k = M/2 pairs with itself: W^{N/4} = -j, X = 2 conj(Z)
@@ -473,26 +478,26 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             __syncthreads();                                               // partner reads done: the scratch becomes MAG / Y / ROUTE
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                MAG[4 + t + T * r] = (float)(xa[r].x * xa[r].x + xa[r].y * xa[r].y);
-                MAG[4 + M - t - T * r] = (float)(xb[r].x * xb[r].x + xb[r].y * xb[r].y);
+                MAG[4 + tq + T * r] = (float)(xa[r].x * xa[r].x + xa[r].y * xa[r].y);
+                MAG[4 + M - tq - T * r] = (float)(xb[r].x * xb[r].x + xb[r].y * xb[r].y);
                 XA[r] = float2{(float)xa[r].x, (float)xa[r].y};
                 XB[r] = float2{(float)xb[r].x, (float)xb[r].y};
             }
-            if (t == 0) MAG[4 + M / 2] = (float)(xH.x * xH.x + xH.y * xH.y);
+            if (tq == 0) MAG[4 + M / 2] = (float)(xH.x * xH.x + xH.y * xH.y);
             xHf = float2{(float)xH.x, (float)xH.y};
             if (pf < 1.0) {                                                // fp32 spectrum stash for the fast residue (Y is not live yet)
 #pragma unroll
-                for (int r = 0; r < 4; r++) { Y[t + T * r] = XA[r]; Y[M - t - T * r] = XB[r]; }
-                if (t == 0) Y[M / 2] = xHf;
+                for (int r = 0; r < 4; r++) { Y[tq + T * r] = XA[r]; Y[M - tq - T * r] = XB[r]; }
+                if (tq == 0) Y[M / 2] = xHf;
             }
             if (dbg) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int ka = t + T * r, kb = M - ka;
+                    const int ka = tq + T * r, kb = M - ka;
                     p.dbg_X[2 * ka] = xa[r].x; p.dbg_X[2 * ka + 1] = xa[r].y;
                     p.dbg_X[2 * kb] = xb[r].x; p.dbg_X[2 * kb + 1] = xb[r].y;
                 }
-                if (t == 0) { p.dbg_X[M] = xH.x; p.dbg_X[M + 1] = xH.y; }
+                if (tq == 0) { p.dbg_X[M] = xH.x; p.dbg_X[M + 1] = xH.y; }
             }
         }
         // slide the raw window; the rows the next frame adds are issued here
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 psh_valid = true;
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const int pk = t + T * r;
+                    const int pk = tq + T * r;
                     const double ps = floor((double)pk * pf + 0.5);
                     const bool ok = (ps <= (double)H) && (ps >= -(double)(2 * N));
                     DSH[pk] = ok ? (short)((int)ps - pk) : (short)DROP;             // DROP pushes every target of the region out of range
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         if (pf < 1.0) {
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int k = 1 + t + T * j;                                // k in [1, N/8]
+                const int k = 1 + tq + T * j;                                // k in [1, N/8]
                 const float2 x0 = Y[k], x1 = Y[k + M / 2], x2 = Y[M - k], x3 = Y[M / 2 - k];
                 const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
                 s2v[j] = cmul(tsum, cconj(p.tw32[2 * k]));
@@ -547,10 +552,10 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             // LDS-address-space vector loads: otherwise the optimizer re-pairs the 12 words into misaligned ds_read2_b32 (8 LDS cycles each)
             typedef const volatile __attribute__((address_space(3))) v2u *lds_v2u;
             typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
-            const v2u q0 = *(lds_v2u)(&MAG[4 + 8 * t - 2]);
-            const v4u q1 = *(lds_v4u)(&MAG[4 + 8 * t]);
-            const v4u q2 = *(lds_v4u)(&MAG[4 + 8 * t + 4]);
-            const v2u q3 = *(lds_v2u)(&MAG[4 + 8 * t + 8]);
+            const v2u q0 = *(lds_v2u)(&MAG[4 + 8 * tq - 2]);
+            const v4u q1 = *(lds_v4u)(&MAG[4 + 8 * tq]);
+            const v4u q2 = *(lds_v4u)(&MAG[4 + 8 * tq + 4]);
+            const v2u q3 = *(lds_v2u)(&MAG[4 + 8 * tq + 8]);
             mg[0] = q0.x; mg[1] = q0.y; mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w;
             mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w; mg[10] = q3.x; mg[11] = q3.y;
             unsigned pm[11];
@@ -560,20 +565,20 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 // bin k = 8t + i, candidates are 2 <= k < H - 2 (pv:97-100): thread 0 drops i < 2, the last thread drops i = 7
-                const bool in_range = (i < 2) ? (t != 0) : (i == 7) ? (t != T - 1) : true;
+                const bool in_range = (i < 2) ? (tq != 0) : (i == 7) ? (tq != T - 1) : true;
                 fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
             }
             if (dbg) {
-                for (int i = 0; i < 8; i++) { p.dbg_flags[8 * t + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * t + i] = __uint_as_float(mg[i + 2]); }
-                if (t == T - 1) { p.dbg_flags[M] = 0; p.dbg_mag[M] = __uint_as_float(mg[10]); }
+                for (int i = 0; i < 8; i++) { p.dbg_flags[8 * tq + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * tq + i] = __uint_as_float(mg[i + 2]); }
+                if (tq == T - 1) { p.dbg_flags[M] = 0; p.dbg_mag[M] = __uint_as_float(mg[10]); }
             }
             // candidate peaks travel as packed words (bin << 16 | shift & 0xFFFF), see pv_wave_kernel.hip: one 16-byte read of the shift table
             // per thread instead of a 4-way-conflicted DSH[owner] lookup per bin
-            const v4u dq = *(lds_v4u)(&DSH[8 * t]);
+            const v4u dq = *(lds_v4u)(&DSH[8 * tq]);
             int pd[8];
 #pragma unroll
             for (int i = 0; i < 8; i++)
-                pd[i] = (int)__builtin_amdgcn_perm((unsigned)(8 * t + i), dq[i >> 1], (i & 1) ? 0x05040302u : 0x05040100u);
+                pd[i] = (int)__builtin_amdgcn_perm((unsigned)(8 * tq + i), dq[i >> 1], (i & 1) ? 0x05040302u : 0x05040100u);
             int cur = NEGPD;
 #pragma unroll
             for (int i = 0; i < 8; i++) { cur = fl[i] ? pd[i] : cur; lastown[i] = cur; }
@@ -585,8 +590,8 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         // ---- nearest peaks outside this thread's byte: per-wave occupancy ballots + per-thread last/first peak, through LDS ----
         {
             const unsigned long long occ = __ballot(last_in >= 0);
-            LASTIN[t] = last_in;
-            FIRSTIN[t] = first_in;
+            LASTIN[tq] = last_in;
+            FIRSTIN[tq] = first_in;
             if (l == 0) OCC[wv] = occ;
         }
         __syncthreads();                                                   // also: every MAG read is done -> ROUTE may overwrite MAG
@@ -621,27 +626,27 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
 #pragma unroll
                 for (int i = 0; i < 8; i++) rt[i] = NOROUTE;
             } else {
-                // owner rule (pv:132-141) + shift (pv:147-152): ROUTE = ((delta * t) mod N) << 16 | target; a route is valid iff its target
-                // field is < H (pv:127-129 via DROP, pv:150-152, negative index); bits above the rotation index are don't-care
+                // owner rule (pv:132-141) + shift (pv:147-152): ROUTE = ((delta * tq) mod N) << 16 | target; a route is valid iff its target
+                // field is < H (pv:127-129 via DROP, pv:150-152, negative index); bits above the rotation index are don'tq-care
                 auto route_of = [&](int b, int pp, int pn) -> unsigned {
                     const int own = (b - (pp >> 16) < (pn >> 16) - b) ? pp : pn;     // at least one side is a real peak here
                     const int delta = __builtin_amdgcn_sbfe(own, 0, 16);
                     return __builtin_amdgcn_perm((unsigned)__mul24(delta, tmod), (unsigned)(b + delta), 0x05040100u);
                 };
 #pragma unroll
-                for (int i = 0; i < 8; i++) rt[i] = route_of(8 * t + i, max(lastown[i], cprev), min(firstown[i], cnext));
-                if (t == T - 1) rtM = route_of(M, max(last_in, cprev), POSPD);
+                for (int i = 0; i < 8; i++) rt[i] = route_of(8 * tq + i, max(lastown[i], cprev), min(firstown[i], cnext));
+                if (tq == T - 1) rtM = route_of(M, max(last_in, cprev), POSPD);
             }
-            *reinterpret_cast<uint4 *>(&ROUTE[8 * t]) = uint4{rt[0], rt[1], rt[2], rt[3]};
-            *reinterpret_cast<uint4 *>(&ROUTE[8 * t + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
-            if (t == T - 1) ROUTE[M] = rtM;
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * tq]) = uint4{rt[0], rt[1], rt[2], rt[3]};
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * tq + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
+            if (tq == T - 1) ROUTE[M] = rtM;
         }
         int upper_end = H;
         if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
         // ---- zero Y (pv:121) ----
 #pragma unroll
-        for (int r = 0; r < 4; r++) *reinterpret_cast<v4f *>(&Y[2 * t + 2 * T * r]) = v4f{0.f, 0.f, 0.f, 0.f};      // four ds_write_b128 instead of eight ds_write_b64
-        if (t == 0) Y[M] = float2{0.f, 0.f};
+        for (int r = 0; r < 4; r++) *reinterpret_cast<v4f *>(&Y[2 * tq + 2 * T * r]) = v4f{0.f, 0.f, 0.f, 0.f};      // four ds_write_b128 instead of eight ds_write_b64
+        if (tq == 0) Y[M] = float2{0.f, 0.f};
         const bool need_res = upper_end > H;
         __syncthreads();
         // ---- shiftPeaks (pv:119-173) ----
@@ -662,12 +667,12 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                     };
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const unsigned ra = ROUTE[t + T * r], ta = ra & 0xFFFFu;
-                        const unsigned rb = ROUTE[M - t - T * r], tb = rb & 0xFFFFu;
+                        const unsigned ra = ROUTE[tq + T * r], ta = ra & 0xFFFFu;
+                        const unsigned rb = ROUTE[M - tq - T * r], tb = rb & 0xFFFFu;
                         if (ta < (unsigned)H) Y[ta] = rot(ra, XA[r]);
                         if (tb < (unsigned)H) Y[tb] = rot(rb, XB[r]);
                     }
-                    if (t == 0) { const unsigned rt = ROUTE[M / 2], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, xHf); }
+                    if (tq == 0) { const unsigned rt = ROUTE[M / 2], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, xHf); }
                 };
                 if (tmod == 0) scatter(std::integral_constant<int, 0>{});
                 else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
@@ -678,28 +683,28 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 int id[9];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    id[r] = t + T * r; rt[r] = ROUTE[id[r]]; ys[r] = rotate_route<R, LOG2N>(rt[r], XA[r], p.tw32);
-                    id[4 + r] = M - t - T * r; rt[4 + r] = ROUTE[id[4 + r]]; ys[4 + r] = rotate_route<R, LOG2N>(rt[4 + r], XB[r], p.tw32);
+                    id[r] = tq + T * r; rt[r] = ROUTE[id[r]]; ys[r] = rotate_route<R, LOG2N>(rt[r], XA[r], p.tw32);
+                    id[4 + r] = M - tq - T * r; rt[4 + r] = ROUTE[id[4 + r]]; ys[4 + r] = rotate_route<R, LOG2N>(rt[4 + r], XB[r], p.tw32);
                 }
-                rt[8] = (t == 0) ? ROUTE[M / 2] : NOROUTE;
+                rt[8] = (tq == 0) ? ROUTE[M / 2] : NOROUTE;
                 ys[8] = rotate_route<R, LOG2N>(rt[8], xHf, p.tw32);
                 id[8] = M / 2;
                 __syncthreads();                                            // every ROUTE read is done: the region becomes the claim words
 #pragma unroll
-                for (int r = 0; r < 8; r++) CLAIM[t + T * r] = 0xFFFFFFFFu;
-                if (t == 0) CLAIM[M] = 0xFFFFFFFFu;
+                for (int r = 0; r < 8; r++) CLAIM[tq + T * r] = 0xFFFFFFFFu;
+                if (tq == 0) CLAIM[M] = 0xFFFFFFFFu;
                 claim_rounds_wg<9, H>(rt, ys, id, Y, CLAIM);                  // (its first barrier orders the fill before the first claims)
                 if (need_res) {
                     __syncthreads();
                     const int up_delta = (int)DSH[last_peak];
                     const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
-                    if (upper_end <= H + N / 8) {                           // sources b = H + t + T j, all owned by the last peak (pv:133)
+                    if (upper_end <= H + N / 8) {                           // sources b = H + tq + T j, all owned by the last peak (pv:133)
                         unsigned rt2[2];
                         float2 ys2[2];
                         int id2[2];
 #pragma unroll
                         for (int j = 0; j < 2; j++) {
-                            const int b = H + t + T * j, tgt = b + up_delta;
+                            const int b = H + tq + T * j, tgt = b + up_delta;
                             rt2[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
                             ys2[j] = rotate_route<R, LOG2N>(rt2[j], s2v[j], p.tw32);
                             id2[j] = b - N / 2;
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                         }
                         claim_rounds_wg<2, H>(rt2, ys2, id2, Y, CLAIM);
                     } else {
-                        residue_scatter_wg<LOG2N, R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, t, upper_end, up_delta, up_ridx,
+                        residue_scatter_wg<LOG2N, R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, tq, upper_end, up_delta, up_ridx,
                                                      dbg ? p.dbg_X : nullptr);
                     }
                 }
@@ -716,11 +721,11 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         __syncthreads();
         if (dbg) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) { const int k = t + T * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
-            if (t == 0) { p.dbg_Y[2 * M] = Y[M].x; p.dbg_Y[2 * M + 1] = Y[M].y; }
+            for (int r = 0; r < 8; r++) { const int k = tq + T * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
+            if (tq == 0) { p.dbg_Y[2 * M] = Y[M].x; p.dbg_Y[2 * M + 1] = Y[M].y; }
         }
         // ---- c2r pre-pass in conjugate pairs, packed fp32: with E = Yk + conj(Ym), O = Yk - conj(Ym), c = e^{+2 pi j k/N} O / N (m = M - k):
-        //      Z[k] = E / N + j c and Z[m] = conj(E / N - j c); thread t computes k = t + T r, r < 4, and hands Z[m] over through LDS ----
+        //      Z[k] = E / N + j c and Z[m] = conj(E / N - j c); thread tq computes k = tq + T r, r < 4, and hands Z[m] over through LDS ----
         pk::c32 zi[8];
         {
             const float sc = 1.0f / (float)N;
@@ -729,7 +734,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             pk::c32 zb[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int k = t + T * r;
+                const int k = tq + T * r;
                 pk::c32 yk = Yc[k], ym = Yc[M - k];
                 if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
                 const pk::c32 E = pk::add_conj(yk, ym), O = pk::sub_conj(yk, ym);
@@ -741,14 +746,14 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             // hand-over buffer = the residue quarter buffer (free here, disjoint from Y): element m = M - k of the packed sequence, m in (4T, 8T)
             pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem + C::OFF_RESQ);
 #pragma unroll
-            for (int r = 0; r < 4; r++) if (r > 0 || t > 0) XCH[4 * T - t - T * r] = zb[r];   // index m - 4T; (t = 0, r = 0) would be Z[M]: does not exist
+            for (int r = 0; r < 4; r++) if (r > 0 || tq > 0) XCH[4 * T - tq - T * r] = zb[r];   // index m - 4T; (tq = 0, r = 0) would be Z[M]: does not exist
             __syncthreads();
 #pragma unroll
-            for (int r = 4; r < 8; r++) zi[r] = XCH[t + T * (r - 4)];
-            if (t == 0) zi[4] = pk::c32{2.0f * yH.x * sc, -2.0f * yH.y * sc};   // the self-paired bin M/2
+            for (int r = 4; r < 8; r++) zi[r] = XCH[tq + T * (r - 4)];
+            if (tq == 0) zi[4] = pk::c32{2.0f * yH.x * sc, -2.0f * yH.y * sc};   // the self-paired bin M/2
         }
         __syncthreads();
-        fft_wg_inv_pk<G, RING>(zi, reinterpret_cast<pk::c32 *>(S32), TWA, TWB, TWC, t);
+        fft_wg_inv_pk<G, RING>(zi, reinterpret_cast<pk::c32 *>(S32), TWA, TWB, TWC, tq);
         // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
         {
             const bool emit_out = (m >= emit_v);
@@ -760,7 +765,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 // of the frame take over the slots the emitted hop freed (0 + x, ola:130-137)
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const int j = 2 * t + 2 * T * r;
+                    const int j = 2 * tq + 2 * T * r;
                     if (j < Lr) {
                         int slot = ring + j; if (slot >= Lr) slot -= Lr;
                         const float2 a = *reinterpret_cast<const float2 *>(&ACC[slot]);
@@ -776,7 +781,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 __syncthreads();
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const int j = 2 * t + 2 * T * r;
+                    const int j = 2 * tq + 2 * T * r;
                     if (j >= Lr) {
                         int slot = ring + (j - Lr); if (slot >= Lr) slot -= Lr;
                         *reinterpret_cast<float2 *>(&ACC[slot]) = fr[r];
@@ -788,7 +793,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             for (int r = 0; r < (RING ? 0 : S_ROWS); r++) {
                 const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
                 if (emit_out) {
-                    float *dst = outp + (long)m * HOP + 2 * t + 2 * T * r;
+                    float *dst = outp + (long)m * HOP + 2 * tq + 2 * T * r;
                     if (vec_out) __builtin_nontemporal_store(v2f{o.x, o.y}, reinterpret_cast<v2f *>(dst));
                     else { dst[0] = o.x; dst[1] = o.y; }
                 }
