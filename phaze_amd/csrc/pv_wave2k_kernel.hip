@@ -1,0 +1,586 @@
+// pv_wave2k_kernel.hip -- one wavefront per 2048-point frame chain: N = 2048, hop in {256, 512, 1024, 2048} (BASELINE configs[2]).
+//
+// The workgroup kernel spreads a 2048-point frame over two wavefronts and pays ~21 workgroup barriers per frame for it: its waves sit
+// parked 40 % of their life (profiles/r02_wg_pmc.md).  Here ONE wave holds the frame, 16 packed complex elements per lane, and no
+// barrier exists:
+//
+//   z[n] = xw[2n] + j xw[2n+1], n < 1024, split by parity:   ze[n'] = z[2n'],  zo[n'] = z[2n'+1]      lane l, register r <-> n' = l + 64 r
+//
+//   forward  : E = FFT512(ze), O = FFT512(zo)  (the two-transpose wave FFT of pv_wave_fft.h, one after the other through the same scratch),
+//              Z[k] = E[k] + W_1024^k O[k], Z[k + 512] = E[k] - W_1024^k O[k]  in registers (decimation in time)
+//   inverse  : A[k] = Z[k] + Z[k + 512], B[k] = (Z[k] - Z[k + 512]) e^{+2 pi j k / 1024}  in registers (decimation in frequency),
+//              ze = IFFT512(A), zo = IFFT512(B)
+//   a lane's raw / output samples of register row r are the 16 contiguous bytes 4 (l + 64 r) .. +3: float4 loads and stores
+//
+// Everything between the FFTs is the wave kernel's pipeline with 16 bins per lane (pv_wave_kernel.hip has the commentary and the reference
+// citations: split pass in conjugate pairs, |X|^2 -> v_max3_u32 peak flags, packed (bin, shift) peak words, select chains + ballot + two
+// bpermutes, one route per source bin, plain-store scatter for f >= 1, claim rounds for f < 1, fast above-Nyquist residue from the
+// spectrum, c2r pre-pass, overlap-add accumulator in registers).
+//
+// Scope: pitchFactor >= 0.75 on every frame of a launch -- then the last region never reads beyond N/2 + N/8 and the fast residue is
+// the only residue form needed.  The host decides per launch (pv_pitch_scan_kernel below sets a flag that this kernel and the workgroup
+// kernel both read: exactly one of them runs, the other returns at once); NaN, negative and small factors take the workgroup kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "pv_kernels.h"
+#include "pv_device_common.h"
+#include "pv_pk_math.h"
+#include "pv_wave_fft.h"
+
+namespace {
+
+constexpr int WAVES2 = 8;                         // frame chains per workgroup = 2 waves per SIMD (<= 256 VGPRs)
+constexpr int T2_TW1 = 0;                         // double2[8*64]  W_512^{l k}
+constexpr int T2_TW2 = T2_TW1 + 8 * 64 * 16;      // double2[8*8]   W_64^{n0 k}
+constexpr int T2_TW1F = T2_TW2 + 8 * 8 * 16;      // float4[4*64]   conj, fp32, rows k = 2j, 2j+1 interleaved
+constexpr int T2_TW2F = T2_TW1F + 4 * 64 * 16;    // float4[4*8]
+constexpr int T2_HANN = T2_TW2F + 4 * 8 * 16;     // float4[8*64]   0.5 * Hann at samples 4n'..4n'+3, n' = l + 64 r: entry [r*64 + l]
+constexpr int T2_BYTES = T2_HANN + 8 * 64 * 16;   // 22016
+
+// per-wave LDS (byte offsets)
+constexpr int O2_S = 0;                           // fp64 transpose scratch 9216 B | partner exchange | Y float2[1025] | fp32 transposes | spectrum stash (f < 1)
+constexpr int O2_ROUTE = 9216;                    // u32[1040] routes | f32 mags (alias) | u16 claim ids (alias) | c2r hand-over (alias) | i16 shift table image
+constexpr int WAVE2_LDS = O2_ROUTE + 4160;        // 13376: 22016 + 8 * 13376 = 129024 B per workgroup
+
+constexpr int N2 = 2048, M2 = 1024, H2 = 1025;
+
+// o * W_32^r = o * exp(-2 pi j r / 32), r = 0..7 (compile-time), fp64: the wave-uniform part of the split-pass twiddle
+__device__ __forceinline__ double2 mul_w32(double2 o, int r)
+{
+    constexpr double c[8] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708, 0.70710678118654752440,
+                             0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785};
+    if (r == 0) return o;
+    return cmul(o, double2{c[r], -c[8 - r]});      // sin(2 pi r / 32) = cos(2 pi (8 - r) / 32)
+}
+// o * exp(+2 pi j r / 32), packed fp32 (c2r twiddle)
+__device__ __forceinline__ pk::c32 mul_w32_inv_pk(pk::c32 o, int r)
+{
+    constexpr float c[9] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                            0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.0f};
+    if (r == 0) return o;
+    return pk::cmul(o, pk::c32{c[r], c[8 - r]});
+}
+// o * exp(+2 pi j r / 16), r = 0..7, packed fp32 (first stage of the decimation-in-frequency inverse)
+__device__ __forceinline__ pk::c32 mul_w16_inv_pk8(pk::c32 o, int r)
+{
+    constexpr float c = 0.92387953251128675613f, s = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    switch (r) {
+    case 0: return o;
+    case 1: return pk::cmul(o, pk::c32{c, s});
+    case 2: return pk::cmul(o, pk::c32{h, h});
+    case 3: return pk::cmul(o, pk::c32{s, c});
+    case 4: return pk::c32{-o.y, o.x};            // * j
+    case 5: return pk::cmul(o, pk::c32{-s, c});
+    case 6: return pk::cmul(o, pk::c32{-h, h});
+    default: return pk::cmul(o, pk::c32{-c, s});
+    }
+}
+
+// claim rounds of one wave (see pv_wave_kernel.hip): every pending source posts its id on the claim word of its target, the id that sticks
+// does a plain read-modify-write, losers retry.  LDS traffic of a wave executes in order, so the result is deterministic.
+template <int NS>
+__device__ __forceinline__ void claim_rounds2(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned short *CLAIM)
+{
+    unsigned pend = 0;
+    unsigned tg[NS];
+#pragma unroll
+    for (int r = 0; r < NS; r++) {
+        const unsigned t = rt[r] & 0xFFFFu;
+        const bool ok = t < (unsigned)H2;
+        pend |= ok ? (1u << r) : 0u;
+        tg[r] = ok ? t : 0u;
+    }
+    while (__any(pend != 0u)) {
+#pragma unroll
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[tg[r]] = (unsigned short)id[r];
+        wave_sync();
+        unsigned short c[NS];
+        float2 o[NS];
+#pragma unroll
+        for (int r = 0; r < NS; r++) c[r] = CLAIM[tg[r]];
+#pragma unroll
+        for (int r = 0; r < NS; r++) o[r] = Y[tg[r]];
+#pragma unroll
+        for (int r = 0; r < NS; r++) {
+            if ((pend & (1u << r)) && c[r] == (unsigned short)id[r]) {
+                Y[tg[r]] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
+                pend &= ~(1u << r);
+            }
+        }
+        wave_sync();
+    }
+}
+
+template <int S_ROWS>
+__global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kernel(const PvKernelParams p)
+{
+    if (p.gate && *p.gate != p.gate_value) return;                      // a frame of this launch needs the workgroup kernel (f < 0.75, NaN): it runs instead
+    constexpr int N = N2, M = M2, H = H2;
+    constexpr int HOP = 256 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long chain = (long)blockIdx.x * WAVES2 + wv;
+    const int ch = (int)(chain / p.nchunks), chunk = (int)(chain - (long)ch * p.nchunks);
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const double2 *TW1 = reinterpret_cast<const double2 *>(smem_all + T2_TW1);
+    const double2 *TW2 = reinterpret_cast<const double2 *>(smem_all + T2_TW2);
+    const v4f *TW1F4 = reinterpret_cast<const v4f *>(smem_all + T2_TW1F);
+    const v4f *TW2F4 = reinterpret_cast<const v4f *>(smem_all + T2_TW2F);
+    const v4f *HW4 = reinterpret_cast<const v4f *>(smem_all + T2_HANN);
+    {
+        double2 *t1 = reinterpret_cast<double2 *>(smem_all + T2_TW1);
+        double2 *t2 = reinterpret_cast<double2 *>(smem_all + T2_TW2);
+        float2 *t1f = reinterpret_cast<float2 *>(smem_all + T2_TW1F);
+        float2 *t2f = reinterpret_cast<float2 *>(smem_all + T2_TW2F);
+        v4f *hh = reinterpret_cast<v4f *>(smem_all + T2_HANN);
+        for (int i = threadIdx.x; i < 512; i += 64 * WAVES2) {
+            const int k = i >> 6, ln = i & 63;
+            const double2 w = p.tw64[(4 * ln * k) & (N - 1)];              // W_512^{ln k} = exp(-2 pi j ln k 4 / 2048)
+            t1[i] = w;
+            t1f[2 * ((k >> 1) * 64 + ln) + (k & 1)] = float2{(float)w.x, -(float)w.y};
+            hh[i] = v4f{0.5f * p.hann[4 * i], 0.5f * p.hann[4 * i + 1], 0.5f * p.hann[4 * i + 2], 0.5f * p.hann[4 * i + 3]};   // n' = i = ln + 64 k: row k
+            if (i < 64) {
+                const int k2 = i >> 3, n0 = i & 7;
+                const double2 w2 = p.tw64[(32 * n0 * k2) & (N - 1)];       // W_64^{n0 k2}
+                t2[i] = w2;
+                t2f[2 * ((k2 >> 1) * 8 + n0) + (k2 & 1)] = float2{(float)w2.x, -(float)w2.y};
+            }
+        }
+    }
+    __syncthreads();                                                     // the only workgroup-wide barrier
+    if (ch >= p.nch) return;
+
+    const unsigned wave_off = T2_BYTES + wv * WAVE2_LDS;
+    unsigned char *smem = smem_all + wave_off;
+    double2 *S64 = reinterpret_cast<double2 *>(smem + O2_S);
+    float2 *Y = reinterpret_cast<float2 *>(smem + O2_S);
+    float *MAG = reinterpret_cast<float *>(smem + O2_ROUTE);
+    unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + O2_ROUTE);
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + O2_ROUTE);
+    v4u dq0{0u, 0u, 0u, 0u}, dq1{0u, 0u, 0u, 0u};                       // shifts of this lane's own 16 candidate bins (i16 each)
+    unsigned psh_key = 0u;
+    bool psh_valid = false;
+
+    const int first_out = chunk * p.frames_per_chunk;
+    int last_out = first_out + p.frames_per_chunk;
+    if (last_out > p.nhops) last_out = p.nhops;
+    int first_frame = first_out - (R - 1);
+    const bool from_state = (first_frame <= 0);
+    if (from_state) first_frame = 0;
+
+    const long cbase = (long)ch * p.ch_stride;
+    const WaveSrc src{p.in + cbase, p.hist_in + (long)ch * (N - HOP), N - HOP};
+    float *outp = p.out + cbase;
+    const bool vec_out = (reinterpret_cast<uintptr_t>(outp) & 15u) == 0;
+    const bool vec_in = ((reinterpret_cast<uintptr_t>(src.in) | reinterpret_cast<uintptr_t>(src.hist)) & 15u) == 0;
+    const float *pitch_row = p.pitch + (p.pitch_stride ? (long)(ch / p.ch_per_stream) * p.pitch_stride : 0);
+
+    const double2 w1024 = p.tw64[2 * lane];                               // W_1024^l: decimation-in-time twiddle W_1024^{l + 64 r} = w1024 * W_16^r
+    const double2 w2048 = p.tw64[lane];                                   // W_2048^l: split-pass twiddle W_2048^{l + 64 r} = w2048 * W_32^r
+    constexpr float SC = 2.0f / ((float)N * (float)R);                    // 1/N of the inverse, 1/R of the overlap-add, 2 for the shared 0.5 * Hann table (exact)
+    const float2 c2048 = cconj(p.tw32[lane]), c1024 = cconj(p.tw32[2 * lane]);
+    const pk::c32 wl2048s{c2048.x * SC, c2048.y * SC};                    // c2r twiddle e^{+2 pi j l / 2048}, scale folded in
+    const pk::c32 wl1024f{c1024.x, c1024.y};                              // DIF twiddle e^{+2 pi j l / 1024}
+
+    v4f acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) acc[r] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (from_state) {
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) {
+            const float *a = p.acc_in + (long)ch * (N - HOP) + 4 * lane + 256 * r;
+            acc[r] = v4f{a[0], a[1], a[2], a[3]};
+        }
+    }
+    auto load_rows = [&](v4f *w, int frame) {
+        const long s0 = (long)(frame + 1) * HOP - N + 4 * lane;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const long sx = s0 + 256 * r;                                   // a multiple of 4: the four samples never straddle history / input
+            const float *q = sx < 0 ? src.hist + sx + src.hist_len : src.in + sx;
+            if (vec_in) w[r] = *reinterpret_cast<const v4f *>(q);
+            else w[r] = v4f{q[0], q[1], q[2], q[3]};
+        }
+    };
+    v4f raw[8];
+    load_rows(raw, first_frame);
+    float pf_next = pitch_row[first_frame];
+    int emit_v = first_out;
+    asm volatile("" : "+v"(emit_v));
+    v4f hw[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) hw[r] = HW4[r * 64 + lane];
+
+    for (int m = first_frame; m < last_out; ++m) {
+        int l = lane;
+        asm volatile("" : "+v"(l));                                       // LDS addresses are recomputed per frame instead of hoisted (see pv_wg_kernel.hip)
+        const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));
+        const double pf = (double)pfm;
+        const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
+
+        // ---- Hann (pv:55), pack by parity, two 512-point fp64 FFTs, decimation-in-time stage ----
+        double2 zlo[8], zhi[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const v4f xw = raw[r] * hw[r];
+            zlo[r] = double2{(double)xw.x, (double)xw.y};                  // ze[l + 64 r] = z[2 n']
+            zhi[r] = double2{(double)xw.z, (double)xw.w};                  // zo[l + 64 r] = z[2 n' + 1]
+        }
+        fft512_wave<double, false>(zlo, S64, TW1, TW2, l);
+        fft512_wave<double, false>(zhi, S64, TW1, TW2, l);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const double2 t = cmul(w1024, mul_w16<double, false>(zhi[r], r));
+            const double2 e = zlo[r];
+            zlo[r] = cadd(e, t);                                           // Z[l + 64 r]
+            zhi[r] = csub(e, t);                                           // Z[l + 64 r + 512]
+        }
+        // ---- split pass in conjugate pairs: k = l + 64 r pairs with M - k = element 512 + (64 - l) + 64 (7 - r), i.e. zhi[7 - r] of lane 64 - l ----
+        float2 XA[8], XB[8];                                               // X[l + 64 r], X[1024 - l - 64 r] rounded to fp32 after the decisions
+        float2 x512f{0.f, 0.f};
+        {
+#pragma unroll
+            for (int r = 0; r < 8; r++) S64[r * 64 + l] = zhi[r];
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const double2 zm = S64[(7 - r) * 64 + 64 - l];             // (l = 0, r = 0) reads one element past the rows: replaced below
+                const double2 E{zlo[r].x + zm.x, zlo[r].y - zm.y};
+                const double2 O{zlo[r].x - zm.x, zlo[r].y + zm.y};
+                const double2 WO = cmul(w2048, mul_w32(O, r));
+                double2 xa{E.x + WO.y, E.y - WO.x};
+                double2 xb{E.x - WO.y, -(E.y + WO.x)};
+                if (r == 0 && l == 0) {                                    // Z[0] is pre-halved: X[0] = 2(zr + zi), X[1024] = 2(zr - zi), both real
+                    xa = double2{2.0 * (zlo[0].x + zlo[0].y), 0.0};
+                    xb = double2{2.0 * (zlo[0].x - zlo[0].y), 0.0};
+                }
+                MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                MAG[4 + 1024 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                XA[r] = float2{(float)xa.x, (float)xa.y};
+                XB[r] = float2{(float)xb.x, (float)xb.y};
+            }
+            if (l == 0) {
+                const double2 x512{2.0 * zhi[0].x, -2.0 * zhi[0].y};        // k = 512 pairs with itself: X = 2 conj(Z[512])
+                MAG[4 + 512] = (float)(x512.x * x512.x + x512.y * x512.y);
+                x512f = float2{(float)x512.x, (float)x512.y};
+            }
+        }
+        wave_sync();
+        // ---- f < 1: above-Nyquist residue, fast form, computed while Y's space can hold a stash of the fp32 spectrum (positions N/2+1 .. N/2+N/8 of
+        //      fft.js's buffer = clean first half of the N/4-point sub-DFT of xw[4n+2]: W^{2k} S2[k] = (X[k] - X[k+N/4] + X[k+N/2] - X[k+3N/4]) / 4) ----
+        float2 s2v[4] = {float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}};
+        if (pf < 1.0) {
+            float2 *XS = reinterpret_cast<float2 *>(smem + O2_S);
+#pragma unroll
+            for (int r = 0; r < 8; r++) { XS[l + 64 * r] = XA[r]; XS[1024 - l - 64 * r] = XB[r]; }
+            if (l == 0) XS[512] = x512f;
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = 1 + l + 64 * j;                                // k in [1, 256]
+                const float2 x0 = XS[k], x1 = XS[k + 512], x2 = XS[1024 - k], x3 = XS[512 - k];
+                const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
+                s2v[j] = cmul(tsum, cconj(p.tw32[2 * k]));
+            }
+            wave_sync();
+        }
+        // ---- shift table, rebuilt only when f changes ----
+        {
+            const unsigned pfb = __float_as_uint(pfm);
+            if (!psh_valid || pfb != psh_key) {
+                psh_key = pfb; psh_valid = true;
+                // Math.round(p * f) - p (pv:125,147) of every candidate bin, DROP where the reference skips the peak (pv:127-129): lane l computes
+                // bins l + 64 r but needs bins 16l..16l+15, so the table is written as an image into the (free) scratch and 32 bytes are read back
+                short *IMG = reinterpret_cast<short *>(smem + O2_S);
+                const double pfd = (double)pfm;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int pk = l + 64 * r;
+                    const double ps = floor((double)pk * pfd + 0.5);
+                    const bool ok = (ps <= (double)H) && (ps >= -(double)(2 * N));
+                    IMG[pk] = ok ? (short)((int)ps - pk) : (short)0x4000;   // DROP pushes every target of the region out of range
+                }
+                wave_sync();
+                typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u_;
+                dq0 = *(lds_v4u_)(smem + O2_S + 32 * l);
+                dq1 = *(lds_v4u_)(smem + O2_S + 32 * l + 16);
+                wave_sync();
+            }
+        }
+        // ---- peak flags (pv:95-116) for bins 16l..16l+15, nearest peaks, one ROUTE word per source bin ----
+        int last_peak = -1, last_shift = 0;
+        {
+            unsigned mg[20];
+            typedef const volatile __attribute__((address_space(3))) v2u *lds_v2u;
+            typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
+            const v2u q0 = *(lds_v2u)(&MAG[4 + 16 * l - 2]);
+            const v4u q1 = *(lds_v4u)(&MAG[4 + 16 * l]);
+            const v4u q2 = *(lds_v4u)(&MAG[4 + 16 * l + 4]);
+            const v4u q3 = *(lds_v4u)(&MAG[4 + 16 * l + 8]);
+            const v4u q4 = *(lds_v4u)(&MAG[4 + 16 * l + 12]);
+            const v2u q5 = *(lds_v2u)(&MAG[4 + 16 * l + 16]);
+            mg[0] = q0.x; mg[1] = q0.y;
+            mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w; mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w;
+            mg[10] = q3.x; mg[11] = q3.y; mg[12] = q3.z; mg[13] = q3.w; mg[14] = q4.x; mg[15] = q4.y; mg[16] = q4.z; mg[17] = q4.w;
+            mg[18] = q5.x; mg[19] = q5.y;
+            unsigned pm[19];
+#pragma unroll
+            for (int j = 3; j < 19; j++) pm[j] = max(mg[j], mg[j + 1]);
+            bool fl[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                // candidates are 2 <= k < H - 2 = 1023 (pv:97-100): lane 0 drops i < 2, lane 63 drops i = 15
+                const bool in_range = (i < 2) ? (l != 0) : (i == 15) ? (l != 63) : true;
+                fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
+            }
+            constexpr int NEGPD = -(4096 << 16), POSPD = 8192 << 16;        // "no peak on this side"
+            int pd[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const unsigned w = (i < 8) ? dq0[i >> 1] : dq1[(i - 8) >> 1];
+                pd[i] = (int)__builtin_amdgcn_perm((unsigned)(16 * l + i), w, (i & 1) ? 0x05040302u : 0x05040100u);
+            }
+            int lastown[16], firstown[16];
+            int cur = NEGPD;
+#pragma unroll
+            for (int i = 0; i < 16; i++) { cur = fl[i] ? pd[i] : cur; lastown[i] = cur; }
+            int nx = POSPD;
+#pragma unroll
+            for (int i = 15; i >= 0; i--) { firstown[i] = nx; nx = fl[i] ? pd[i] : nx; }
+            const int last_in = cur, first_in = nx;
+            const unsigned long long occ = __ballot(cur >= 0);
+            const unsigned long long below = occ & ((1ull << l) - 1ull);
+            const unsigned long long above = (l == 63) ? 0ull : (occ >> (l + 1));
+            const int src_lo = below ? 63 - __clzll((long long)below) : 0;
+            const int src_hi = above ? l + __ffsll((long long)above) : 0;
+            int cprev = __shfl(last_in, src_lo, 64), cnext = __shfl(first_in, src_hi, 64);
+            if (!below) cprev = NEGPD;
+            if (!above) cnext = POSPD;
+            unsigned rt[16];
+            unsigned rt1024 = NOROUTE;
+            if (occ == 0ull) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) rt[i] = NOROUTE;
+            } else {
+                const int lp = __shfl(last_in, 63 - __clzll((long long)occ), 64);
+                last_peak = lp >> 16;
+                last_shift = (int)(short)(lp & 0xFFFF);
+                auto route_of = [&](int b, int pp, int pn) -> unsigned {
+                    const int own = (b - (pp >> 16) < (pn >> 16) - b) ? pp : pn;    // owner rule (pv:132-141)
+                    const int delta = __builtin_amdgcn_sbfe(own, 0, 16);
+                    return __builtin_amdgcn_perm((unsigned)__mul24(delta, tmod), (unsigned)(b + delta), 0x05040100u);
+                };
+#pragma unroll
+                for (int i = 0; i < 16; i++) rt[i] = route_of(16 * l + i, max(lastown[i], cprev), min(firstown[i], cnext));
+                if (l == 63) rt1024 = route_of(1024, max(last_in, cprev), POSPD);   // source bin N/2: owner is the last peak
+            }
+            wave_sync();                                                   // MAG is dead (in registers): ROUTE aliases it
+#pragma unroll
+            for (int j = 0; j < 4; j++) *reinterpret_cast<uint4 *>(&ROUTE[16 * l + 4 * j]) = uint4{rt[4 * j], rt[4 * j + 1], rt[4 * j + 2], rt[4 * j + 3]};
+            if (l == 63) ROUTE[1024] = rt1024;
+        }
+        (void)last_peak;
+        int upper_end = H;
+        if (last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }
+        // ---- zero Y (pv:121) ----
+#pragma unroll
+        for (int r = 0; r < 8; r++) *reinterpret_cast<v4f *>(&Y[2 * l + 128 * r]) = v4f{0.f, 0.f, 0.f, 0.f};
+        if (l == 0) Y[1024] = float2{0.f, 0.f};
+        wave_sync();
+        // ---- shiftPeaks (pv:119-173) ----
+        if (pf >= 1.0) {
+            auto scatter = [&](auto mode_tag) {
+                constexpr int MODE = decltype(mode_tag)::value;
+                auto rot = [&](unsigned rt, float2 v) -> float2 {
+                    if (MODE == 0) return v;
+                    if (MODE == 2) {
+                        const unsigned sg = (rt << 5) & 0x80000000u;         // top bit of the 11-bit rotation index = bit 26 of the route
+                        return float2{__uint_as_float(__float_as_uint(v.x) ^ sg), __uint_as_float(__float_as_uint(v.y) ^ sg)};
+                    }
+                    return rotate_route<R, 11>(rt, v, p.tw32);
+                };
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const unsigned ra = ROUTE[l + 64 * r], ta = ra & 0xFFFFu;
+                    const unsigned rb = ROUTE[1024 - l - 64 * r], tb = rb & 0xFFFFu;
+                    if (ta < (unsigned)H) Y[ta] = rot(ra, XA[r]);
+                    if (tb < (unsigned)H) Y[tb] = rot(rb, XB[r]);
+                }
+                if (l == 0) { const unsigned rt = ROUTE[512], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, x512f); }
+            };
+            if (tmod == 0) scatter(std::integral_constant<int, 0>{});
+            else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
+            else scatter(std::integral_constant<int, 1>{});
+        } else {
+            // 0.75 <= f < 1: regions compress, `+=` collisions (pv:169-170) -> claim rounds; then the residue sources b = N/2 + k, all owned by the last peak
+            unsigned rt[17];
+            float2 ys[17];
+            int id[17];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                id[r] = l + 64 * r; rt[r] = ROUTE[id[r]]; ys[r] = rotate_route<R, 11>(rt[r], XA[r], p.tw32);
+                id[8 + r] = 1024 - l - 64 * r; rt[8 + r] = ROUTE[id[8 + r]]; ys[8 + r] = rotate_route<R, 11>(rt[8 + r], XB[r], p.tw32);
+            }
+            rt[16] = (l == 0) ? ROUTE[512] : NOROUTE;
+            ys[16] = rotate_route<R, 11>(rt[16], x512f, p.tw32);
+            id[16] = 512;
+            wave_sync();                                                   // routes are in registers: CLAIM may overwrite ROUTE
+            claim_rounds2<17>(rt, ys, id, Y, CLAIM);
+            if (upper_end > H) {
+                const int up_delta = last_shift;
+                const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+                unsigned rt2[4];
+                float2 ys2[4];
+                int id2[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int b = 1024 + 1 + l + 64 * j, tgt = b + up_delta;
+                    rt2[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+                    ys2[j] = rotate_route<R, 11>(rt2[j], s2v[j], p.tw32);
+                    id2[j] = b;
+                }
+                claim_rounds2<4>(rt2, ys2, id2, Y, CLAIM);
+            }
+        }
+        wave_sync();
+        // ---- c2r pre-pass in conjugate pairs (bundle:69-76,102-114 folded), packed fp32: Zc[k] = SC ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)), m = M - k ----
+        pk::c32 zA[8], zB[8];                                              // Zc[l + 64 r], Zc[l + 64 r + 512]
+        {
+            const pk::c32 scsc{SC, SC};
+            const pk::c32 *Yc = reinterpret_cast<const pk::c32 *>(Y);
+            pk::c32 zb[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = l + 64 * r;
+                pk::c32 yk = Yc[k], ym = Yc[M - k];
+                if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
+                const pk::c32 E = pk::add_conj(yk, ym), O = pk::sub_conj(yk, ym);
+                const pk::c32 c = pk::cmul(mul_w32_inv_pk(O, r), wl2048s);
+                zA[r] = pk::fma_addj(E, scsc, c);
+                zb[r] = pk::fma_conj_subj(E, scsc, c);                        // Zc[M - k]
+            }
+            const pk::c32 y512 = Yc[512];
+            // hand-over through LDS (the route region is free): Zc[M - k] of the pair (l', r') is element 512 + (64 - l') + 64 (7 - r')
+            pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem + O2_ROUTE);
+#pragma unroll
+            for (int r = 0; r < 8; r++) XCH[r * 64 + l] = zb[r];
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 8; r++) zB[7 - r] = XCH[r * 64 + 64 - l];   // lane 0 pairs with itself one register higher; its zB[0] is the self-paired bin 512
+            if (l == 0) zB[0] = pk::c32{2.0f * y512.x * SC, -2.0f * y512.y * SC};
+        }
+        wave_sync();
+        // ---- decimation-in-frequency stage, then two 512-point packed-fp32 inverse FFTs ----
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const pk::c32 a = pk::add(zA[r], zB[r]), d = pk::sub(zA[r], zB[r]);
+            zA[r] = a;                                                     // -> z[2 n']
+            zB[r] = pk::cmul(mul_w16_inv_pk8(d, r), wl1024f);                // -> z[2 n' + 1]
+        }
+        {   // every global access of the next frame, issued here (no row is carried through the forward FFTs)
+            const int mn = (m + 1 < last_out) ? m + 1 : m;
+            load_rows(raw, mn);
+            pf_next = pitch_row[mn];
+        }
+        fft512_wave_inv_pk(zA, reinterpret_cast<pk::c32 *>(smem + O2_S), TW1F4, TW2F4, l);
+        fft512_wave_inv_pk(zB, reinterpret_cast<pk::c32 *>(smem + O2_S), TW1F4, TW2F4, l);
+        // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
+        {
+            const bool emit_out = (m >= emit_v);
+#pragma unroll
+            for (int r = 0; r < 8; r++) hw[r] = HW4[r * 64 + l];            // stays live for the next frame's analysis window
+            v4f fr[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) fr[r] = v4f{zA[r].x, zA[r].y, zB[r].x, zB[r].y} * hw[r];
+#pragma unroll
+            for (int r = 0; r < S_ROWS; r++) {
+                const v4f o = acc[r] + fr[r];
+                if (emit_out) {
+                    float *dst = outp + (long)m * HOP + 4 * l + 256 * r;
+                    if (vec_out) __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(dst));
+                    else { dst[0] = o.x; dst[1] = o.y; dst[2] = o.z; dst[3] = o.w; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < LROWS; r++) {
+                const int s = r + S_ROWS;
+                acc[r] = (s < LROWS) ? acc[s] + fr[s] : fr[s];
+            }
+        }
+    }
+
+    if (chunk == p.nchunks - 1) {
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) {
+            float *a = p.acc_out + (long)ch * (N - HOP) + 4 * lane + 256 * r;
+            a[0] = acc[r].x; a[1] = acc[r].y; a[2] = acc[r].z; a[3] = acc[r].w;
+            float *hs = p.hist_out + (long)ch * (N - HOP) + 4 * lane + 256 * r;
+            const long s = (long)p.nhops * HOP - (N - HOP) + 4 * lane + 256 * r;
+#pragma unroll
+            for (int i = 0; i < 4; i++) hs[i] = src.at(s + i);
+        }
+    }
+}
+
+// flag = 1 iff some pitchFactor of the launch is outside what pv_wave2k_kernel implements (it needs f >= 0.75 on every frame)
+__global__ void pv_pitch_scan_kernel(const float *pitch, int nhops, int nrows, int row_stride, int *flag)
+{
+    const long n = (long)nhops * nrows;
+    bool bad = false;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float f = pitch[(i / nhops) * (long)row_stride + (i % nhops)];
+        bad |= !(f >= 0.75f);                                               // NaN fails the test as well
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+template <int S_ROWS>
+hipError_t launch2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+{
+    static bool attr_done[16] = {};
+    auto k = pv_wave2k_kernel<S_ROWS>;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 15]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_wave2k_lds_bytes());
+        if (e != hipSuccess) return e;
+        attr_done[dev & 15] = true;
+    }
+    PvKernelParams q = p;
+    q.nchunks = nchunks;
+    q.nch = nch;
+    const long chains = (long)nch * nchunks;
+    hipLaunchKernelGGL(k, dim3((unsigned)((chains + WAVES2 - 1) / WAVES2), 1, 1), dim3(64 * WAVES2, 1, 1), pv_wave2k_lds_bytes(), st, q);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t pv_wave2k_lds_bytes() { return T2_BYTES + WAVES2 * WAVE2_LDS; }
+int pv_wave2k_threads() { return 64 * WAVES2; }
+bool pv_wave2k_supported(int log2n, int hop) { return log2n == 11 && (hop == 256 || hop == 512 || hop == 1024 || hop == 2048); }
+bool pv_wave2k_handles(float f) { return f >= 0.75f; }
+
+hipError_t pv_launch_pitch_scan(const float *d_pitch, int nhops, int nrows, int row_stride, int *d_flag, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
+    const long n = (long)nhops * nrows;
+    const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    hipLaunchKernelGGL(pv_pitch_scan_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, d_pitch, nhops, nrows, row_stride, d_flag);
+    return hipGetLastError();
+}
+
+hipError_t pv_launch_wave2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+{
+    switch (p.hop) {
+    case 256: return launch2k<1>(p, nch, nchunks, st);
+    case 512: return launch2k<2>(p, nch, nchunks, st);
+    case 1024: return launch2k<4>(p, nch, nchunks, st);
+    case 2048: return launch2k<8>(p, nch, nchunks, st);
+    default: return hipErrorInvalidValue;
+    }
+}
