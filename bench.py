@@ -477,6 +477,8 @@ def main():
         T8 = 1 << 17
         add("8ch", f"8-ch 48 kHz FFT=1024 hop=256 pitchFactor=1.5 (the target's phrasing), 8 ch x {T8} hops resident", 1024, 256, 8, T8,
             torch.full((T8,), 1.5, device=dev, dtype=torch.float32))
+        add("native", f"the reference's shipped configuration (phase-vocoder.js:6, ola-processor.js:3): stereo 48 kHz FFT=2048 hop=128 (16 overlaps), "
+            f"pitchFactor=1.0, 2 ch x {T3} hops resident", 2048, 128, 2, T3, torch.full((T3,), 1.0, device=dev, dtype=torch.float32))
         out["configs"] = extras
         out["latency_us"] = latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True)
 

@@ -113,15 +113,21 @@ __device__ __forceinline__ void claim_rounds2(const unsigned (&rt)[NS], const fl
     }
 }
 
-template <int S_ROWS>
+// HOPQ = hop / 128.  HOPQ >= 2: the hop is S_ROWS whole rows of 256 samples, the accumulator slides by renaming registers.  HOPQ = 1 (the reference's
+// shipped 2048 / 128, R = 16): the hop is HALF a row = 32 lanes.  Instead of moving the accumulator across lanes the kernel alternates two register
+// layouts: on even frames of a chain lane L holds samples 4L.. of its row (as always), on odd frames samples 4(L ^ 32)..; the slide is then a
+// lane-wise select between neighbouring rows, and the synthesis side of an odd frame (c2r, inverse FFTs, window) simply runs with the lane id
+// L ^ 32 -- every exchange there goes through LDS addresses, so relabelling the lanes costs nothing.
+template <int HOPQ>
 __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kernel(const PvKernelParams p)
 {
     if (p.gate && *p.gate != p.gate_value) return;                      // a frame of this launch needs the workgroup kernel (f < 0.75, NaN): it runs instead
     constexpr int N = N2, M = M2, H = H2;
-    constexpr int HOP = 256 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;
+    constexpr bool HALF = (HOPQ == 1);
+    constexpr int S_ROWS = HOPQ / 2, HOP = 128 * HOPQ, R = N / HOP, LROWS = HALF ? 8 : 8 - S_ROWS, L = N - HOP;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long chain = (long)blockIdx.x * WAVES2 + wv;
+    const long chain = (long)blockIdx.x * (blockDim.x >> 6) + wv;        // a small launch runs fewer waves per workgroup (launch2k)
     const int ch = (int)(chain / p.nchunks), chunk = (int)(chain - (long)ch * p.nchunks);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
         float2 *t1f = reinterpret_cast<float2 *>(smem_all + T2_TW1F);
         float2 *t2f = reinterpret_cast<float2 *>(smem_all + T2_TW2F);
         v4f *hh = reinterpret_cast<v4f *>(smem_all + T2_HANN);
-        for (int i = threadIdx.x; i < 512; i += 64 * WAVES2) {
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) {
             const int k = i >> 6, ln = i & 63;
             const double2 w = p.tw64[(4 * ln * k) & (N - 1)];              // W_512^{ln k} = exp(-2 pi j ln k 4 / 2048)
             t1[i] = w;
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
     if (from_state) first_frame = 0;
 
     const long cbase = (long)ch * p.ch_stride;
-    const WaveSrc src{p.in + cbase, p.hist_in + (long)ch * (N - HOP), N - HOP};
+    const WaveSrc src{p.in + cbase, p.hist_in + (long)ch * L, L};
     float *outp = p.out + cbase;
     const bool vec_out = (reinterpret_cast<uintptr_t>(outp) & 15u) == 0;
     const bool vec_in = ((reinterpret_cast<uintptr_t>(src.in) | reinterpret_cast<uintptr_t>(src.hist)) & 15u) == 0;
@@ -184,6 +190,12 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
     const float2 c2048 = cconj(p.tw32[lane]), c1024 = cconj(p.tw32[2 * lane]);
     const pk::c32 wl2048s{c2048.x * SC, c2048.y * SC};                    // c2r twiddle e^{+2 pi j l / 2048}, scale folded in
     const pk::c32 wl1024f{c1024.x, c1024.y};                              // DIF twiddle e^{+2 pi j l / 1024}
+    pk::c32 wl2048s_x = wl2048s, wl1024f_x = wl1024f;                     // the same for the lane id l ^ 32 (odd frames of the half-row hop)
+    if (HALF) {
+        const float2 d2048 = cconj(p.tw32[lane ^ 32]), d1024 = cconj(p.tw32[2 * (lane ^ 32)]);
+        wl2048s_x = pk::c32{d2048.x * SC, d2048.y * SC};
+        wl1024f_x = pk::c32{d1024.x, d1024.y};
+    }
 
     v4f acc[8];
 #pragma unroll
@@ -191,8 +203,8 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
     if (from_state) {
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
-            const float *a = p.acc_in + (long)ch * (N - HOP) + 4 * lane + 256 * r;
-            acc[r] = v4f{a[0], a[1], a[2], a[3]};
+            const float *a = p.acc_in + (long)ch * L + 4 * lane + 256 * r;
+            if (4 * lane + 256 * r < L) acc[r] = v4f{a[0], a[1], a[2], a[3]};
         }
     }
     auto load_rows = [&](v4f *w, int frame) {
@@ -220,6 +232,12 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
         const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));
         const double pf = (double)pfm;
         const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
+        const int par = HALF ? ((m - first_frame) & 1) : 0;                // accumulator layout of this frame (wave-uniform)
+        const int li = l ^ (par << 5);                                    // lane id of the synthesis side
+        if (HALF) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) hw[r] = HW4[r * 64 + l];            // the analysis window is always in the natural layout
+        }
 
         // ---- Hann (pv:55), pack by parity, two 512-point fp64 FFTs, decimation-in-time stage ----
         double2 zlo[8], zhi[8];
@@ -450,15 +468,16 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
         pk::c32 zA[8], zB[8];                                              // Zc[l + 64 r], Zc[l + 64 r + 512]
         {
             const pk::c32 scsc{SC, SC};
+            const pk::c32 w2048i = par ? wl2048s_x : wl2048s;
             const pk::c32 *Yc = reinterpret_cast<const pk::c32 *>(Y);
             pk::c32 zb[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const int k = l + 64 * r;
+                const int k = li + 64 * r;
                 pk::c32 yk = Yc[k], ym = Yc[M - k];
                 if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
                 const pk::c32 E = pk::add_conj(yk, ym), O = pk::sub_conj(yk, ym);
-                const pk::c32 c = pk::cmul(mul_w32_inv_pk(O, r), wl2048s);
+                const pk::c32 c = pk::cmul(mul_w32_inv_pk(O, r), w2048i);
                 zA[r] = pk::fma_addj(E, scsc, c);
                 zb[r] = pk::fma_conj_subj(E, scsc, c);                        // Zc[M - k]
             }
@@ -466,61 +485,88 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             // hand-over through LDS (the route region is free): Zc[M - k] of the pair (l', r') is element 512 + (64 - l') + 64 (7 - r')
             pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem + O2_ROUTE);
 #pragma unroll
-            for (int r = 0; r < 8; r++) XCH[r * 64 + l] = zb[r];
+            for (int r = 0; r < 8; r++) XCH[r * 64 + li] = zb[r];
             wave_sync();
 #pragma unroll
-            for (int r = 0; r < 8; r++) zB[7 - r] = XCH[r * 64 + 64 - l];   // lane 0 pairs with itself one register higher; its zB[0] is the self-paired bin 512
-            if (l == 0) zB[0] = pk::c32{2.0f * y512.x * SC, -2.0f * y512.y * SC};
+            for (int r = 0; r < 8; r++) zB[7 - r] = XCH[r * 64 + 64 - li];   // lane 0 pairs with itself one register higher; its zB[0] is the self-paired bin 512
+            if (li == 0) zB[0] = pk::c32{2.0f * y512.x * SC, -2.0f * y512.y * SC};
         }
         wave_sync();
         // ---- decimation-in-frequency stage, then two 512-point packed-fp32 inverse FFTs ----
+        const pk::c32 w1024i = par ? wl1024f_x : wl1024f;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const pk::c32 a = pk::add(zA[r], zB[r]), d = pk::sub(zA[r], zB[r]);
             zA[r] = a;                                                     // -> z[2 n']
-            zB[r] = pk::cmul(mul_w16_inv_pk8(d, r), wl1024f);                // -> z[2 n' + 1]
+            zB[r] = pk::cmul(mul_w16_inv_pk8(d, r), w1024i);                // -> z[2 n' + 1]
         }
         {   // every global access of the next frame, issued here (no row is carried through the forward FFTs)
             const int mn = (m + 1 < last_out) ? m + 1 : m;
             load_rows(raw, mn);
             pf_next = pitch_row[mn];
         }
-        fft512_wave_inv_pk(zA, reinterpret_cast<pk::c32 *>(smem + O2_S), TW1F4, TW2F4, l);
-        fft512_wave_inv_pk(zB, reinterpret_cast<pk::c32 *>(smem + O2_S), TW1F4, TW2F4, l);
+        fft512_wave_inv_pk(zA, reinterpret_cast<pk::c32 *>(smem + O2_S), TW1F4, TW2F4, li);
+        fft512_wave_inv_pk(zB, reinterpret_cast<pk::c32 *>(smem + O2_S), TW1F4, TW2F4, li);
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         {
             const bool emit_out = (m >= emit_v);
 #pragma unroll
-            for (int r = 0; r < 8; r++) hw[r] = HW4[r * 64 + l];            // stays live for the next frame's analysis window
+            for (int r = 0; r < 8; r++) hw[r] = HW4[r * 64 + li];           // HOPQ >= 2: stays live for the next frame's analysis window
             v4f fr[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) fr[r] = v4f{zA[r].x, zA[r].y, zB[r].x, zB[r].y} * hw[r];
+            if (HALF) {
+                // lane L holds samples 256 r + 4 (L ^ 32 par) ..: the half of the lanes with li < 32 holds the earlier half row
+                const bool early = li < 32;
+                v4f sum[9];
 #pragma unroll
-            for (int r = 0; r < S_ROWS; r++) {
-                const v4f o = acc[r] + fr[r];
-                if (emit_out) {
-                    float *dst = outp + (long)m * HOP + 4 * l + 256 * r;
-                    if (vec_out) __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(dst));
-                    else { dst[0] = o.x; dst[1] = o.y; dst[2] = o.z; dst[3] = o.w; }
+                for (int r = 0; r < 8; r++) sum[r] = acc[r] + fr[r];
+                sum[8] = v4f{0.f, 0.f, 0.f, 0.f};
+                if (emit_out && early) {
+                    float *dst = outp + (long)m * HOP + 4 * li;
+                    if (vec_out) __builtin_nontemporal_store(sum[0], reinterpret_cast<v4f *>(dst));
+                    else { dst[0] = sum[0].x; dst[1] = sum[0].y; dst[2] = sum[0].z; dst[3] = sum[0].w; }
                 }
-            }
 #pragma unroll
-            for (int r = 0; r < LROWS; r++) {
-                const int s = r + S_ROWS;
-                acc[r] = (s < LROWS) ? acc[s] + fr[s] : fr[s];
+                for (int r = 0; r < 8; r++) {                              // slide by half a row: the early half takes the next row, the layout flips
+                    acc[r].x = early ? sum[r + 1].x : sum[r].x;
+                    acc[r].y = early ? sum[r + 1].y : sum[r].y;
+                    acc[r].z = early ? sum[r + 1].z : sum[r].z;
+                    acc[r].w = early ? sum[r + 1].w : sum[r].w;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < S_ROWS; r++) {
+                    const v4f o = acc[r] + fr[r];
+                    if (emit_out) {
+                        float *dst = outp + (long)m * HOP + 4 * l + 256 * r;
+                        if (vec_out) __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(dst));
+                        else { dst[0] = o.x; dst[1] = o.y; dst[2] = o.z; dst[3] = o.w; }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < LROWS; r++) {
+                    const int s = r + S_ROWS;
+                    acc[r] = (s < LROWS) ? acc[s] + fr[s] : fr[s];
+                }
             }
         }
     }
 
     if (chunk == p.nchunks - 1) {
+        const int lend = HALF ? (lane ^ (((last_out - first_frame) & 1) << 5)) : lane;     // layout the last frame left the accumulator in
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
-            float *a = p.acc_out + (long)ch * (N - HOP) + 4 * lane + 256 * r;
-            a[0] = acc[r].x; a[1] = acc[r].y; a[2] = acc[r].z; a[3] = acc[r].w;
-            float *hs = p.hist_out + (long)ch * (N - HOP) + 4 * lane + 256 * r;
-            const long s = (long)p.nhops * HOP - (N - HOP) + 4 * lane + 256 * r;
+            if (4 * lend + 256 * r < L) {
+                float *a = p.acc_out + (long)ch * L + 4 * lend + 256 * r;
+                a[0] = acc[r].x; a[1] = acc[r].y; a[2] = acc[r].z; a[3] = acc[r].w;
+            }
+            if (4 * lane + 256 * r < L) {
+                float *hs = p.hist_out + (long)ch * L + 4 * lane + 256 * r;
+                const long s = (long)p.nhops * HOP - L + 4 * lane + 256 * r;
 #pragma unroll
-            for (int i = 0; i < 4; i++) hs[i] = src.at(s + i);
+                for (int i = 0; i < 4; i++) hs[i] = src.at(s + i);
+            }
         }
     }
 }
@@ -537,11 +583,14 @@ __global__ void pv_pitch_scan_kernel(const float *pitch, int nhops, int nrows, i
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
-template <int S_ROWS>
+#ifndef PV_W2K_WMIN
+#define PV_W2K_WMIN 2
+#endif
+template <int HOPQ>
 hipError_t launch2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
     static bool attr_done[16] = {};
-    auto k = pv_wave2k_kernel<S_ROWS>;
+    auto k = pv_wave2k_kernel<HOPQ>;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_done[dev & 15]) {
@@ -553,7 +602,13 @@ hipError_t launch2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t s
     q.nchunks = nchunks;
     q.nch = nch;
     const long chains = (long)nch * nchunks;
-    hipLaunchKernelGGL(k, dim3((unsigned)((chains + WAVES2 - 1) / WAVES2), 1, 1), dim3(64 * WAVES2, 1, 1), pv_wave2k_lds_bytes(), st, q);
+    // a streaming quantum has a handful of chains: spread them over the CUs instead of packing WAVES2 into one workgroup
+    static int cus[16] = {};
+    if (!cus[dev & 15]) { int c = 0; (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); cus[dev & 15] = c > 0 ? c : 1; }
+    long w = (chains + cus[dev & 15] - 1) / cus[dev & 15];
+    if (w < PV_W2K_WMIN) w = PV_W2K_WMIN;
+    if (w > WAVES2) w = WAVES2;
+    hipLaunchKernelGGL(k, dim3((unsigned)((chains + w - 1) / w), 1, 1), dim3(64 * (unsigned)w, 1, 1), T2_BYTES + (size_t)w * WAVE2_LDS, st, q);
     return hipGetLastError();
 }
 
@@ -561,7 +616,7 @@ hipError_t launch2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t s
 
 size_t pv_wave2k_lds_bytes() { return T2_BYTES + WAVES2 * WAVE2_LDS; }
 int pv_wave2k_threads() { return 64 * WAVES2; }
-bool pv_wave2k_supported(int log2n, int hop) { return log2n == 11 && (hop == 256 || hop == 512 || hop == 1024 || hop == 2048); }
+bool pv_wave2k_supported(int log2n, int hop) { return log2n == 11 && (hop == 128 || hop == 256 || hop == 512 || hop == 1024 || hop == 2048); }
 bool pv_wave2k_handles(float f) { return f >= 0.75f; }
 
 hipError_t pv_launch_pitch_scan(const float *d_pitch, int nhops, int nrows, int row_stride, int *d_flag, hipStream_t st)
@@ -577,10 +632,11 @@ hipError_t pv_launch_pitch_scan(const float *d_pitch, int nhops, int nrows, int 
 hipError_t pv_launch_wave2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
     switch (p.hop) {
-    case 256: return launch2k<1>(p, nch, nchunks, st);
-    case 512: return launch2k<2>(p, nch, nchunks, st);
-    case 1024: return launch2k<4>(p, nch, nchunks, st);
-    case 2048: return launch2k<8>(p, nch, nchunks, st);
+    case 128: return launch2k<1>(p, nch, nchunks, st);
+    case 256: return launch2k<2>(p, nch, nchunks, st);
+    case 512: return launch2k<4>(p, nch, nchunks, st);
+    case 1024: return launch2k<8>(p, nch, nchunks, st);
+    case 2048: return launch2k<16>(p, nch, nchunks, st);
     default: return hipErrorInvalidValue;
     }
 }

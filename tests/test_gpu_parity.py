@@ -240,11 +240,13 @@ def test_residue_fast_and_general_paths(fft, hop):
         assert np.max(np.abs(y[1])) == 0.0, "silence stays silence"
 
 
-@pytest.mark.parametrize("hop", [256, 512, 1024, 2048])
+@pytest.mark.parametrize("hop", [128, 256, 512, 1024, 2048])
 def test_wave2k_kernel_and_its_gate(hop):
     """N = 2048: one wave per frame (pv_wave2k_kernel) when every pitchFactor of the launch is >= 0.75, the workgroup kernel otherwise -- decided on
     the device per launch.  Both sides of the gate, the boundary value, collisions (0.75 <= f < 1: claim rounds + fast residue), chunking and the
-    hand-over of the carried state between the two kernels (consecutive launches of ONE handle on different sides of the gate) against the oracle."""
+    hand-over of the carried state between the two kernels (consecutive launches of ONE handle on different sides of the gate) against the oracle.
+    hop = 128 (the reference's shipped 2048/128) slides the accumulator by half a register row: launches of odd length hand the state over in
+    either of its two register layouts."""
     fft, T, nch = 2048, 36, 2
     x = np.stack([S.make_signal("tonal", c, T * hop, stream=9) for c in range(nch)])
     pv = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T)
@@ -269,8 +271,9 @@ def test_wave2k_kernel_and_its_gate(hop):
         assert np.array_equal(y, ref)
     # one stream, three launches on alternating sides of the gate: the carried state (history, accumulator, timeCursor) is the same for both kernels
     pv.reset()
-    pm = np.concatenate([np.full(12, 1.3, np.float32), np.full(12, 0.5, np.float32), np.full(12, 0.9, np.float32)])
-    parts = [pv.process_batch(x[:, i * 12 * hop:(i + 1) * 12 * hop], pm[i * 12:(i + 1) * 12]) for i in range(3)]
+    cuts = [0, 11, 24, T]
+    pm = np.concatenate([np.full(11, 1.3, np.float32), np.full(13, 0.5, np.float32), np.full(T - 24, 0.9, np.float32)])
+    parts = [pv.process_batch(x[:, a * hop:b * hop], pm[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
     pv.close()
     yo = oracle_lib.Oracle(fft, hop, nch).process_planar(x, pm)
     assert S.rms(np.concatenate(parts, axis=1).astype(np.float64) - yo) < REGRESSION_RMS
