@@ -42,8 +42,7 @@ struct pv_handle {
     int active_nch;
     bool use_wave;                               // N = 1024: wave-per-frame kernel (pv_wave_kernel.hip)
     bool use_wg;                                 // N = 2048..8192, R <= 8: register-resident workgroup kernel (pv_wg_kernel.hip)
-    bool use_wave2k;                             // N = 2048, hop 256..2048: one wave per frame (pv_wave2k_kernel.hip) for launches whose pitchFactors are all >= 0.75
-    int *d_gate;                                 // ... decided on the device per launch (pv_pitch_scan_kernel): 0 = wave2k runs, 1 = the workgroup kernel runs
+    bool use_wave2k;                             // N = 2048, hop 128..2048: one wave per frame (pv_wave2k_kernel.hip)
     char devname[64];
     char err[256];
 };
@@ -72,15 +71,13 @@ int fail_hip(pv_handle *h, hipError_t e, const char *what)
 
 bool live(const pv_handle *h) { return h && h->magic == kMagic; }
 
-enum KernelKind { K_AUTO, K_WAVE2K };
-
-int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops, KernelKind kind = K_AUTO)
+int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
 {
     if (h->frames_per_chunk_cfg > 0) return h->frames_per_chunk_cfg;
     // Trade-off: long chains amortise the (R-1)-frame halo, but the last partial round of workgroups idles the chip.
     // resident = chains the GPU runs concurrently (wave kernels: one per wave; others: LDS-limited workgroups per CU).
     long per_cu;
-    if (kind == K_WAVE2K) per_cu = pv_wave2k_threads() / 64;
+    if (h->use_wave2k) per_cu = pv_wave2k_threads() / 64;
     else if (h->use_wave) per_cu = pv_wave_threads() / 64;
     else if (h->use_wg) { per_cu = (160 * 1024) / (long)pv_wg_lds_bytes(h->log2n, h->hop); if (per_cu < 1) per_cu = 1; }
     else { per_cu = (160 * 1024) / (long)pv_kernel_lds_bytes(h->log2n, h->hop); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1; }
@@ -114,7 +111,7 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops, KernelKind kin
 
 // One launch over [nch] channel slots x [nhops] hops; flips the state ping-pong and advances timeCursor.
 int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops, long ch_stride, const float *d_pitch,
-              int pitch_stride, int ch_per_stream, bool commit, int dbg_ch, const float *host_pitch = nullptr)
+              int pitch_stride, int ch_per_stream, bool commit, int dbg_ch)
 {
     PvKernelParams p;
     memset(&p, 0, sizeof p);
@@ -131,31 +128,9 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     const int nchunks = (nhops + p.frames_per_chunk - 1) / p.frames_per_chunk;
     h->last_frames_per_chunk = p.frames_per_chunk;
     hipError_t e = hipSuccess;
-    bool done = false;
     if (h->use_wave2k && dbg_ch < 0) {
-        // N = 2048: one wave per frame when every pitchFactor of the launch is >= 0.75, the workgroup kernel otherwise.  A streaming quantum knows
-        // its factor on the host; a batch is decided on the device (scan + two gated launches, exactly one of which does the work).
-        PvKernelParams q = p;
-        q.frames_per_chunk = commit ? pick_frames_per_chunk(h, nch, nhops, K_WAVE2K) : nhops;
-        const int qchunks = (nhops + q.frames_per_chunk - 1) / q.frames_per_chunk;
-        if (host_pitch) {
-            if (pv_wave2k_handles(*host_pitch)) {
-                e = pv_launch_wave2k(q, nch, qchunks, h->stream);
-                h->last_frames_per_chunk = q.frames_per_chunk;
-                done = true;
-            }
-        } else {
-            const int nrows = pitch_stride ? (nch + p.ch_per_stream - 1) / p.ch_per_stream : 1;
-            e = pv_launch_pitch_scan(d_pitch, nhops, nrows, pitch_stride, h->d_gate, h->stream);
-            if (e != hipSuccess) return fail_hip(h, e, "pitch scan launch");
-            q.gate = h->d_gate; q.gate_value = 0;
-            e = pv_launch_wave2k(q, nch, qchunks, h->stream);
-            if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
-            h->last_frames_per_chunk = q.frames_per_chunk;
-            p.gate = h->d_gate; p.gate_value = 1;                          // the workgroup kernel below runs iff the scan found a factor wave2k does not handle
-        }
-    }
-    if (!done) {
+        e = pv_launch_wave2k(p, nch, nchunks, h->stream);
+    } else {
         if (!h->use_wave && nch > 65535) return fail(h, PV_ERR_CAPACITY, "more than 65535 channel slots in one launch (grid.y limit): split the call");
         e = h->use_wave ? pv_launch_wave(p, nch, nchunks, h->stream)
           : h->use_wg ? pv_launch_wg(h->log2n, p, nch, nchunks, h->stream)
@@ -294,8 +269,6 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         (void)hipGetLastError();
     }
     CHK(hipMalloc(&h->d_quantum, quantum));
-    CHK(hipMalloc(&h->d_gate, sizeof(int)));
-    CHK(hipMemset(h->d_gate, 0, sizeof(int)));
     CHK(hipMalloc(&h->d_dbgX, sizeof(double) * 2 * N));
     CHK(hipMalloc(&h->d_dbgMag, sizeof(float) * (N / 2 + 1)));
     CHK(hipMalloc(&h->d_dbgFlags, sizeof(int) * (N / 2 + 1)));
@@ -316,7 +289,6 @@ int pv_destroy(pv_handle *h)
     (void)hipFree(h->d_stage_in); (void)hipFree(h->d_stage_out); (void)hipFree(h->d_pitch);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     (void)hipFree(h->d_quantum);
-    (void)hipFree(h->d_gate);
     (void)hipFree(h->d_dbgX); (void)hipFree(h->d_dbgMag); (void)hipFree(h->d_dbgFlags); (void)hipFree(h->d_dbgY);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     h->magic = 0;
@@ -446,13 +418,13 @@ int pv_process(pv_handle *h, const float *const *in, float *const *out, int32_t 
     }
     if (h->d_pin_mapped) {
         float *m_in = h->d_pin_mapped + kHdrFloats, *m_out = m_in + (size_t)h->max_channels * hop;
-        const int rc = run_chain(h, m_in, m_out, nch, 1, hop, h->d_pin_mapped, 0, 1, true, -1, &pitch_factor);
+        const int rc = run_chain(h, m_in, m_out, nch, 1, hop, h->d_pin_mapped, 0, 1, true, -1);
         if (rc != PV_OK) return rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));
     } else {
         float *dq_in = h->d_quantum + kHdrFloats, *dq_out = dq_in + (size_t)h->max_channels * hop;
         HIPCHK(h, hipMemcpyAsync(h->d_quantum, h->h_pin, sizeof(float) * (kHdrFloats + (size_t)nch * hop), hipMemcpyHostToDevice, h->stream));
-        const int rc = run_chain(h, dq_in, dq_out, nch, 1, hop, h->d_quantum, 0, 1, true, -1, &pitch_factor);
+        const int rc = run_chain(h, dq_in, dq_out, nch, 1, hop, h->d_quantum, 0, 1, true, -1);
         if (rc != PV_OK) return rc;
         HIPCHK(h, hipMemcpyAsync(pin_out, dq_out, sizeof(float) * (size_t)nch * hop, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));

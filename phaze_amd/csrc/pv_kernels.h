@@ -29,10 +29,6 @@ struct PvKernelParams {
     int *dbg_flags;
     float *dbg_Y;
     int dbg_ch, dbg_frame;
-    // launch gate (N = 2048 only): the kernel runs iff gate == nullptr or *gate == gate_value.  pv_pitch_scan_kernel sets *gate = 1 when some frame of
-    // the launch needs the workgroup kernel (pitchFactor < 0.75 or NaN); pv_wave2k_kernel is launched with gate_value 0, pv_wg_kernel with 1
-    const int *gate;
-    int gate_value;
 };
 
 int pv_kernel_threads(int log2n);
@@ -47,10 +43,8 @@ hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStre
 
 // one wavefront per 2048-point frame (pv_wave2k_kernel.hip): N = 2048, hop in {256, 512, 1024, 2048}, pitchFactor >= 0.75 on every frame of the launch
 bool pv_wave2k_supported(int log2n, int hop);
-bool pv_wave2k_handles(float pitch_factor);
 size_t pv_wave2k_lds_bytes();
 int pv_wave2k_threads();
-hipError_t pv_launch_pitch_scan(const float *d_pitch, int nhops, int nrows, int row_stride, int *d_flag, hipStream_t st);
 hipError_t pv_launch_wave2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
 
 // register-resident workgroup kernel for N = 2048..8192, hop in {N/8, N/4, N/2, N} (pv_wg_kernel.hip)

@@ -1,4 +1,5 @@
-// pv_wave2k_kernel.hip -- one wavefront per 2048-point frame chain: N = 2048, hop in {256, 512, 1024, 2048} (BASELINE configs[2]).
+// pv_wave2k_kernel.hip -- one wavefront per 2048-point frame chain: N = 2048, hop in {128, 256, 512, 1024, 2048} (BASELINE configs[2] and the
+// reference's shipped 2048 / 128), every pitchFactor.
 //
 // The workgroup kernel spreads a 2048-point frame over two wavefronts and pays ~21 workgroup barriers per frame for it: its waves sit
 // parked 40 % of their life (profiles/r02_wg_pmc.md).  Here ONE wave holds the frame, 16 packed complex elements per lane, and no
@@ -17,9 +18,8 @@
 // bpermutes, one route per source bin, plain-store scatter for f >= 1, claim rounds for f < 1, fast above-Nyquist residue from the
 // spectrum, c2r pre-pass, overlap-add accumulator in registers).
 //
-// Scope: pitchFactor >= 0.75 on every frame of a launch -- then the last region never reads beyond N/2 + N/8 and the fast residue is
-// the only residue form needed.  The host decides per launch (pv_pitch_scan_kernel below sets a flag that this kernel and the workgroup
-// kernel both read: exactly one of them runs, the other returns at once); NaN, negative and small factors take the workgroup kernel.
+// f < 1 frames whose last region reads beyond N/2 + N/8 (possible below f = 0.75) rebuild the above-Nyquist residue quarter by quarter
+// (residue_scatter_2k, out of line, rare).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -42,7 +42,8 @@ constexpr int T2_BYTES = T2_HANN + 8 * 64 * 16;   // 22016
 // per-wave LDS (byte offsets)
 constexpr int O2_S = 0;                           // fp64 transpose scratch 9216 B | partner exchange | Y float2[1025] | fp32 transposes | spectrum stash (f < 1)
 constexpr int O2_ROUTE = 9216;                    // u32[1040] routes | f32 mags (alias) | u16 claim ids (alias) | c2r hand-over (alias) | i16 shift table image
-constexpr int WAVE2_LDS = O2_ROUTE + 4160;        // 13376: 22016 + 8 * 13376 = 129024 B per workgroup
+constexpr int O2_RESQ = O2_ROUTE + 4160;          // float2[512] one quarter of the above-Nyquist residue (general form only)
+constexpr int WAVE2_LDS = O2_RESQ + 4096;         // 17472: 22016 + 8 * 17472 = 161792 B per workgroup (<= 160 KB)
 
 constexpr int N2 = 2048, M2 = 1024, H2 = 1025;
 
@@ -113,6 +114,76 @@ __device__ __forceinline__ void claim_rounds2(const unsigned (&rt)[NS], const fl
     }
 }
 
+__device__ __forceinline__ int digitrev4_2k(int v, int nd)
+{
+    const unsigned r = __brev((unsigned)v) >> (32 - 2 * nd);
+    return (int)(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u));
+}
+
+// Rare path (f < 1 frames whose last region reads beyond position N/2 + N/8): what fft.js's in-place real DIT leaves at positions
+// N/2+1 .. N-1, one quarter of the buffer at a time (quarter 2 = sub-FFT of xw[4n+2], positions 1024..1535; quarter 3 = xw[4n+3], 1536..2047),
+// by re-running the reference's stage structure on that quarter in fp32 (log2 N odd: radix-2 base blocks, bundle:447-463, then the radix-4
+// stages with their predicated stores, bundle:329-441) -- and its sources, all owned by the last peak (pv:133), added into Y.  One wave, so
+// the stages are separated by wave_sync only; out of line so that its registers and its global loads stay out of the main loop.
+template <int R_>
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
+                                                                             const float2 *__restrict__ tw32, unsigned wave_off, int l, int upper_end, int up_delta,
+                                                                             unsigned up_ridx)
+{
+    constexpr int N = N2, H = H2, QN = N / 4, LOG2N = 11;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    float2 *Y = reinterpret_cast<float2 *>(smem_all + wave_off + O2_S);
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + O2_ROUTE);
+    float2 *Q = reinterpret_cast<float2 *>(smem_all + wave_off + O2_RESQ);
+    const WaveSrc src{in, hist, hist_len};
+    for (int base = N / 2; base < N && base < upper_end; base += QN) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                                      // QN / 2 = 256 radix-2 blocks per quarter; input index = base-4 digit reversal of the block
+            const int lb = l + 64 * i, blk = base / 2 + lb;
+            const int off = digitrev4_2k(blk, (LOG2N - 1) / 2);
+            const float a = src.at(s0 + off) * hann[off], b = src.at(s0 + off + N / 2) * hann[off + N / 2];
+            Q[2 * lb] = float2{a + b, 0.f};
+            Q[2 * lb + 1] = float2{a - b, 0.f};
+        }
+        wave_sync();
+        for (int log2m = 3; log2m <= LOG2N - 2; log2m += 2) {              // block sizes 8, 32, 128, 512 inside the quarter
+            const int q = (1 << log2m) >> 2, hq = q >> 1;
+            const int nblocks = QN >> log2m;
+            const int tws = LOG2N - log2m;
+            for (int t = l; t < nblocks * (hq + 1); t += 64) {             // the butterflies of a stage touch disjoint elements: any order
+                int blk, i;
+                if (t < nblocks * hq) { blk = t / hq; i = t - blk * hq; } else { blk = t - nblocks * hq; i = hq; }
+                const int o = blk << log2m;
+                const float2 A = Q[o + i];
+                const float2 Bv = cmul(Q[o + q + i], tw32[i << tws]);
+                const float2 Cc = cmul(Q[o + 2 * q + i], tw32[(2 * i) << tws]);
+                const float2 D = cmul(Q[o + 3 * q + i], tw32[(3 * i) << tws]);
+                const float2 T0 = cadd(A, Cc), T1 = csub(A, Cc), T2 = cadd(Bv, D), T3 = csub(Bv, D);
+                Q[o + i] = cadd(T0, T2);
+                Q[o + q + i] = float2{T1.x + T3.y, T1.y - T3.x};
+                if (i == 0) {
+                    Q[o + 2 * q] = csub(T0, T2);                          // bundle:400-406
+                } else if (i != hq) {                                     // bundle:409-440
+                    Q[o + q - i] = float2{T1.x - T3.y, -(T1.y + T3.x)};
+                    Q[o + 2 * q - i] = float2{T0.x - T2.x, -(T0.y - T2.y)};
+                }
+            }
+            wave_sync();
+        }
+        unsigned rt[8];
+        float2 ys[8];
+        int id[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int b = base + l + 64 * j, tgt = b + up_delta;
+            rt[j] = (b >= H && b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+            ys[j] = rotate_route<R_, 11>(rt[j], Q[l + 64 * j], tw32);
+            id[j] = b;
+        }
+        claim_rounds2<8>(rt, ys, id, Y, CLAIM);
+    }
+}
+
 // HOPQ = hop / 128.  HOPQ >= 2: the hop is S_ROWS whole rows of 256 samples, the accumulator slides by renaming registers.  HOPQ = 1 (the reference's
 // shipped 2048 / 128, R = 16): the hop is HALF a row = 32 lanes.  Instead of moving the accumulator across lanes the kernel alternates two register
 // layouts: on even frames of a chain lane L holds samples 4L.. of its row (as always), on odd frames samples 4(L ^ 32)..; the slide is then a
@@ -121,7 +192,6 @@ __device__ __forceinline__ void claim_rounds2(const unsigned (&rt)[NS], const fl
 template <int HOPQ>
 __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kernel(const PvKernelParams p)
 {
-    if (p.gate && *p.gate != p.gate_value) return;                      // a frame of this launch needs the workgroup kernel (f < 0.75, NaN): it runs instead
     constexpr int N = N2, M = M2, H = H2;
     constexpr bool HALF = (HOPQ == 1);
     constexpr int S_ROWS = HOPQ / 2, HOP = 128 * HOPQ, R = N / HOP, LROWS = HALF ? 8 : 8 - S_ROWS, L = N - HOP;
@@ -433,7 +503,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
             else scatter(std::integral_constant<int, 1>{});
         } else {
-            // 0.75 <= f < 1: regions compress, `+=` collisions (pv:169-170) -> claim rounds; then the residue sources b = N/2 + k, all owned by the last peak
+            // f < 1 (and NaN): regions compress, `+=` collisions (pv:169-170) -> claim rounds; then the residue sources b = N/2 + k, all owned by the last peak
             unsigned rt[17];
             float2 ys[17];
             int id[17];
@@ -450,17 +520,21 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             if (upper_end > H) {
                 const int up_delta = last_shift;
                 const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
-                unsigned rt2[4];
-                float2 ys2[4];
-                int id2[4];
+                if (upper_end <= H + N / 8) {                              // always when f >= 0.75; the fast form of the residue (s2v above)
+                    unsigned rt2[4];
+                    float2 ys2[4];
+                    int id2[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int b = 1024 + 1 + l + 64 * j, tgt = b + up_delta;
-                    rt2[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
-                    ys2[j] = rotate_route<R, 11>(rt2[j], s2v[j], p.tw32);
-                    id2[j] = b;
+                    for (int j = 0; j < 4; j++) {
+                        const int b = 1024 + 1 + l + 64 * j, tgt = b + up_delta;
+                        rt2[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+                        ys2[j] = rotate_route<R, 11>(rt2[j], s2v[j], p.tw32);
+                        id2[j] = b;
+                    }
+                    claim_rounds2<4>(rt2, ys2, id2, Y, CLAIM);
+                } else {
+                    residue_scatter_2k<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, wave_off, l, upper_end, up_delta, up_ridx);
                 }
-                claim_rounds2<4>(rt2, ys2, id2, Y, CLAIM);
             }
         }
         wave_sync();
@@ -571,18 +645,6 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
     }
 }
 
-// flag = 1 iff some pitchFactor of the launch is outside what pv_wave2k_kernel implements (it needs f >= 0.75 on every frame)
-__global__ void pv_pitch_scan_kernel(const float *pitch, int nhops, int nrows, int row_stride, int *flag)
-{
-    const long n = (long)nhops * nrows;
-    bool bad = false;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float f = pitch[(i / nhops) * (long)row_stride + (i % nhops)];
-        bad |= !(f >= 0.75f);                                               // NaN fails the test as well
-    }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-}
-
 #ifndef PV_W2K_WMIN
 #define PV_W2K_WMIN 2
 #endif
@@ -617,18 +679,6 @@ hipError_t launch2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t s
 size_t pv_wave2k_lds_bytes() { return T2_BYTES + WAVES2 * WAVE2_LDS; }
 int pv_wave2k_threads() { return 64 * WAVES2; }
 bool pv_wave2k_supported(int log2n, int hop) { return log2n == 11 && (hop == 128 || hop == 256 || hop == 512 || hop == 1024 || hop == 2048); }
-bool pv_wave2k_handles(float f) { return f >= 0.75f; }
-
-hipError_t pv_launch_pitch_scan(const float *d_pitch, int nhops, int nrows, int row_stride, int *d_flag, hipStream_t st)
-{
-    hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(int), st);
-    if (e != hipSuccess) return e;
-    const long n = (long)nhops * nrows;
-    const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
-    hipLaunchKernelGGL(pv_pitch_scan_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, d_pitch, nhops, nrows, row_stride, d_flag);
-    return hipGetLastError();
-}
-
 hipError_t pv_launch_wave2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
     switch (p.hop) {

@@ -352,7 +352,6 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     constexpr int LROWS = RING ? 0 : 8 - S_ROWS;
     constexpr int NEGPD = -(1 << 30), POSPD = 1 << 30;                    // packed (bin << 16 | shift) sentinels: no peak on this side
     constexpr int DROP = 0x4000;                                        // shift sentinel: b + DROP >= H for every bin, above every real shift
-    if (p.gate && *p.gate != p.gate_value) return;                        // N = 2048: pv_wave2k_kernel handles this launch (see pv_kernels.h)
     const int t = threadIdx.x;
     const int ch = blockIdx.y, chunk = blockIdx.x;
 

@@ -3,7 +3,7 @@
    profiles/<tag>_kernel_trace.md, profiles/<tag>_pmc.md (per-frame counter table of the headline kernel), profiles/<tag>_wg_pmc.md and
    profiles/hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per shape, keyed like bench.py looks them up, stamped with the kernel-source hash).
 usage: python profiles/pmc_report.py <gpurun_out/tag> <tag>"""
-import csv
+import csv, re
 import glob
 import hashlib
 import json
@@ -29,6 +29,21 @@ def counters(pattern, kernel_sub="pv_"):
             if kernel_sub in r["Kernel_Name"]:
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def dominant_counters(pattern):
+    """Counters of the kernel that does the work of a launch.  An N = 2048 launch is a pitch scan + pv_wave2k_kernel + a gated pv_wg_kernel, one of the two
+    returning at once: take the pv_* kernel (never the scan) with the largest counter total."""
+    per = {}
+    for f in glob.glob(pattern, recursive=True):
+        for r in csv.DictReader(open(f)):
+            kn = r["Kernel_Name"]
+            if "pv_" in kn and "pitch_scan" not in kn:
+                per.setdefault(kn, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if not per:
+        return {}, ""
+    name = max(per, key=lambda k: sum(sum(v) for v in per[k].values()))
+    return {k: sum(v) / len(v) for k, v in per[name].items()}, name
 
 
 def kernel_stats(d):
@@ -88,24 +103,24 @@ def main():
         calib[cn] = best
     shapes = {"c2": (1024, 256, 1, 1 << 20), "c3": (2048, 512, 2, 262144), "c4": (4096, 1024, 1024, 64), "c5": (8192, 2048, 8, 16384), "native": (2048, 128, 2, 262144)}
     for name, (fft, hop, nch, hops) in shapes.items():
-        fs, _ = counters(os.path.join(d, f"hbm_{name}_FETCH_SIZE", "**", "*counter_collection.csv"))
-        ws, _ = counters(os.path.join(d, f"hbm_{name}_WRITE_SIZE", "**", "*counter_collection.csv"))
+        fs, kname = dominant_counters(os.path.join(d, f"hbm_{name}_FETCH_SIZE", "**", "*counter_collection.csv"))
+        ws, _ = dominant_counters(os.path.join(d, f"hbm_{name}_WRITE_SIZE", "**", "*counter_collection.csv"))
         if "FETCH_SIZE" not in fs or "WRITE_SIZE" not in ws:
             continue
         fetch = fs["FETCH_SIZE"] * 1024 * 2                      # KiB, gfx950 wide-read correction (MI355X_MICROARCH.md, HBM section)
         write = ws["WRITE_SIZE"] * 1024
         alg = nch * hops * 2 * hop * 4
         tj[f"{fft}/{hop}/ch{nch}/hops{hops}"] = {"bytes_per_launch": int(fetch + write), "fetch_bytes_corrected_x2": int(fetch), "write_bytes": int(write),
-                                                  "algorithmic_bytes": alg, "traffic_over_algorithmic": (fetch + write) / alg, "csrc_sha16": sha,
+                                                  "algorithmic_bytes": alg, "traffic_over_algorithmic": (fetch + write) / alg, "kernel": (re.search(r"pv_\w+", kname) or [""])[0], "csrc_sha16": sha,
                                                   "source": f"profiles/run_profile_r02.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE (KiB) doubled per the gfx950 wide-read rule"}
     tj["_calibration"] = {"what": "torch copy_ of 1 GiB (4 dispatches) under the same counters: largest dispatch", "FETCH_SIZE_KiB": calib.get("FETCH_SIZE"),
                           "WRITE_SIZE_KiB": calib.get("WRITE_SIZE"), "expected_KiB": 1 << 20,
                           "fetch_x2_over_expected": (calib.get("FETCH_SIZE", 0) * 2) / (1 << 20), "write_over_expected": calib.get("WRITE_SIZE", 0) / (1 << 20)}
     json.dump(tj, open(tj_path, "w"), indent=1)
     # ---- workgroup kernel ----
-    lines = [f"# {tag}: workgroup kernel (pv_wg_kernel) counters per shape, per computed frame (separate --pmc passes)", ""]
-    for name in ("c3", "c3f15", "c4", "c5", "native"):
-        c, _ = counters(os.path.join(d, f"wg_{name}_*", "**", "*counter_collection.csv"), "pv_wg")
+    lines = [f"# {tag}: counters of the other shapes' kernels (pv_wave2k_kernel at N = 2048, pv_wg_kernel above), per computed frame (separate --pmc passes)", ""]
+    for name in ("c3", "c3f15", "c3f07", "c4", "c5", "native"):
+        c, kname = dominant_counters(os.path.join(d, f"wg_{name}_*", "**", "*counter_collection.csv"))
         if not c:
             continue
         try:
@@ -114,7 +129,7 @@ def main():
             R = cfg["fft"] // cfg["hop"]
             chains = -(-cfg["hops_per_step"] // cfg["frames_per_chunk"])
             frames = cfg["channels"] * (cfg["hops_per_step"] + (chains - 1) * (R - 1))
-            head = f"## {name}: {cfg['workload'][:110]} -- {j['roofline']['kernel_ms']:.3f} ms, {j['value']:.4g} frames/s, {100*j['roofline']['frac']:.2f} % of 8 TB/s"
+            head = f"## {name} (`{(re.search(r'pv_[A-Za-z0-9_]+', kname) or [''])[0]}`): {cfg['workload'][:110]} -- {j['roofline']['kernel_ms']:.3f} ms, {j['value']:.4g} frames/s, {100*j['roofline']['frac']:.2f} % of 8 TB/s"
         except Exception:
             frames, head = None, f"## {name}"
         lines += [head, "", "| counter | per dispatch | per computed frame |", "|---|---|---|"]

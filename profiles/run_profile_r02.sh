@@ -3,7 +3,7 @@
 #   1. rocprofv3 --kernel-trace --stats of the default bench command            -> gpurun_out/<tag>/trace
 #   2. separate --pmc passes of the headline workload (never with sys/hip/hsa tracing) -> gpurun_out/<tag>/pmc_<i>
 #   3. FETCH_SIZE / WRITE_SIZE passes for every BASELINE shape + a calibration copy     -> gpurun_out/<tag>/hbm_<shape>_<counter>
-#   4. LDS / VALU / wait counters of the workgroup kernel on C3, C4, C5 and the native shape -> gpurun_out/<tag>/wg_<shape>_<i>
+#   4. LDS / VALU / wait counters of the kernels of C3, C4, C5 and the native shape (pv_wave2k_kernel / pv_wg_kernel) -> gpurun_out/<tag>/wg_<shape>_<i>
 # profiles/pmc_report.py turns the CSVs into the committed summaries.
 set -u
 TAG=${1:-r02}
@@ -31,7 +31,7 @@ shape c2
 shape c3 --fft 2048 --hop 512 --channels 2 --hops 262144 --pitch 0.8
 shape c4 --fft 4096 --hop 1024 --channels 1024 --hops 64 --pitch 1.25
 shape c5 --fft 8192 --hop 2048 --channels 8 --hops 16384 --pitch 1.5
-shape native --fft 2048 --hop 128 --channels 2 --hops 262144 --pitch 1.5
+shape native --fft 2048 --hop 128 --channels 2 --hops 262144 --pitch 1.0
 # calibration: a device-to-device copy of 1 GiB (torch) under the same counters
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/hbm_calib_$c" -- python -c "
@@ -42,7 +42,7 @@ torch.cuda.synchronize()" > "$OUT/hbm_calib_$c.log" 2>&1
 done
 # workgroup kernel: LDS / VALU / wait counters per shape
 wg() { n=$1; shift; j=0
-  for grp in "SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
+  for grp in "SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" \
              "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" ; do
     j=$((j+1))
@@ -53,7 +53,8 @@ wg c3 --fft 2048 --hop 512 --channels 2 --hops 262144 --pitch 0.8
 wg c3f15 --fft 2048 --hop 512 --channels 2 --hops 262144 --pitch 1.5
 wg c4 --fft 4096 --hop 1024 --channels 1024 --hops 64 --pitch 1.25
 wg c5 --fft 8192 --hop 2048 --channels 8 --hops 16384 --pitch 1.5
-wg native --fft 2048 --hop 128 --channels 2 --hops 262144 --pitch 1.5
+wg c3f07 --fft 2048 --hop 512 --channels 2 --hops 262144 --pitch 0.7
+wg native --fft 2048 --hop 128 --channels 2 --hops 262144 --pitch 1.0
 # the machine model behind DESIGN.md section 4: instruction issue costs and LDS pipe costs at 1..4 waves per SIMD
 for mb in valu_microbench valu_microbench2 overlap_microbench; do
   [ -x $ROOT/tools/$mb ] && $ROOT/tools/$mb > "$OUT/$mb.txt" 2>&1

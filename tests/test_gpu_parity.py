@@ -241,39 +241,39 @@ def test_residue_fast_and_general_paths(fft, hop):
 
 
 @pytest.mark.parametrize("hop", [128, 256, 512, 1024, 2048])
-def test_wave2k_kernel_and_its_gate(hop):
-    """N = 2048: one wave per frame (pv_wave2k_kernel) when every pitchFactor of the launch is >= 0.75, the workgroup kernel otherwise -- decided on
-    the device per launch.  Both sides of the gate, the boundary value, collisions (0.75 <= f < 1: claim rounds + fast residue), chunking and the
-    hand-over of the carried state between the two kernels (consecutive launches of ONE handle on different sides of the gate) against the oracle.
-    hop = 128 (the reference's shipped 2048/128) slides the accumulator by half a register row: launches of odd length hand the state over in
-    either of its two register layouts."""
+def test_wave2k_kernel(hop):
+    """N = 2048: one wave per frame (pv_wave2k_kernel) for every pitchFactor.  f >= 1 (plain stores), 0.75 <= f < 1 (claim rounds + the fast residue),
+    f < 0.75 (the residue rebuilt quarter by quarter whenever the last region reads beyond N/2 + N/8), 0, negative, NaN and Inf, chunking, and
+    launches of odd length (hop = 128 slides the accumulator by half a register row: the state is handed over in either of its two layouts)."""
     fft, T, nch = 2048, 36, 2
     x = np.stack([S.make_signal("tonal", c, T * hop, stream=9) for c in range(nch)])
     pv = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T)
     assert pv.info()["kernel_name"] == "pv_wave2k_kernel"
+    ar = np.arange(T)
     for pitch in (np.full(T, 0.75, np.float32), np.full(T, 0.8, np.float32), np.full(T, 1.0, np.float32), np.full(T, 1.5, np.float32),
-                  (0.75 + 1.5 * np.arange(T) / (T - 1)).astype(np.float32),                                  # all inside the gate
-                  np.where(np.arange(T) == 17, 0.7, 1.2).astype(np.float32),                                  # ONE frame outside -> workgroup kernel
-                  np.where(np.arange(T) % 5 == 0, np.nan, 0.9).astype(np.float32)):                           # NaN -> workgroup kernel
+                  np.full(T, 0.5, np.float32), np.full(T, 0.3, np.float32), np.full(T, 0.62, np.float32), np.full(T, 2.0, np.float32),
+                  (0.4 + 1.85 * ar / (T - 1)).astype(np.float32),
+                  np.where(ar == 17, 0.7, 1.2).astype(np.float32),
+                  np.where(ar % 5 == 0, np.nan, 0.9).astype(np.float32),
+                  np.where(ar % 7 == 3, 0.0, np.where(ar % 7 == 5, -0.6, 0.55)).astype(np.float32),
+                  np.where(ar % 4 == 1, np.inf, 0.45).astype(np.float32)):
         pv.reset()
         y = pv.process_batch(x, pitch)
         yo = oracle_lib.Oracle(fft, hop, nch).process_planar(x, pitch)
         assert np.all(np.isfinite(y))
-        assert S.rms(y.astype(np.float64) - yo) < REGRESSION_RMS
-    # chunked == unchunked bit for bit inside the gate
-    p = np.full(T, 0.85, np.float32)
-    ref = None
-    for F in (T, 5, 11):
-        h = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T, frames_per_chunk=F)
-        y = h.process_batch(x, p)
-        h.close()
-        ref = y if ref is None else ref
-        assert np.array_equal(y, ref)
-    # one stream, three launches on alternating sides of the gate: the carried state (history, accumulator, timeCursor) is the same for both kernels
-    pv.reset()
-    cuts = [0, 11, 24, T]
-    pm = np.concatenate([np.full(11, 1.3, np.float32), np.full(13, 0.5, np.float32), np.full(T - 24, 0.9, np.float32)])
-    parts = [pv.process_batch(x[:, a * hop:b * hop], pm[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert S.rms(y.astype(np.float64) - yo) < REGRESSION_RMS, pitch[:6]
+    # chunked == unchunked == call-split bit for bit, on both residue forms
+    for f in (0.85, 0.55):
+        p = np.full(T, f, np.float32)
+        ref = None
+        for F in (T, 5, 11):
+            h = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T, frames_per_chunk=F)
+            y = h.process_batch(x, p)
+            h.close()
+            ref = y if ref is None else ref
+            assert np.array_equal(y, ref)
+        pv.reset()
+        cuts = [0, 11, 24, T]
+        parts = [pv.process_batch(x[:, a * hop:b * hop], p[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts, axis=1), ref)
     pv.close()
-    yo = oracle_lib.Oracle(fft, hop, nch).process_planar(x, pm)
-    assert S.rms(np.concatenate(parts, axis=1).astype(np.float64) - yo) < REGRESSION_RMS
