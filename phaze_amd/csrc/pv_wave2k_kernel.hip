@@ -37,13 +37,14 @@ constexpr int T2_TW2 = T2_TW1 + 8 * 64 * 16;      // double2[8*8]   W_64^{n0 k}
 constexpr int T2_TW1F = T2_TW2 + 8 * 8 * 16;      // float4[4*64]   conj, fp32, rows k = 2j, 2j+1 interleaved
 constexpr int T2_TW2F = T2_TW1F + 4 * 64 * 16;    // float4[4*8]
 constexpr int T2_HANN = T2_TW2F + 4 * 8 * 16;     // float4[8*64]   0.5 * Hann at samples 4n'..4n'+3, n' = l + 64 r: entry [r*64 + l]
-constexpr int T2_BYTES = T2_HANN + 8 * 64 * 16;   // 22016
+constexpr int T2_ROT = T2_HANN + 8 * 64 * 16;     // float2[16]     exp(+2 pi j q / 16): the rotations of pv:155-170 when the hop is N / 8 or N / 16 (R = 8, 16)
+constexpr int T2_BYTES = T2_ROT + 16 * 8;         // 22144
 
 // per-wave LDS (byte offsets)
 constexpr int O2_S = 0;                           // fp64 transpose scratch 9216 B | partner exchange | Y float2[1025] | fp32 transposes | spectrum stash (f < 1)
 constexpr int O2_ROUTE = 9216;                    // u32[1040] routes | f32 mags (alias) | u16 claim ids (alias) | c2r hand-over (alias) | i16 shift table image
 constexpr int O2_RESQ = O2_ROUTE + 4160;          // float2[512] one quarter of the above-Nyquist residue (general form only)
-constexpr int WAVE2_LDS = O2_RESQ + 4096;         // 17472: 22016 + 8 * 17472 = 161792 B per workgroup (<= 160 KB)
+constexpr int WAVE2_LDS = O2_RESQ + 4096;         // 17472: 22144 + 8 * 17472 = 161920 B per workgroup (<= 160 KB)
 
 constexpr int N2 = 2048, M2 = 1024, H2 = 1025;
 
@@ -81,7 +82,10 @@ __device__ __forceinline__ pk::c32 mul_w16_inv_pk8(pk::c32 o, int r)
 
 // claim rounds of one wave (see pv_wave_kernel.hip): every pending source posts its id on the claim word of its target, the id that sticks
 // does a plain read-modify-write, losers retry.  LDS traffic of a wave executes in order, so the result is deterministic.
-template <int NS>
+// (Measured and rejected: two ds_add_f32 per source instead of the rounds -- an LDS float atomic costs ~180 CU-cycles per wave instruction on
+// gfx950, the f = 0.8 frame went from 3.8 to 9.1 ms per launch.)
+// FRESH: Y is all zeros on entry (the frame's first scatter): the winners of the first round store their value without reading Y.
+template <int NS, bool FRESH = false>
 __device__ __forceinline__ void claim_rounds2(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned short *CLAIM)
 {
     unsigned pend = 0;
@@ -92,6 +96,22 @@ __device__ __forceinline__ void claim_rounds2(const unsigned (&rt)[NS], const fl
         const bool ok = t < (unsigned)H2;
         pend |= ok ? (1u << r) : 0u;
         tg[r] = ok ? t : 0u;
+    }
+    if (FRESH) {
+#pragma unroll
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[tg[r]] = (unsigned short)id[r];
+        wave_sync();
+        unsigned short c[NS];
+#pragma unroll
+        for (int r = 0; r < NS; r++) c[r] = CLAIM[tg[r]];
+#pragma unroll
+        for (int r = 0; r < NS; r++) {
+            if ((pend & (1u << r)) && c[r] == (unsigned short)id[r]) {
+                Y[tg[r]] = ys[r];
+                pend &= ~(1u << r);
+            }
+        }
+        wave_sync();
     }
     while (__any(pend != 0u)) {
 #pragma unroll
@@ -112,6 +132,20 @@ __device__ __forceinline__ void claim_rounds2(const unsigned (&rt)[NS], const fl
         }
         wave_sync();
     }
+}
+
+// Rotation exp(+2 pi j ridx / N) of one source value (pv:155-170): ridx = (delta * t) mod N is a multiple of N / R.  R = 4 is rotate_route's
+// swap-and-sign form; R = 8 and 16 read the root from a 16-entry LDS table (a global table load would sit on the critical path of every frame).
+template <int R_>
+__device__ __forceinline__ float2 rotate2k(unsigned route, float2 v, const float2 *ROT)
+{
+    if (R_ == 1) return v;
+    if (R_ == 2) {
+        const unsigned sg = (route << 5) & 0x80000000u;                     // top bit of the 11-bit rotation index = bit 26 of the route
+        return float2{__uint_as_float(__float_as_uint(v.x) ^ sg), __uint_as_float(__float_as_uint(v.y) ^ sg)};
+    }
+    if (R_ == 4) return rotate_route<4, 11>(route, v, nullptr);
+    return cmul(v, ROT[(route >> 23) & 15u]);                              // bits 23..26 of the route = top four bits of the rotation index
 }
 
 __device__ __forceinline__ int digitrev4_2k(int v, int nd)
@@ -177,7 +211,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(cons
         for (int j = 0; j < 8; j++) {
             const int b = base + l + 64 * j, tgt = b + up_delta;
             rt[j] = (b >= H && b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
-            ys[j] = rotate_route<R_, 11>(rt[j], Q[l + 64 * j], tw32);
+            ys[j] = rotate2k<R_>(rt[j], Q[l + 64 * j], reinterpret_cast<const float2 *>(smem_all + T2_ROT));
             id[j] = b;
         }
         claim_rounds2<8>(rt, ys, id, Y, CLAIM);
@@ -206,6 +240,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
     const v4f *TW1F4 = reinterpret_cast<const v4f *>(smem_all + T2_TW1F);
     const v4f *TW2F4 = reinterpret_cast<const v4f *>(smem_all + T2_TW2F);
     const v4f *HW4 = reinterpret_cast<const v4f *>(smem_all + T2_HANN);
+    const float2 *ROT = reinterpret_cast<const float2 *>(smem_all + T2_ROT);
     {
         double2 *t1 = reinterpret_cast<double2 *>(smem_all + T2_TW1);
         double2 *t2 = reinterpret_cast<double2 *>(smem_all + T2_TW2);
@@ -218,6 +253,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             t1[i] = w;
             t1f[2 * ((k >> 1) * 64 + ln) + (k & 1)] = float2{(float)w.x, -(float)w.y};
             hh[i] = v4f{0.5f * p.hann[4 * i], 0.5f * p.hann[4 * i + 1], 0.5f * p.hann[4 * i + 2], 0.5f * p.hann[4 * i + 3]};   // n' = i = ln + 64 k: row k
+            if (i < 16) reinterpret_cast<float2 *>(smem_all + T2_ROT)[i] = cconj(p.tw32[(i * (N / 16)) & (N - 1)]);
             if (i < 64) {
                 const int k2 = i >> 3, n0 = i & 7;
                 const double2 w2 = p.tw64[(32 * n0 * k2) & (N - 1)];       // W_64^{n0 k2}
@@ -488,7 +524,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
                         const unsigned sg = (rt << 5) & 0x80000000u;         // top bit of the 11-bit rotation index = bit 26 of the route
                         return float2{__uint_as_float(__float_as_uint(v.x) ^ sg), __uint_as_float(__float_as_uint(v.y) ^ sg)};
                     }
-                    return rotate_route<R, 11>(rt, v, p.tw32);
+                    return rotate2k<R>(rt, v, ROT);
                 };
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
@@ -509,11 +545,11 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             int id[17];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                id[r] = l + 64 * r; rt[r] = ROUTE[id[r]]; ys[r] = rotate_route<R, 11>(rt[r], XA[r], p.tw32);
-                id[8 + r] = 1024 - l - 64 * r; rt[8 + r] = ROUTE[id[8 + r]]; ys[8 + r] = rotate_route<R, 11>(rt[8 + r], XB[r], p.tw32);
+                id[r] = l + 64 * r; rt[r] = ROUTE[id[r]]; ys[r] = rotate2k<R>(rt[r], XA[r], ROT);
+                id[8 + r] = 1024 - l - 64 * r; rt[8 + r] = ROUTE[id[8 + r]]; ys[8 + r] = rotate2k<R>(rt[8 + r], XB[r], ROT);
             }
             rt[16] = (l == 0) ? ROUTE[512] : NOROUTE;
-            ys[16] = rotate_route<R, 11>(rt[16], x512f, p.tw32);
+            ys[16] = rotate2k<R>(rt[16], x512f, ROT);
             id[16] = 512;
             wave_sync();                                                   // routes are in registers: CLAIM may overwrite ROUTE
             claim_rounds2<17>(rt, ys, id, Y, CLAIM);
@@ -528,7 +564,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
                     for (int j = 0; j < 4; j++) {
                         const int b = 1024 + 1 + l + 64 * j, tgt = b + up_delta;
                         rt2[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
-                        ys2[j] = rotate_route<R, 11>(rt2[j], s2v[j], p.tw32);
+                        ys2[j] = rotate2k<R>(rt2[j], s2v[j], ROT);
                         id2[j] = b;
                     }
                     claim_rounds2<4>(rt2, ys2, id2, Y, CLAIM);
