@@ -42,11 +42,18 @@ constexpr int T2_BYTES = T2_ROT + 16 * 8;         // 22144
 
 // per-wave LDS (byte offsets)
 constexpr int O2_S = 0;                           // fp64 transpose scratch 9216 B | partner exchange | Y float2[1025] | fp32 transposes | spectrum stash (f < 1)
-constexpr int O2_ROUTE = 9216;                    // u32[1040] routes | f32 mags (alias) | u16 claim ids (alias) | c2r hand-over (alias) | i16 shift table image
+constexpr int O2_ROUTE = 9216;                    // routes u32 | f32 mags (alias) -- both in the padded layout below, running on into RESQ -- | u16 claim ids (alias) | c2r hand-over (alias)
 constexpr int O2_RESQ = O2_ROUTE + 4160;          // float2[512] one quarter of the above-Nyquist residue (general form only)
 constexpr int WAVE2_LDS = O2_RESQ + 4096;         // 17472: 22144 + 8 * 17472 = 161920 B per workgroup (<= 160 KB)
 
 constexpr int N2 = 2048, M2 = 1024, H2 = 1025;
+
+// Magnitudes and routes are written bin-major by the FFT's layout (lane l <-> bins l + 64 r) and read / written 16 consecutive bins per lane by the
+// peak search: at a lane stride of 64 B the latter are 4- to 8-way bank conflicts.  Both arrays therefore live in a padded layout, every group
+// of 16 bins followed by 4 unused words: P(bin) = bin + 4 (bin >> 4).  A lane's 16 bins start at word 20 l (80 B stride: the 16 lanes of a
+// b128 pass cover the 64 banks exactly once), and the bin-major side only sees 2-way conflicts on 12 banks.
+//   P(l + 64 r) = pl + 80 r, pl = l + 4 (l >> 4);   P(1024 - l - 64 r) = 1280 - ql - 80 r, ql = l + 4 ((l + 15) >> 4);   P(512) = 640, P(1024) = 1280
+constexpr int MAG0 = 8;                           // magnitudes start 8 words in: bins -2, -1 of lane 0's window stay inside the region
 
 // o * W_32^r = o * exp(-2 pi j r / 32), r = 0..7 (compile-time), fp64: the wave-uniform part of the split-pass twiddle
 __device__ __forceinline__ double2 mul_w32(double2 o, int r)
@@ -338,6 +345,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
         const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));
         const double pf = (double)pfm;
         const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
+        const int pl = l + 4 * (l >> 4), ql = l + 4 * ((l + 15) >> 4);     // padded positions of the bins this lane's FFT registers hold (see P above)
         const int par = HALF ? ((m - first_frame) & 1) : 0;                // accumulator layout of this frame (wave-uniform)
         const int li = l ^ (par << 5);                                    // lane id of the synthesis side
         if (HALF) {
@@ -381,14 +389,14 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
                     xa = double2{2.0 * (zlo[0].x + zlo[0].y), 0.0};
                     xb = double2{2.0 * (zlo[0].x - zlo[0].y), 0.0};
                 }
-                MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
-                MAG[4 + 1024 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                MAG[MAG0 + pl + 80 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                MAG[MAG0 + 1280 - ql - 80 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
                 XA[r] = float2{(float)xa.x, (float)xa.y};
                 XB[r] = float2{(float)xb.x, (float)xb.y};
             }
             if (l == 0) {
                 const double2 x512{2.0 * zhi[0].x, -2.0 * zhi[0].y};        // k = 512 pairs with itself: X = 2 conj(Z[512])
-                MAG[4 + 512] = (float)(x512.x * x512.x + x512.y * x512.y);
+                MAG[MAG0 + 640] = (float)(x512.x * x512.x + x512.y * x512.y);
                 x512f = float2{(float)x512.x, (float)x512.y};
             }
         }
@@ -440,12 +448,12 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             unsigned mg[20];
             typedef const volatile __attribute__((address_space(3))) v2u *lds_v2u;
             typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
-            const v2u q0 = *(lds_v2u)(&MAG[4 + 16 * l - 2]);
-            const v4u q1 = *(lds_v4u)(&MAG[4 + 16 * l]);
-            const v4u q2 = *(lds_v4u)(&MAG[4 + 16 * l + 4]);
-            const v4u q3 = *(lds_v4u)(&MAG[4 + 16 * l + 8]);
-            const v4u q4 = *(lds_v4u)(&MAG[4 + 16 * l + 12]);
-            const v2u q5 = *(lds_v2u)(&MAG[4 + 16 * l + 16]);
+            const v2u q0 = *(lds_v2u)(&MAG[MAG0 + 20 * l - 6]);            // bins 16 l - 2, 16 l - 1: the tail of the previous group
+            const v4u q1 = *(lds_v4u)(&MAG[MAG0 + 20 * l]);
+            const v4u q2 = *(lds_v4u)(&MAG[MAG0 + 20 * l + 4]);
+            const v4u q3 = *(lds_v4u)(&MAG[MAG0 + 20 * l + 8]);
+            const v4u q4 = *(lds_v4u)(&MAG[MAG0 + 20 * l + 12]);
+            const v2u q5 = *(lds_v2u)(&MAG[MAG0 + 20 * l + 20]);           // bins 16 l + 16, 16 l + 17: the head of the next group
             mg[0] = q0.x; mg[1] = q0.y;
             mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w; mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w;
             mg[10] = q3.x; mg[11] = q3.y; mg[12] = q3.z; mg[13] = q3.w; mg[14] = q4.x; mg[15] = q4.y; mg[16] = q4.z; mg[17] = q4.w;
@@ -503,8 +511,8 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             }
             wave_sync();                                                   // MAG is dead (in registers): ROUTE aliases it
 #pragma unroll
-            for (int j = 0; j < 4; j++) *reinterpret_cast<uint4 *>(&ROUTE[16 * l + 4 * j]) = uint4{rt[4 * j], rt[4 * j + 1], rt[4 * j + 2], rt[4 * j + 3]};
-            if (l == 63) ROUTE[1024] = rt1024;
+            for (int j = 0; j < 4; j++) *reinterpret_cast<uint4 *>(&ROUTE[20 * l + 4 * j]) = uint4{rt[4 * j], rt[4 * j + 1], rt[4 * j + 2], rt[4 * j + 3]};
+            if (l == 63) ROUTE[1280] = rt1024;
         }
         (void)last_peak;
         int upper_end = H;
@@ -528,12 +536,12 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
                 };
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const unsigned ra = ROUTE[l + 64 * r], ta = ra & 0xFFFFu;
-                    const unsigned rb = ROUTE[1024 - l - 64 * r], tb = rb & 0xFFFFu;
+                    const unsigned ra = ROUTE[pl + 80 * r], ta = ra & 0xFFFFu;
+                    const unsigned rb = ROUTE[1280 - ql - 80 * r], tb = rb & 0xFFFFu;
                     if (ta < (unsigned)H) Y[ta] = rot(ra, XA[r]);
                     if (tb < (unsigned)H) Y[tb] = rot(rb, XB[r]);
                 }
-                if (l == 0) { const unsigned rt = ROUTE[512], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, x512f); }
+                if (l == 0) { const unsigned rt = ROUTE[640], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, x512f); }
             };
             if (tmod == 0) scatter(std::integral_constant<int, 0>{});
             else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
@@ -545,10 +553,10 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             int id[17];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                id[r] = l + 64 * r; rt[r] = ROUTE[id[r]]; ys[r] = rotate2k<R>(rt[r], XA[r], ROT);
-                id[8 + r] = 1024 - l - 64 * r; rt[8 + r] = ROUTE[id[8 + r]]; ys[8 + r] = rotate2k<R>(rt[8 + r], XB[r], ROT);
+                id[r] = l + 64 * r; rt[r] = ROUTE[pl + 80 * r]; ys[r] = rotate2k<R>(rt[r], XA[r], ROT);
+                id[8 + r] = 1024 - l - 64 * r; rt[8 + r] = ROUTE[1280 - ql - 80 * r]; ys[8 + r] = rotate2k<R>(rt[8 + r], XB[r], ROT);
             }
-            rt[16] = (l == 0) ? ROUTE[512] : NOROUTE;
+            rt[16] = (l == 0) ? ROUTE[640] : NOROUTE;
             ys[16] = rotate2k<R>(rt[16], x512f, ROT);
             id[16] = 512;
             wave_sync();                                                   // routes are in registers: CLAIM may overwrite ROUTE
