@@ -58,11 +58,13 @@ typedef struct pv_config {
 } pv_config;
 
 /* pv_config.flags: explicit A/B switches for tests and measurements (the library reads NO environment
- * variables).  Both select complete, parity-tested implementations of the same path. */
+ * variables).  All select complete, parity-tested implementations of the same path. */
 enum {
     PV_FLAG_GENERIC_KERNEL = 1, /* always launch the LDS-staged fallback kernel (pv_chain_kernel)        */
-    PV_FLAG_STREAM_COPY = 2     /* streaming quantum through H2D + kernel + D2H copies instead of the
+    PV_FLAG_STREAM_COPY = 2,    /* streaming quantum through H2D + kernel + D2H copies instead of the
                                  * zero-copy mapping of the pinned staging buffer                         */
+    PV_FLAG_WORKGROUP_KERNEL = 4 /* N = 2048 / 4096: the workgroup-per-frame kernel (pv_wg_kernel) instead of the
+                                  * one-wave (pv_wave2k_kernel) / wave-pair (pv_pair_kernel) kernels      */
 };
 
 typedef struct pv_info {

@@ -35,7 +35,7 @@ class _Config(C.Structure):
 
 
 # pv_config.flags (include/phaze_amd.h): explicit A/B switches; the library reads no environment variables
-FLAG_GENERIC_KERNEL, FLAG_STREAM_COPY = 1, 2
+FLAG_GENERIC_KERNEL, FLAG_STREAM_COPY, FLAG_WORKGROUP_KERNEL = 1, 2, 4
 
 
 class _Info(C.Structure):

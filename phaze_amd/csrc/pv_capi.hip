@@ -43,6 +43,7 @@ struct pv_handle {
     bool use_wave;                               // N = 1024: wave-per-frame kernel (pv_wave_kernel.hip)
     bool use_wg;                                 // N = 2048..8192, R <= 8: register-resident workgroup kernel (pv_wg_kernel.hip)
     bool use_wave2k;                             // N = 2048, hop 128..2048: one wave per frame (pv_wave2k_kernel.hip)
+    bool use_pair;                               // N = 4096, hop 512..4096: a pair of waves per frame (pv_pair_kernel.hip)
     char devname[64];
     char err[256];
 };
@@ -78,6 +79,7 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
     // resident = chains the GPU runs concurrently (wave kernels: one per wave; others: LDS-limited workgroups per CU).
     long per_cu;
     if (h->use_wave2k) per_cu = pv_wave2k_threads() / 64;
+    else if (h->use_pair) per_cu = (160 * 1024) / (long)pv_pair_lds_bytes();
     else if (h->use_wave) per_cu = pv_wave_threads() / 64;
     else if (h->use_wg) { per_cu = (160 * 1024) / (long)pv_wg_lds_bytes(h->log2n, h->hop); if (per_cu < 1) per_cu = 1; }
     else { per_cu = (160 * 1024) / (long)pv_kernel_lds_bytes(h->log2n, h->hop); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1; }
@@ -130,6 +132,8 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     hipError_t e = hipSuccess;
     if (h->use_wave2k && dbg_ch < 0) {
         e = pv_launch_wave2k(p, nch, nchunks, h->stream);
+    } else if (h->use_pair && dbg_ch < 0) {
+        e = pv_launch_pair(p, nch, nchunks, h->stream);
     } else {
         if (!h->use_wave && nch > 65535) return fail(h, PV_ERR_CAPACITY, "more than 65535 channel slots in one launch (grid.y limit): split the call");
         e = h->use_wave ? pv_launch_wave(p, nch, nchunks, h->stream)
@@ -207,7 +211,9 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         const bool generic = (cfg->flags & PV_FLAG_GENERIC_KERNEL) != 0;      // explicit A/B switch (tests, measurements); no environment is read
         h->use_wave = pv_wave_supported(log2n, hop) && !generic;
         h->use_wg = pv_wg_supported(log2n, hop) && !generic;
-        h->use_wave2k = h->use_wg && pv_wave2k_supported(log2n, hop);
+        const bool wg_only = (cfg->flags & PV_FLAG_WORKGROUP_KERNEL) != 0;    // A/B: the workgroup kernel where a one-wave / wave-pair kernel exists
+        h->use_wave2k = h->use_wg && !wg_only && pv_wave2k_supported(log2n, hop);
+        h->use_pair = h->use_wg && !wg_only && pv_pair_supported(log2n, hop);
     }
 
 #define CHK(call)                                                          \
@@ -303,10 +309,10 @@ int pv_get_info(const pv_handle *h, pv_info *out)
     memset(out, 0, sizeof *out);
     out->fft_size = h->N; out->hop_size = h->hop; out->overlaps = h->R;
     out->max_channels = h->max_channels; out->max_hops = h->max_hops;
-    out->threads_per_workgroup = h->use_wave ? pv_wave_threads() : h->use_wave2k ? pv_wave2k_threads() : h->use_wg ? pv_wg_threads(h->log2n) : pv_kernel_threads(h->log2n);
+    out->threads_per_workgroup = h->use_wave ? pv_wave_threads() : h->use_wave2k ? pv_wave2k_threads() : h->use_pair ? pv_pair_threads() : h->use_wg ? pv_wg_threads(h->log2n) : pv_kernel_threads(h->log2n);
     snprintf(out->kernel_name, sizeof out->kernel_name, "%s",
-             h->use_wave ? "pv_wave_kernel_1024" : h->use_wave2k ? "pv_wave2k_kernel" : h->use_wg ? "pv_wg_kernel" : "pv_chain_kernel");
-    out->lds_bytes_per_workgroup = (int32_t)(h->use_wave ? pv_wave_lds_bytes() : h->use_wave2k ? pv_wave2k_lds_bytes()
+             h->use_wave ? "pv_wave_kernel_1024" : h->use_wave2k ? "pv_wave2k_kernel" : h->use_pair ? "pv_pair_kernel" : h->use_wg ? "pv_wg_kernel" : "pv_chain_kernel");
+    out->lds_bytes_per_workgroup = (int32_t)(h->use_wave ? pv_wave_lds_bytes() : h->use_wave2k ? pv_wave2k_lds_bytes() : h->use_pair ? pv_pair_lds_bytes()
                                              : h->use_wg ? pv_wg_lds_bytes(h->log2n, h->hop) : pv_kernel_lds_bytes(h->log2n, h->hop));
     out->frames_per_chunk = h->last_frames_per_chunk;
     out->compute_units = h->cus; out->device_id = h->device;

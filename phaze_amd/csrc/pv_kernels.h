@@ -52,3 +52,9 @@ bool pv_wg_supported(int log2n, int hop);
 size_t pv_wg_lds_bytes(int log2n, int hop);
 int pv_wg_threads(int log2n);
 hipError_t pv_launch_wg(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
+
+// wave-pair-per-frame kernel for N = 4096 (pv_pair_kernel.hip)
+bool pv_pair_supported(int log2n, int hop);
+size_t pv_pair_lds_bytes();
+int pv_pair_threads();
+hipError_t pv_launch_pair(const PvKernelParams &p, int nch, int nchunks, hipStream_t st);

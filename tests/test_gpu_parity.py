@@ -277,3 +277,44 @@ def test_wave2k_kernel(hop):
         parts = [pv.process_batch(x[:, a * hop:b * hop], p[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
         assert np.array_equal(np.concatenate(parts, axis=1), ref)
     pv.close()
+
+
+@pytest.mark.parametrize("hop", [512, 1024, 2048, 4096])
+def test_pair_kernel(hop):
+    """N = 4096: a pair of waves per frame (pv_pair_kernel).  f >= 1 (plain stores), f < 1 (atomic-MIN claim rounds across the two waves + the fast
+    residue), f < 0.75 (the residue rebuilt quarter by quarter by both waves), 0, negative, NaN and Inf, chunking, call splitting, and the same
+    stream through the workgroup kernel (PV_FLAG_WORKGROUP_KERNEL) as a second implementation of the path."""
+    fft, T, nch = 4096, 28, 3
+    x = np.stack([S.make_signal("tonal" if c != 1 else "noise", c, T * hop, stream=4) for c in range(nch)])
+    pv = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T)
+    assert pv.info()["kernel_name"] == "pv_pair_kernel"
+    wg = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T, flags=4)
+    assert wg.info()["kernel_name"] == "pv_wg_kernel"
+    ar = np.arange(T)
+    for pitch in (np.full(T, 1.25, np.float32), np.full(T, 1.0, np.float32), np.full(T, 2.0, np.float32), np.full(T, 0.8, np.float32),
+                  np.full(T, 0.75, np.float32), np.full(T, 0.5, np.float32), np.full(T, 0.3, np.float32),
+                  (0.4 + 1.85 * ar / (T - 1)).astype(np.float32),
+                  np.where(ar % 5 == 0, np.nan, 0.9).astype(np.float32),
+                  np.where(ar % 7 == 3, 0.0, np.where(ar % 7 == 5, -0.6, 0.55)).astype(np.float32),
+                  np.where(ar % 4 == 1, np.inf, 0.45).astype(np.float32)):
+        pv.reset(); wg.reset()
+        y = pv.process_batch(x, pitch)
+        yo = oracle_lib.Oracle(fft, hop, nch).process_planar(x, pitch)
+        assert np.all(np.isfinite(y))
+        assert S.rms(y.astype(np.float64) - yo) < REGRESSION_RMS, pitch[:6]
+        assert S.rms(wg.process_batch(x, pitch).astype(np.float64) - yo) < REGRESSION_RMS
+    wg.close()
+    for f in (1.25, 0.85, 0.55):                                               # chunked == unchunked == call-split == repeated, bit for bit
+        p = np.full(T, f, np.float32)
+        ref = None
+        for F in (T, 5, 11, T):
+            h = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T, frames_per_chunk=F)
+            y = h.process_batch(x, p)
+            h.close()
+            ref = y if ref is None else ref
+            assert np.array_equal(y, ref)
+        pv.reset()
+        cuts = [0, 9, 20, T]
+        parts = [pv.process_batch(x[:, a * hop:b * hop], p[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts, axis=1), ref)
+    pv.close()
