@@ -459,17 +459,17 @@ def main():
     if world == 1 and not args.no_extras:
         # ---- the other BASELINE configs, each a short measured line (same harness, same timing method) ----
         extras = []
-        def add(label, workload, f2, h2, c2, T2, pt, **kw):
-            r = measure(torch, phaze_amd, dev, None, f2, h2, c2, T2, pt, 5, 2, label, local_rank, parity_hops=12, **kw)
-            extras.append({"workload": workload, "value": r["frames_per_step_rank"] * 5 / r["elapsed"], "unit": "frames/s",
-                           "ms_per_step": r["elapsed"] / 5 * 1e3, "kernel_ms": r["kernel_ms"], "kernel": r["info"]["kernel_name"],
+        def add(label, workload, f2, h2, c2, T2, pt, steps=8, warm=3, **kw):
+            r = measure(torch, phaze_amd, dev, None, f2, h2, c2, T2, pt, steps, warm, label, local_rank, parity_hops=12, **kw)
+            extras.append({"workload": workload, "value": r["frames_per_step_rank"] * steps / r["elapsed"], "unit": "frames/s", "steps": steps, "warmup": warm,
+                           "ms_per_step": r["elapsed"] / steps * 1e3, "kernel_ms": r["kernel_ms"], "kernel": r["info"]["kernel_name"],
                            "roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS, "parity_rms_vs_oracle": r["parity"],
                            "frames_per_chunk": r["info"]["frames_per_chunk"]})
         T3 = 1 << 18
         add("C3", f"BASELINE configs[2]: stereo 48 kHz FFT=2048 hop=512 pitchFactor=f32(0.8), 2 ch x {T3} hops resident", 2048, 512, 2, T3,
             torch.full((T3,), 0.8, device=dev, dtype=torch.float32))
         add("C4", "BASELINE configs[3], one GPU's share: 8-ch 48 kHz FFT=4096 hop=1024, 128 streams x 8 ch = 1024 channel slots x 64 hops, pitchFactor=1.25",
-            4096, 1024, 1024, 64, torch.full((64,), 1.25, device=dev, dtype=torch.float32), ch_per_stream=8)
+            4096, 1024, 1024, 64, torch.full((64,), 1.25, device=dev, dtype=torch.float32), steps=40, warm=10, ch_per_stream=8)   # 1 ms launches: as many steps as the headline
         T5 = 1 << 14
         sweep = (0.5 + 1.5 * (torch.arange(T5, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
         add("C5", f"BASELINE configs[4]: 8-ch 96 kHz FFT=8192 hop=2048, pitchFactor swept 0.5->2.0 per hop (period 64 hops), 8 ch x {T5} hops resident",

@@ -249,10 +249,12 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     tw64[N / 2] = double2{-1, 0}; tw32[N / 2] = float2{-1, 0};
     CHK(hipMalloc(&h->d_tw64, sizeof(double2) * N));
     CHK(hipMalloc(&h->d_tw32, sizeof(float2) * N));
-    CHK(hipMalloc(&h->d_hann, sizeof(float) * N));
+    CHK(hipMalloc(&h->d_hann, sizeof(float) * 2 * N));                       // [0, N): the window; [N, 2N): half of it (exact), for kernels that fold the 1/2 of the split pass into it
     CHK(hipMemcpy(h->d_tw64, tw64.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
     CHK(hipMemcpy(h->d_tw32, tw32.data(), sizeof(float2) * N, hipMemcpyHostToDevice));
     CHK(hipMemcpy(h->d_hann, hann.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+    for (int k = 0; k < N; k++) hann[k] *= 0.5f;
+    CHK(hipMemcpy(h->d_hann + N, hann.data(), sizeof(float) * N, hipMemcpyHostToDevice));
 
     const size_t state = sizeof(float) * (size_t)maxch * (size_t)(h->L > 0 ? h->L : 1);
     for (int i = 0; i < 2; i++) {

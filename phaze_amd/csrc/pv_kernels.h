@@ -22,7 +22,7 @@ struct PvKernelParams {
     int t0_mod_n;             // timeCursor at the first hop of the launch, mod N (phase-vocoder.js:31,71)
     const double2 *tw64;      // exp(-2 pi j k / N), k in [0, N), fp64
     const float2 *tw32;       // same, rounded to fp32
-    const float *hann;        // periodic Hann, fp32 (phase-vocoder.js:8-14)
+    const float *hann;        // periodic Hann, fp32 (phase-vocoder.js:8-14), N values, followed by N values of 0.5 * Hann
     // test taps (all null in production)
     double *dbg_X;
     float *dbg_mag;

@@ -327,23 +327,36 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
             acc[r] = v4f{a[0], a[1], a[4], a[5]};
         }
     }
+    // Global accesses of a frame: one VGPR byte offset (this lane's position inside a register row) on top of wave-uniform row bases, so that the
+    // 32 loads and 4 stores need no per-access 64-bit address arithmetic.  A frame that reaches back into the carried history takes the slow form.
     auto load_rows = [&](v4f *w, int frame, int so) {
-        const long s0 = (long)(frame + 1) * HOP - N + so;
+        const long s0 = (long)(frame + 1) * HOP - N;                        // wave-uniform
+        if (s0 >= 0 && vec_in) {
+            const unsigned ob = 4u * (unsigned)so;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const long sx = s0 + 512 * r;                                   // even: neither float2 straddles history / input (both lengths are even)
-            const float *q0 = sx < 0 ? src.hist + sx + src.hist_len : src.in + sx;
-            const float *q1 = sx + 4 < 0 ? src.hist + sx + 4 + src.hist_len : src.in + sx + 4;
-            if (vec_in) { const v2f a = *reinterpret_cast<const v2f *>(q0), b = *reinterpret_cast<const v2f *>(q1); w[r] = v4f{a.x, a.y, b.x, b.y}; }
-            else w[r] = v4f{q0[0], q0[1], q1[0], q1[1]};
+            for (int r = 0; r < 8; r++) {
+                const char *rb = reinterpret_cast<const char *>(src.in + s0 + 512 * r);
+                const v2f a = *reinterpret_cast<const v2f *>(rb + ob), b = *reinterpret_cast<const v2f *>(rb + ob + 16);
+                w[r] = v4f{a.x, a.y, b.x, b.y};
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const long sx = s0 + so + 512 * r;                          // even: neither float2 straddles history / input (both lengths are even)
+                const float *q0 = sx < 0 ? src.hist + sx + src.hist_len : src.in + sx;
+                const float *q1 = sx + 4 < 0 ? src.hist + sx + 4 + src.hist_len : src.in + sx + 4;
+                if (vec_in) { const v2f a = *reinterpret_cast<const v2f *>(q0), b = *reinterpret_cast<const v2f *>(q1); w[r] = v4f{a.x, a.y, b.x, b.y}; }
+                else w[r] = v4f{q0[0], q0[1], q1[0], q1[1]};
+            }
         }
     };
-    auto load_hann = [&](v4f *w, int so) {                                  // 0.5 * Hann at this lane's samples (the table is full scale; the halving is exact)
-        const float *hb = p.hann + so;                                      // (so is opaque per frame: the 16 addresses are formed where they are used, not kept)
+    auto load_hann = [&](v4f *w, int so) {                                  // 0.5 * Hann at this lane's samples: the second half of the table (pv_kernels.h)
+        const unsigned ob = 4u * (unsigned)so;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const v2f a = *reinterpret_cast<const v2f *>(hb + 512 * r), b = *reinterpret_cast<const v2f *>(hb + 512 * r + 4);
-            w[r] = v4f{0.5f * a.x, 0.5f * a.y, 0.5f * b.x, 0.5f * b.y};
+            const char *rb = reinterpret_cast<const char *>(p.hann + N + 512 * r);
+            const v2f a = *reinterpret_cast<const v2f *>(rb + ob), b = *reinterpret_cast<const v2f *>(rb + ob + 16);
+            w[r] = v4f{a.x, a.y, b.x, b.y};
         }
     };
     v4f raw[8], hw[8];
@@ -777,11 +790,12 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
             for (int r = 0; r < S_ROWS; r++) {
                 const v4f o = acc[r] + fr[r];
                 if (emit_out) {
-                    float *dst = outp + (long)m * HOP + 8 * l + 2 * g + 512 * r;
+                    char *rb = reinterpret_cast<char *>(outp + (long)m * HOP + 512 * r);      // wave-uniform row base + this lane's byte offset
+                    const unsigned ob = 4u * (unsigned)(8 * l + 2 * g);
                     if (vec_out) {
-                        __builtin_nontemporal_store(v2f{o.x, o.y}, reinterpret_cast<v2f *>(dst));
-                        __builtin_nontemporal_store(v2f{o.z, o.w}, reinterpret_cast<v2f *>(dst + 4));
-                    } else { dst[0] = o.x; dst[1] = o.y; dst[4] = o.z; dst[5] = o.w; }
+                        __builtin_nontemporal_store(v2f{o.x, o.y}, reinterpret_cast<v2f *>(rb + ob));
+                        __builtin_nontemporal_store(v2f{o.z, o.w}, reinterpret_cast<v2f *>(rb + ob + 16));
+                    } else { float *dst = reinterpret_cast<float *>(rb + ob); dst[0] = o.x; dst[1] = o.y; dst[4] = o.z; dst[5] = o.w; }
                 }
             }
 #pragma unroll
