@@ -792,9 +792,9 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                 if (emit_out) {
                     char *rb = reinterpret_cast<char *>(outp + (long)m * HOP + 512 * r);      // wave-uniform row base + this lane's byte offset
                     const unsigned ob = 4u * (unsigned)(8 * l + 2 * g);
-                    if (vec_out) {
-                        __builtin_nontemporal_store(v2f{o.x, o.y}, reinterpret_cast<v2f *>(rb + ob));
-                        __builtin_nontemporal_store(v2f{o.z, o.w}, reinterpret_cast<v2f *>(rb + ob + 16));
+                    if (vec_out) {                                              // plain stores: the two waves fill alternate 8-byte pieces of every 32-byte sector and
+                        *reinterpret_cast<v2f *>(rb + ob) = v2f{o.x, o.y};              // L2 merges them (non-temporal stores reached HBM as two partial writes per sector:
+                        *reinterpret_cast<v2f *>(rb + ob + 16) = v2f{o.z, o.w};         // WRITE_SIZE 2.0 x the output)
                     } else { float *dst = reinterpret_cast<float *>(rb + ob); dst[0] = o.x; dst[1] = o.y; dst[4] = o.z; dst[5] = o.w; }
                 }
             }
