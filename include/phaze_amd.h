@@ -73,9 +73,9 @@ typedef struct pv_info {
     int32_t compute_units, device_id;
     char device_name[64];
     char kernel_name[32];    /* "pv_wave_kernel_1024" (N = 1024, hop in {128,256,512,1024}), "pv_wave2k_kernel" (N = 2048, hop in
-                              * {128,256,512,1024,2048}: one wave per frame), "pv_wg_kernel" (N = 4096, 8192 and N = 2048 with smaller
-                              * hops: a workgroup per frame; even hops that fit LDS) or "pv_chain_kernel" (everything else /
-                              * PV_FLAG_GENERIC_KERNEL) */
+                              * {128,256,512,1024,2048}: one wave per frame), "pv_pair_kernel" (N = 4096, hop in {512,1024,2048,
+                              * 4096}: a pair of waves per frame), "pv_wg_kernel" (N = 8192, and N >= 2048 with smaller even hops
+                              * that fit LDS: a workgroup per frame) or "pv_chain_kernel" (everything else / PV_FLAG_GENERIC_KERNEL) */
 } pv_info;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
