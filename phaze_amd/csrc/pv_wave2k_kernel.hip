@@ -320,14 +320,23 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             if (4 * lane + 256 * r < L) acc[r] = v4f{a[0], a[1], a[2], a[3]};
         }
     }
+    // A frame that lies inside the input takes wave-uniform row bases plus ONE lane offset (no per-row 64-bit address arithmetic); only the first
+    // R - 1 frames of a stream reach back into the carried history and pick a pointer per row.
     auto load_rows = [&](v4f *w, int frame) {
-        const long s0 = (long)(frame + 1) * HOP - N + 4 * lane;
+        const long s0u = (long)(frame + 1) * HOP - N;                       // wave-uniform
+        if (HALF && s0u >= 0 && vec_in) {                                   // (hop 128 only: -3 % there; at hop 512 the f < 1 path lost 3 % to the changed register allocation)
+            const unsigned ob = 16u * (unsigned)lane;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const long sx = s0 + 256 * r;                                   // a multiple of 4: the four samples never straddle history / input
-            const float *q = sx < 0 ? src.hist + sx + src.hist_len : src.in + sx;
-            if (vec_in) w[r] = *reinterpret_cast<const v4f *>(q);
-            else w[r] = v4f{q[0], q[1], q[2], q[3]};
+            for (int r = 0; r < 8; r++) w[r] = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(src.in + s0u + 256 * r) + ob);
+        } else {
+            const long s0 = s0u + 4 * lane;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const long sx = s0 + 256 * r;                               // a multiple of 4: the four samples never straddle history / input
+                const float *q = sx < 0 ? src.hist + sx + src.hist_len : src.in + sx;
+                if (vec_in) w[r] = *reinterpret_cast<const v4f *>(q);
+                else w[r] = v4f{q[0], q[1], q[2], q[3]};
+            }
         }
     };
     v4f raw[8];
