@@ -89,3 +89,12 @@ def test_no_environment_switches_in_the_product_library():
         for f in files:
             txt = open(os.path.join(base, f), errors="ignore").read()
             assert "getenv" not in txt and "ablate" not in txt, f
+
+
+def test_flag_constants_match_the_header():
+    """The ctypes binding's FLAG_* values are the header's PV_FLAG_* enumerators."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "phaze_amd.h")).read()
+    vals = dict(re.findall(r"(PV_FLAG_[A-Z_]+)\s*=\s*(\d+)", hdr))
+    assert vals == {"PV_FLAG_GENERIC_KERNEL": "1", "PV_FLAG_STREAM_COPY": "2", "PV_FLAG_WORKGROUP_KERNEL": "4"}
+    assert (phaze_amd.FLAG_GENERIC_KERNEL, phaze_amd.FLAG_STREAM_COPY, phaze_amd.FLAG_WORKGROUP_KERNEL) == (1, 2, 4)

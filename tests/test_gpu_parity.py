@@ -249,6 +249,11 @@ def test_wave2k_kernel(hop):
     x = np.stack([S.make_signal("tonal", c, T * hop, stream=9) for c in range(nch)])
     pv = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T)
     assert pv.info()["kernel_name"] == "pv_wave2k_kernel"
+    wg = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T, flags=4)                  # PV_FLAG_WORKGROUP_KERNEL: the second implementation of the path
+    assert wg.info()["kernel_name"] == "pv_wg_kernel"
+    pw = np.where(np.arange(T) % 3 == 0, 0.6, 1.3).astype(np.float32)
+    assert S.rms(wg.process_batch(x, pw).astype(np.float64) - oracle_lib.Oracle(fft, hop, nch).process_planar(x, pw)) < REGRESSION_RMS
+    wg.close()
     ar = np.arange(T)
     for pitch in (np.full(T, 0.75, np.float32), np.full(T, 0.8, np.float32), np.full(T, 1.0, np.float32), np.full(T, 1.5, np.float32),
                   np.full(T, 0.5, np.float32), np.full(T, 0.3, np.float32), np.full(T, 0.62, np.float32), np.full(T, 2.0, np.float32),
