@@ -323,3 +323,49 @@ def test_pair_kernel(hop):
         parts = [pv.process_batch(x[:, a * hop:b * hop], p[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
         assert np.array_equal(np.concatenate(parts, axis=1), ref)
     pv.close()
+
+
+@pytest.mark.parametrize("fft,hop", [(1024, 256), (2048, 512), (2048, 128), (4096, 1024), (8192, 2048), (512, 128)])
+def test_unaligned_device_buffers(fft, hop):
+    """pv_process_batch_device promises nothing about alignment beyond float: input / output rows that start 4, 8 or 12 bytes off a 16-byte
+    boundary (odd channel stride, offset base) take the kernels' scalar load / store paths and must give the same stream bit for bit."""
+    import torch
+    T, nch = 20, 3
+    x = np.stack([S.make_signal("tonal", c, T * hop, stream=2) for c in range(nch)])
+    pitch = np.where(np.arange(T) % 4 == 1, 0.8, 1.3).astype(np.float32)
+    yo = oracle_lib.Oracle(fft, hop, nch).process_planar(x, pitch)
+    dev = torch.device("cuda:0")
+    pt = torch.from_numpy(pitch).to(dev)
+    ref = None
+    for off, pad in ((0, 0), (1, 1), (2, 3), (3, 0)):
+        stride = T * hop + pad
+        xin = torch.zeros(nch * stride + 8, device=dev)
+        out = torch.full((nch * stride + 8,), 7.0, device=dev)
+        for c in range(nch):
+            xin[off + c * stride: off + c * stride + T * hop] = torch.from_numpy(x[c]).to(dev)
+        pv = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T)
+        pv.process_batch_device(xin.data_ptr() + 4 * off, out.data_ptr() + 4 * off, nch, T, stride, pt.data_ptr())
+        pv.synchronize()
+        pv.close()
+        o = out.cpu().numpy()
+        y = np.stack([o[off + c * stride: off + c * stride + T * hop] for c in range(nch)])
+        assert S.rms(y.astype(np.float64) - yo) < REGRESSION_RMS, (off, pad)
+        if pad:                                                               # nothing written between the rows
+            assert np.all(o[off + T * hop: off + stride] == 7.0)
+        ref = y if ref is None else ref
+        assert np.array_equal(y, ref), (off, pad)
+
+
+@pytest.mark.parametrize("fft,hop", [(2048, 512), (4096, 1024), (8192, 2048)])
+def test_per_stream_pitch_rows(fft, hop):
+    """C4's form: several streams of a few channels each in one launch, one pitchFactor row per stream (channel c reads row c // channels_per_stream)."""
+    T, nstreams, cps = 18, 3, 2
+    nch = nstreams * cps
+    x = np.stack([S.make_signal("tonal" if c % 2 else "noise", c, T * hop, stream=c // cps) for c in range(nch)])
+    pitch = np.stack([np.full(T, 1.25, np.float32), (0.6 + 1.2 * np.arange(T) / (T - 1)).astype(np.float32), np.where(np.arange(T) % 3 == 0, 0.8, 1.0).astype(np.float32)])
+    pv = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T)
+    y = pv.process_batch(x, pitch, channels_per_stream=cps)
+    pv.close()
+    for s in range(nstreams):
+        yo = oracle_lib.Oracle(fft, hop, cps).process_planar(x[s * cps:(s + 1) * cps], pitch[s])
+        assert S.rms(y[s * cps:(s + 1) * cps].astype(np.float64) - yo) < REGRESSION_RMS, s
