@@ -442,24 +442,26 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
         auto finish_groups = [&](auto gtag) {
             constexpr int G = decltype(gtag)::value;
             const double2 *SO64 = reinterpret_cast<const double2 *>(SO);
-            const double2 wNf = lane_twiddle(), wM = csq(wNf);
+            const double2 wNf = lane_twiddle();
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int r = 4 * G + i;
                 const double2 oa = SO64[(2 * i) * 64 + l], ob = SO64[(2 * i + 1) * 64 + l];
                 const double2 a0 = G ? oa : zlo[r], b0 = G ? ob : zm[r], a1 = G ? zlo[r] : oa, b1 = G ? zm[r] : ob;
-                // Z[k] = a0 + W^k a1, Z[1024 + k] = a0 - W^k a1, Z[1024 - k] = b0 - conj(W^k) b1, Z[2048 - k] = b0 + conj(W^k) b1,  W^k = wM W_32^r
-                const double2 t = cmul(wM, mul_w32_f(a1, r));
-                const double2 uc = cmul(wM, mul_w32_f(cconj(b1), r));        // conj(conj(W^k) b1)
+                // Z[k] = a0 + W^k a1, Z[1024 + k] = a0 - W^k a1, Z[1024 - k] = b0 - conj(W^k) b1, Z[2048 - k] = b0 + conj(W^k) b1.
+                // The group's twiddles are formed once: v = W_4096^k = wN W_64^r (split pass), W^k = W_2048^k = v^2 (radix-2 stage)
+                const double2 vk = mul_w64_f(wNf, r), wk = csq(vk);
+                const double2 t = cmul(wk, a1);
+                const double2 uc = cmul(wk, cconj(b1));                      // conj(conj(W^k) b1)
                 const double2 Zk = cadd(a0, t), Ze = csub(a0, t);
                 const double2 Zc{b0.x - uc.x, b0.y + uc.y}, Zd{b0.x + uc.x, b0.y - uc.y};
                 // pair (k, 2048 - k), twiddle W_4096^k = wN W_64^r
                 const double2 E{Zk.x + Zd.x, Zk.y - Zd.y}, O{Zk.x - Zd.x, Zk.y + Zd.y};
-                const double2 WO = cmul(wNf, mul_w64_f(O, r));
+                const double2 WO = cmul(vk, O);
                 double2 xa{E.x + WO.y, E.y - WO.x}, xb{E.x - WO.y, -(E.y + WO.x)};
                 // pair (1024 - k, 1024 + k), twiddle W_4096^{1024 - k} = -j conj(W_4096^k): with q = W_4096^k conj(O2), -j conj(q) O2-term = (-q.y, -q.x)
                 const double2 E2{Zc.x + Ze.x, Zc.y - Ze.y}, O2{Zc.x - Ze.x, Zc.y + Ze.y};
-                const double2 q = cmul(wNf, mul_w64_f(cconj(O2), r));
+                const double2 q = cmul(vk, cconj(O2));
                 double2 xc{E2.x - q.x, E2.y + q.y}, xd{E2.x + q.x, -(E2.y - q.y)};
                 if (G == 0 && i == 0 && l == 0) {                           // k = 0: Z[0] = a0 + a1, Z[1024] = a0 - a1 (pre-halved)
                     const double2 Z0 = cadd(a0, a1), Z1 = csub(a0, a1);
@@ -698,20 +700,22 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                     const pk::c32 yc = Yc[1024 - k], ye = Yc[1024 + k];
                     if (G == 0 && i == 0 && l == 0) { yk.y = 0.f; yd.y = 0.f; }
                     const pk::c32 E = pk::add_conj(yk, yd), O = pk::sub_conj(yk, yd);
-                    const pk::c32 c = pk::cmul(mul_w64_i(O, r), cNs);
+                    const pk::c32 vks = mul_w64_i(cNs, r);                    // e^{+2 pi j k / 4096} SC, formed once for both pairs of the group
+                    const pk::c32 wki = mul_w32_i(cM, r);                     // e^{+2 pi j k / 2048}, once for both differences
+                    const pk::c32 c = pk::cmul(O, vks);
                     const pk::c32 Zk = pk::fma_addj(E, scsc, c);             // Zc[k]
                     const pk::c32 Zd = pk::fma_conj_subj(E, scsc, c);        // Zc[2048 - k]
                     // pair (1024 - k, 1024 + k): e^{+2 pi j (1024 - k)/N} = j conj(e^{+2 pi j k/N}); with pp = e^{+2 pi j k/N} SC (Y[1024+k] - conj(Y[1024-k])):
                     // Zc[1024 - k] = E2 SC + conj(pp), Zc[1024 + k] = conj(E2 SC) - pp
                     const pk::c32 E2 = pk::add_conj(yc, ye), O2c = pk::sub_conj(ye, yc);
-                    const pk::c32 pp = pk::cmul(mul_w64_i(O2c, r), cNs);
+                    const pk::c32 pp = pk::cmul(O2c, vks);
                     pk::c32 Zc{E2.x * SC + pp.x, E2.y * SC - pp.y};
                     pk::c32 Ze{E2.x * SC - pp.x, -(E2.y * SC) - pp.y};
                     if (G == 0 && i == 0 && l == 0) { Ze = pk::c32{2.0f * yc.x * SC, -2.0f * yc.y * SC}; Zc = Ze; }   // bin 1024 pairs with itself: 2 conj(Y[1024]) SC
                     const pk::c32 Ak = pk::add(Zk, Ze), Dk = pk::sub(Zk, Ze);
-                    const pk::c32 Bk = pk::cmul(mul_w32_i(Dk, r), cM);
+                    const pk::c32 Bk = pk::cmul(Dk, wki);
                     const pk::c32 Ac = pk::add(Zc, Zd), Dc = pk::sub(Zc, Zd);
-                    const pk::c32 sB = pk::cmul(mul_w32_i(pk::c32{Dc.x, -Dc.y}, r), cM);
+                    const pk::c32 sB = pk::cmul(pk::c32{Dc.x, -Dc.y}, wki);
                     const pk::c32 Bc{-sB.x, sB.y};                           // (Zc[1024-k] - Zc[2048-k]) e^{+2 pi j (1024 - k)/2048}
                     if (G == 0) {
                         vkO[i] = Ak; vcO[i] = Ac;
