@@ -56,7 +56,7 @@ wg c5 --fft 8192 --hop 2048 --channels 8 --hops 16384 --pitch 1.5
 wg c3f07 --fft 2048 --hop 512 --channels 2 --hops 262144 --pitch 0.7
 wg native --fft 2048 --hop 128 --channels 2 --hops 262144 --pitch 1.0
 # the machine model behind DESIGN.md section 4: instruction issue costs and LDS pipe costs at 1..4 waves per SIMD
-for mb in valu_microbench valu_microbench2 overlap_microbench; do
+for mb in valu_microbench valu_microbench2 overlap_microbench crosswave_microbench; do
   [ -x $ROOT/tools/$mb ] && $ROOT/tools/$mb > "$OUT/$mb.txt" 2>&1
 done
 # occupancy sweep of the wave kernel (A/B builds under build/exp, if present): frame time per wave vs waves per SIMD
