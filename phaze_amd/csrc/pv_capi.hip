@@ -38,6 +38,9 @@ struct pv_handle {
     float *d_quantum;                            // device twin of h_pin
     float *d_pin_mapped;                         // device view of h_pin (zero-copy streaming quantum); null = stage through d_quantum
     double *d_dbgX; float *d_dbgMag; int *d_dbgFlags; float *d_dbgY;
+#ifdef PV_STAMPS
+    unsigned *d_stamps;                          // measurement builds only: [chain][16] phase clocks of the wave kernel
+#endif
     int64_t time_cursor;
     int active_nch;
     bool use_wave;                               // N = 1024: wave-per-frame kernel (pv_wave_kernel.hip)
@@ -126,6 +129,9 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     p.t0_mod_n = (int)(h->time_cursor & (int64_t)(h->N - 1));
     p.tw64 = h->d_tw64; p.tw32 = h->d_tw32; p.hann = h->d_hann;
     p.dbg_ch = -1; p.dbg_frame = -1;
+#ifdef PV_STAMPS
+    p.stamps = h->d_stamps;
+#endif
     if (dbg_ch >= 0) { p.dbg_X = h->d_dbgX; p.dbg_mag = h->d_dbgMag; p.dbg_flags = h->d_dbgFlags; p.dbg_Y = h->d_dbgY; p.dbg_ch = dbg_ch; p.dbg_frame = 0; }
     const int nchunks = (nhops + p.frames_per_chunk - 1) / p.frames_per_chunk;
     h->last_frames_per_chunk = p.frames_per_chunk;
@@ -281,6 +287,10 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     CHK(hipMalloc(&h->d_dbgMag, sizeof(float) * (N / 2 + 1)));
     CHK(hipMalloc(&h->d_dbgFlags, sizeof(int) * (N / 2 + 1)));
     CHK(hipMalloc(&h->d_dbgY, sizeof(float) * 2 * (N / 2 + 1)));
+#ifdef PV_STAMPS
+    CHK(hipMalloc(&h->d_stamps, sizeof(unsigned) * 16 * 65536));
+    CHK(hipMemset(h->d_stamps, 0, sizeof(unsigned) * 16 * 65536));
+#endif
 #undef CHK
     *out = h;
     return PV_OK;
@@ -503,5 +513,17 @@ int pv_debug_frame(pv_handle *h, int32_t ch, const float *block, float pitch_fac
     if (Y) HIPCHK(h, hipMemcpy(Y, h->d_dbgY, sizeof(float) * 2 * H, hipMemcpyDeviceToHost));
     return PV_OK;
 }
+
+#ifdef PV_STAMPS
+/* measurement builds only (never in the product): phase clocks of the last launch, 16 words per chain */
+PV_API int pv_exp_read_stamps(pv_handle *h, unsigned *dst, int nchains)
+{
+    if (!live(h) || !dst || nchains < 0 || nchains > 65536) return PV_ERR_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(dst, h->d_stamps, sizeof(unsigned) * 16 * (size_t)nchains, hipMemcpyDeviceToHost));
+    return PV_OK;
+}
+#endif
 
 }  // extern "C"

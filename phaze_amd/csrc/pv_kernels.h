@@ -29,6 +29,7 @@ struct PvKernelParams {
     int *dbg_flags;
     float *dbg_Y;
     int dbg_ch, dbg_frame;
+    unsigned *stamps;         // measurement builds only (-DPV_STAMPS, tools/exp_headline.sh): [chain][16] accumulated s_memtime deltas per phase
 };
 
 int pv_kernel_threads(int log2n);
@@ -41,7 +42,7 @@ int pv_wave_threads();
 bool pv_wave_supported(int log2n, int hop);
 hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
 
-// one wavefront per 2048-point frame (pv_wave2k_kernel.hip): N = 2048, hop in {256, 512, 1024, 2048}, pitchFactor >= 0.75 on every frame of the launch
+// one wavefront per 2048-point frame (pv_wave2k_kernel.hip): N = 2048, hop in {128, 256, 512, 1024, 2048}, every pitchFactor
 bool pv_wave2k_supported(int log2n, int hop);
 size_t pv_wave2k_lds_bytes();
 int pv_wave2k_threads();

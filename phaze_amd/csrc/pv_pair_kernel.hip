@@ -32,6 +32,7 @@
 #include "pv_kernels.h"
 #include "pv_device_common.h"
 #include "pv_pk_math.h"
+#define PV_PT 203333103      // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C4 0.92 -> 0.83 ms)
 #include "pv_wave_fft.h"
 
 namespace {
@@ -115,21 +116,34 @@ __device__ __forceinline__ void fft512_wave_inv_pk64(pk::c32 (&a)[8], pk::c32 *S
     pk::radix8_inv(a);
 #pragma unroll
     for (int k = 1; k < 8; k++) { const double2 w = TW1[k * 64 + l]; a[k] = pk::cmul(a[k], pk::c32{(float)w.x, -(float)w.y}); }
+    if (PV_PERM_T1 & 2) {                                                  // transpose 1 in registers (pv_wave_fft.h)
+        unsigned w[8][2];
 #pragma unroll
-    for (int j = 0; j < 4; j++) S4[j * TPP + l] = v4f{a[2 * j].x, a[2 * j].y, a[2 * j + 1].x, a[2 * j + 1].y};
-    wave_sync();
+        for (int k = 0; k < 8; k++) { w[k][0] = __float_as_uint(a[k].x); w[k][1] = __float_as_uint(a[k].y); }
+        transpose_hi3_regs<2>(w);
 #pragma unroll
-    for (int n = 0; n < 8; n++) a[n] = S[2 * ((lh >> 1) * TPP + 8 * n + ll) + (lh & 1)];
-    wave_sync();
+        for (int k = 0; k < 8; k++) a[k] = pk::c32{__uint_as_float(w[k][0]), __uint_as_float(w[k][1])};
+    } else {
+        PV_PRIO_XCH(1, 1);
+#pragma unroll
+        for (int j = 0; j < 4; j++) S4[j * TPP + l] = v4f{a[2 * j].x, a[2 * j].y, a[2 * j + 1].x, a[2 * j + 1].y};
+        wave_sync();
+#pragma unroll
+        for (int n = 0; n < 8; n++) a[n] = S[2 * ((lh >> 1) * TPP + 8 * n + ll) + (lh & 1)];
+        wave_sync();
+        PV_PRIO_XCH(0, 1);
+    }
     pk::radix8_inv(a);
 #pragma unroll
     for (int k = 1; k < 8; k++) { const double2 w = TW2[k * 8 + ll]; a[k] = pk::cmul(a[k], pk::c32{(float)w.x, -(float)w.y}); }
+    PV_PRIO_XCH(1, 1);
 #pragma unroll
     for (int j = 0; j < 4; j++) S4[j * TPP + lh * 8 + ((ll + lh) & 7)] = v4f{a[2 * j].x, a[2 * j].y, a[2 * j + 1].x, a[2 * j + 1].y};
     wave_sync();
 #pragma unroll
     for (int n = 0; n < 8; n++) a[n] = S[2 * ((lh >> 1) * TPP + ll * 8 + ((n + ll) & 7)) + (lh & 1)];
     wave_sync();
+    PV_PRIO_XCH(0, 1);
     pk::radix8_inv(a);
 }
 
@@ -398,6 +412,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
             }
         }
 
+        pv_prio(PH_FA);
         // ---- Hann (pv:55), this wave's half of the packed sequence split by parity, two 512-point fp64 FFTs, decimation-in-time stage ----
         double2 zlo[8], zhi[8];
 #pragma unroll
@@ -418,6 +433,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                 zhi[r] = csub(e, t);                                        // E_g[l + 64 r + 512]
             }
         }
+        pv_prio(PH_SPLIT);
         // ---- wave-local partner exchange: E_g[1024 - k] of k = l + 64 r is element 512 + (64 - l) + 64 (7 - r) ----
         double2 zm[8];
 #pragma unroll
@@ -510,6 +526,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
             if (g == 1 && l == 0) { XS[512] = xm0; XS[1536] = xm1; }
         }
 
+        pv_prio(PH_PEAKS);
         // ---- peak flags (pv:95-116) for bins 16 LL .. 16 LL + 15, nearest peaks inside the wave ----
         int last_shift = 0;
         unsigned rt[16];
@@ -598,6 +615,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                 __syncthreads();                                           // (f < 1 only, uniform in the workgroup) the stash is dead: Y may be zeroed
             }
         }
+        pv_prio(PH_SCATTER);
         // ---- routes (aliasing the magnitudes) and the zeroed Y (pv:121) ----
 #pragma unroll
         for (int j = 0; j < 4; j++) *reinterpret_cast<uint4 *>(&ROUTE[20 * LL + 4 * j]) = uint4{rt[4 * j], rt[4 * j + 1], rt[4 * j + 2], rt[4 * j + 3]};
@@ -680,6 +698,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
             }
         }
         __syncthreads();                                                   // barrier 5: Y complete
+        pv_prio(PH_C2R);
         // ---- c2r pre-pass (bundle:69-76,102-114 folded) and the decimation-in-frequency stage for this wave's four groups, packed fp32 ----
         //      Zc[k] = SC ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)), m = M - k;  A[q] = Zc[q] + Zc[q + 1024], B[q] = (Zc[q] - Zc[q + 1024]) e^{+2 pi j q / 2048}
         pk::c32 vkO[4], vcO[4];                                            // V[k], V[1024 - k] of this wave's kind (A for wave 0, B for wave 1) for its own four groups
@@ -763,6 +782,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                 zA[4 + i] = pk::c32{hi ? vkO[i].x : vkR[i].x, hi ? vkO[i].y : vkR[i].y};
             }
         }
+        pv_prio(PH_IA);
         // ---- this wave's 1024-point inverse: decimation-in-frequency stage, two 512-point packed-fp32 inverse FFTs ----
         {
             const double2 w1024 = csq(csq(lane_twiddle()));
@@ -784,6 +804,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
         }
         fft512_wave_inv_pk64(zA, reinterpret_cast<pk::c32 *>(SA), TW1, TW2, l);
         fft512_wave_inv_pk64(zB, reinterpret_cast<pk::c32 *>(SA), TW1, TW2, l);
+        pv_prio(PH_OLA);
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         {
             const bool emit_out = (m >= emit_v);

@@ -27,6 +27,7 @@
 #include "pv_kernels.h"
 #include "pv_device_common.h"
 #include "pv_pk_math.h"
+#define PV_PT 102222002      // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C3 3.76 -> 3.31 ms)
 #include "pv_wave_fft.h"
 
 namespace {
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             for (int r = 0; r < 8; r++) hw[r] = HW4[r * 64 + l];            // the analysis window is always in the natural layout
         }
 
+        pv_prio(PH_FA);
         // ---- Hann (pv:55), pack by parity, two 512-point fp64 FFTs, decimation-in-time stage ----
         double2 zlo[8], zhi[8];
 #pragma unroll
@@ -379,6 +381,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             zlo[r] = cadd(e, t);                                           // Z[l + 64 r]
             zhi[r] = csub(e, t);                                           // Z[l + 64 r + 512]
         }
+        pv_prio(PH_SPLIT);
         // ---- split pass in conjugate pairs: k = l + 64 r pairs with M - k = element 512 + (64 - l) + 64 (7 - r), i.e. zhi[7 - r] of lane 64 - l ----
         float2 XA[8], XB[8];                                               // X[l + 64 r], X[1024 - l - 64 r] rounded to fp32 after the decisions
         float2 x512f{0.f, 0.f};
@@ -451,6 +454,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
                 wave_sync();
             }
         }
+        pv_prio(PH_PEAKS);
         // ---- peak flags (pv:95-116) for bins 16l..16l+15, nearest peaks, one ROUTE word per source bin ----
         int last_peak = -1, last_shift = 0;
         {
@@ -526,6 +530,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
         (void)last_peak;
         int upper_end = H;
         if (last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }
+        pv_prio(PH_SCATTER);
         // ---- zero Y (pv:121) ----
 #pragma unroll
         for (int r = 0; r < 8; r++) *reinterpret_cast<v4f *>(&Y[2 * l + 128 * r]) = v4f{0.f, 0.f, 0.f, 0.f};
@@ -591,6 +596,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             }
         }
         wave_sync();
+        pv_prio(PH_C2R);
         // ---- c2r pre-pass in conjugate pairs (bundle:69-76,102-114 folded), packed fp32: Zc[k] = SC ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)), m = M - k ----
         pk::c32 zA[8], zB[8];                                              // Zc[l + 64 r], Zc[l + 64 r + 512]
         {
@@ -619,6 +625,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             if (li == 0) zB[0] = pk::c32{2.0f * y512.x * SC, -2.0f * y512.y * SC};
         }
         wave_sync();
+        pv_prio(PH_IA);
         // ---- decimation-in-frequency stage, then two 512-point packed-fp32 inverse FFTs ----
         const pk::c32 w1024i = par ? wl1024f_x : wl1024f;
 #pragma unroll
@@ -632,8 +639,11 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             load_rows(raw, mn);
             pf_next = pitch_row[mn];
         }
-        fft512_wave_inv_pk(zA, reinterpret_cast<pk::c32 *>(smem + O2_S), TW1F4, TW2F4, li);
-        fft512_wave_inv_pk(zB, reinterpret_cast<pk::c32 *>(smem + O2_S), TW1F4, TW2F4, li);
+        // hop 128 runs the synthesis side of odd frames under the lane id L ^ 32: an exchange through LDS addresses follows the relabelling for
+        // free, a register transpose acts on physical lanes -- transpose 1 stays in LDS there
+        fft512_wave_inv_pk<(HOPQ != 1)>(zA, reinterpret_cast<pk::c32 *>(smem + O2_S), TW1F4, TW2F4, li);
+        fft512_wave_inv_pk<(HOPQ != 1)>(zB, reinterpret_cast<pk::c32 *>(smem + O2_S), TW1F4, TW2F4, li);
+        pv_prio(PH_OLA);
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         {
             const bool emit_out = (m >= emit_v);

@@ -73,6 +73,34 @@ __device__ __forceinline__ pk::c32 mul_w16_inv_pk(pk::c32 o, int r)
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
+// Phase clock of the measurement builds (-DPV_STAMPS=1 coarse, =2 with the arithmetic / exchange split inside the FFTs): s_memtime deltas
+// accumulated per phase in SGPRs, written once per chain.  Nothing of this exists in the product build.
+#ifdef PV_STAMPS
+struct Stamps {
+    unsigned prev, acc[13];
+    static __device__ __forceinline__ unsigned now()
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    }
+    __device__ __forceinline__ void start() { for (int i = 0; i < 13; i++) acc[i] = 0; prev = now(); }
+    __device__ __forceinline__ void mark(int id, bool fine = false)
+    {
+        if (fine && PV_STAMPS < 2) return;
+        const unsigned t = now();
+        acc[id] += t - prev;
+        prev = t;
+    }
+};
+#define PV_STAMP(id) stamps.mark(id)
+#define PV_STAMP_FINE(id) stamps.mark(id, true)
+#else
+#define PV_STAMP(id)
+#define PV_STAMP_FINE(id)
+#endif
+
 
 // f < 1: regions compress and `+=` collisions happen (pv:169-170).  LDS float atomics serialise per lane (measured: half of the frame
 // time), so collisions are resolved by CLAIM ROUNDS: every pending source writes its id to CLAIM[target], the id that sticks wins the
@@ -355,6 +383,12 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
     __syncthreads();                                                     // the only workgroup-wide barrier
     if (ch >= p.nch) return;
 
+#ifdef PV_PT_STATIC
+    {   // experiment: static priority by the wave's rank on its SIMD (waves wv, wv + 4, wv + 8 share one)
+        const int rank = (PV_PT_STATIC == 1) ? 2 - (wv >> 2) : (wv >> 2);
+        if (rank == 2) __builtin_amdgcn_s_setprio(2); else if (rank == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     const unsigned wave_off = TAB_BYTES + wv * WAVE_LDS;
     unsigned char *smem = smem_all + wave_off;
     double2 *S64 = reinterpret_cast<double2 *>(smem);                    // 8*72*16 = 9216 B: fp64 transposes
@@ -426,22 +460,33 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
 #pragma unroll
     for (int j = 0; j < 4; j++) { const v4f h = HW4[j * 64 + l]; hw[2 * j] = pk::c32{h.x, h.y}; hw[2 * j + 1] = pk::c32{h.z, h.w}; }
 
+#ifdef PV_STAMPS
+    Stamps stamps;
+    stamps.start();
+    const unsigned stamp_t0 = stamps.prev;
+#endif
     for (int m = first_frame; m < last_out; ++m) {
         const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));   // k-rate pitchFactor (pv:47), wave-uniform
         const double pf = (double)pfm;
         const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
         const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
 
+        pv_prio(PH_FA);
         // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded into the table (exact) ----
         double2 z[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) { const v2f xw = v2f{raw[r].x, raw[r].y} * hw[r]; z[r] = double2{(double)xw.x, (double)xw.y}; }
 
+#ifdef PV_STAMPS
+        fft512_wave<double, false>(z, S64, TW1, TW2, l, [&](int id) { if (id & 1) stamps.mark(id); else stamps.mark(id, true); });
+#else
         fft512_wave<double, false>(z, S64, TW1, TW2, l);
+#endif
 
         // ---- split pass in conjugate pairs: with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved),
         //      X[k] = E - j W^k O and X[512-k] = conj(E + j W^k O).  Lane l owns the pairs k = l + 64 r, r < 4 (partner value from lane
         //      64-l, register 7-r), i.e. bins XA[r] = X[l + 64 r] and XB[r] = X[512 - l - 64 r]; lane 0 also owns the self-paired bin 256.
+        pv_prio(PH_SPLIT);
         float2 XA[4], XB[4];               // fp32 copy of the spectrum: the only thing the shift needs after the decisions
         float2 x256f{0.f, 0.f};
         {
@@ -501,9 +546,11 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
             if (!psh_valid || pfb != psh_key) { psh_key = pfb; psh_valid = true; build_shift_table_1024(pfm, wave_off, l); }
         }
         wave_sync();
+        PV_STAMP(4);
+        pv_prio(PH_PEAKS);
         // ---- peak flags (pv:95-116) for bins 8l..8l+7, nearest peaks by wave scans, then one ROUTE word per source bin ----
         int last_peak = -1, last_shift = 0;
-        {
+        if (!(PV_ABL & 16)) {
             // |X|^2 >= 0, so the fp32 order of two magnitudes is the order of their bit patterns as unsigned integers: the strict test
             // "greater than all four neighbours" (pv:100-110, `>=` rejects) becomes c > max(neighbours) with v_max3_u32 -- two instructions per
             // bin plus eight shared pair maxima, instead of four compares and three mask ANDs.
@@ -587,7 +634,14 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
             *reinterpret_cast<uint4 *>(&ROUTE[8 * l]) = uint4{rt[0], rt[1], rt[2], rt[3]};
             *reinterpret_cast<uint4 *>(&ROUTE[8 * l + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
             if (l == 63) ROUTE[512] = rt512;
+        } else {                                                            // timing-only build: identity routes, no search
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < 8; i++) ROUTE[8 * l + i] = (unsigned)(8 * l + i);
+            if (l == 63) ROUTE[512] = 512u;
         }
+        PV_STAMP(5);
+        pv_prio(PH_SCATTER);
         int upper_end = H;
         if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
         // ---- zero Y (pv:121); the transposes of the forward FFT are done with the scratch.  16 bytes per lane and store: four
@@ -633,6 +687,8 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
             }
         }
         wave_sync();
+        PV_STAMP(6);
+        pv_prio(PH_C2R);
         if (dbg) {
 #pragma unroll
             for (int r = 0; r < 8; r++) { const int k = l + 64 * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
@@ -679,8 +735,14 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
             pf_next = pitch_row[mn];
         }
 #endif
+#ifdef PV_STAMPS
+        stamps.mark(7);
+        fft512_wave_inv_pk<true>(zi, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l, [&](int id) { if (id & 1) stamps.mark(8 + id); else stamps.mark(8 + id, true); });
+#else
         fft512_wave_inv_pk(zi, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l);
+#endif
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
+        pv_prio(PH_OLA);
         {
             const bool emit_out = (m >= emit_v);
             float2 fr[8];
@@ -705,7 +767,17 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
                 acc[r] = (s < LROWS) ? float2{acc[s].x + fr[s].x, acc[s].y + fr[s].y} : fr[s];
             }
         }
+        PV_STAMP(12);
     }
+#ifdef PV_STAMPS
+    if (p.stamps && l == 0) {
+        unsigned *o = p.stamps + 16 * chain;
+        for (int i = 0; i < 13; i++) o[i] = stamps.acc[i];
+        o[13] = stamps.prev - stamp_t0;
+        o[14] = (unsigned)(last_out - first_frame);
+        o[15] = (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: SIMD / CU / SE of this wave
+    }
+#endif
 
     if (chunk == p.nchunks - 1) {
 #pragma unroll
