@@ -32,7 +32,7 @@
 #include "pv_kernels.h"
 #include "pv_device_common.h"
 #include "pv_pk_math.h"
-#define PV_PT 203333103      // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C4 0.92 -> 0.83 ms)
+#define PV_PT 2, 0, 2, 3, 3, 3, 3, 3, 1, 0, 1, 3     // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C4 0.92 -> 0.83 ms)
 #include "pv_wave_fft.h"
 
 namespace {
@@ -124,26 +124,26 @@ __device__ __forceinline__ void fft512_wave_inv_pk64(pk::c32 (&a)[8], pk::c32 *S
 #pragma unroll
         for (int k = 0; k < 8; k++) a[k] = pk::c32{__uint_as_float(w[k][0]), __uint_as_float(w[k][1])};
     } else {
-        PV_PRIO_XCH(1, 1);
+        pv_prio(PH_IX);
 #pragma unroll
         for (int j = 0; j < 4; j++) S4[j * TPP + l] = v4f{a[2 * j].x, a[2 * j].y, a[2 * j + 1].x, a[2 * j + 1].y};
         wave_sync();
 #pragma unroll
         for (int n = 0; n < 8; n++) a[n] = S[2 * ((lh >> 1) * TPP + 8 * n + ll) + (lh & 1)];
         wave_sync();
-        PV_PRIO_XCH(0, 1);
+        pv_prio(PH_IA);
     }
     pk::radix8_inv(a);
 #pragma unroll
     for (int k = 1; k < 8; k++) { const double2 w = TW2[k * 8 + ll]; a[k] = pk::cmul(a[k], pk::c32{(float)w.x, -(float)w.y}); }
-    PV_PRIO_XCH(1, 1);
+    pv_prio(PH_IX);
 #pragma unroll
     for (int j = 0; j < 4; j++) S4[j * TPP + lh * 8 + ((ll + lh) & 7)] = v4f{a[2 * j].x, a[2 * j].y, a[2 * j + 1].x, a[2 * j + 1].y};
     wave_sync();
 #pragma unroll
     for (int n = 0; n < 8; n++) a[n] = S[2 * ((lh >> 1) * TPP + ll * 8 + ((n + ll) & 7)) + (lh & 1)];
     wave_sync();
-    PV_PRIO_XCH(0, 1);
+    pv_prio(PH_IP3);
     pk::radix8_inv(a);
 }
 
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                 zhi[r] = csub(e, t);                                        // E_g[l + 64 r + 512]
             }
         }
-        pv_prio(PH_SPLIT);
+        pv_prio(PH_SPLITX);
         // ---- wave-local partner exchange: E_g[1024 - k] of k = l + 64 r is element 512 + (64 - l) + 64 (7 - r) ----
         double2 zm[8];
 #pragma unroll
@@ -453,6 +453,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
             for (int i = 0; i < 4; i++) { S64[(2 * i) * 64 + l] = zlo[i]; S64[(2 * i + 1) * 64 + l] = zm[i]; }
         }
         __syncthreads();                                                   // barrier 1
+        pv_prio(PH_SPLITM);
         float2 XA[4], XB[4], XC[4], XD[4];                                  // X[k], X[2048 - k], X[1024 - k], X[1024 + k] of this lane's four groups, rounded to fp32
         float2 xm0{0.f, 0.f}, xm1{0.f, 0.f};                                // wave 1, lane 0: X[512], X[1536]
         auto finish_groups = [&](auto gtag) {

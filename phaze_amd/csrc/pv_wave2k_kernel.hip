@@ -27,7 +27,7 @@
 #include "pv_kernels.h"
 #include "pv_device_common.h"
 #include "pv_pk_math.h"
-#define PV_PT 102222002      // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C3 3.76 -> 3.31 ms)
+#define PV_PT 1, 0, 1, 2, 2, 2, 2, 2, 0, 0, 0, 2     // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C3 3.76 -> 3.31 ms)
 #include "pv_wave_fft.h"
 
 namespace {
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             zlo[r] = cadd(e, t);                                           // Z[l + 64 r]
             zhi[r] = csub(e, t);                                           // Z[l + 64 r + 512]
         }
-        pv_prio(PH_SPLIT);
+        pv_prio(PH_SPLITX);
         // ---- split pass in conjugate pairs: k = l + 64 r pairs with M - k = element 512 + (64 - l) + 64 (7 - r), i.e. zhi[7 - r] of lane 64 - l ----
         float2 XA[8], XB[8];                                               // X[l + 64 r], X[1024 - l - 64 r] rounded to fp32 after the decisions
         float2 x512f{0.f, 0.f};
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
 #pragma unroll
             for (int r = 0; r < 8; r++) S64[r * 64 + l] = zhi[r];
             wave_sync();
+            pv_prio(PH_SPLITM);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const double2 zm = S64[(7 - r) * 64 + 64 - l];             // (l = 0, r = 0) reads one element past the rows: replaced below

@@ -27,22 +27,29 @@ struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
 // queue on every hop.  Raising those phases above the bulk phases (FFT arithmetic, and lowest of all the FFT transposes, which are long
 // anyway) lets a wave run through its latency chain while the other two fill the VALU: measured -13 % on the headline launch (2.35 -> 2.03 ms),
 // -12 % on N = 2048, -10 % on N = 4096, results bit-identical.  A static priority per wave (by rank on the SIMD) does nothing.
-// PV_PT is the table: nine decimal digits, one s_setprio level (0..3) per phase, most significant first -- forward arithmetic, forward
-// exchanges, split pass, peak search, scatter, c2r pass, inverse arithmetic, inverse exchanges, window / overlap-add; 9 = leave unchanged
-// (999999999 = the round-2 behaviour).  A kernel file may define its own table before including this header.
+// PV_PT is the table: one s_setprio level (0..3) per phase, in the order of the enum below; 9 = leave the priority unchanged (all 9 = the
+// round-2 behaviour).  A kernel file may define its own table before including this header.
 #ifndef PV_PT
-#define PV_PT 102233002
+#define PV_PT 1, 0, 1, 2, 2, 2, 3, 3, 0, 0, 0, 2
 #endif
-enum { PH_FA = 0, PH_FX, PH_SPLIT, PH_PEAKS, PH_SCATTER, PH_C2R, PH_IA, PH_IX, PH_OLA };
+enum { PH_FA = 0,      // forward FFT: window, pack, passes 1 and 2 (arithmetic)
+       PH_FX,          // forward FFT: LDS transposes
+       PH_FP3,         // forward FFT: pass 3
+       PH_SPLITX,      // split pass: partner exchange
+       PH_SPLITM,      // split pass: arithmetic, |X|^2, prefetch of the next frame's rows
+       PH_PEAKS, PH_SCATTER, PH_C2R,
+       PH_IA,          // inverse FFT: passes 1 and 2
+       PH_IX,          // inverse FFT: LDS transposes
+       PH_IP3,         // inverse FFT: pass 3
+       PH_OLA,         // window, overlap-add, stores
+       PH_COUNT };
 template <int PHASE> __device__ __forceinline__ void pv_prio_t()
 {
-    constexpr long t = PV_PT;
-    constexpr long p10[9] = {100000000, 10000000, 1000000, 100000, 10000, 1000, 100, 10, 1};
-    constexpr int d = (int)(t / p10[PHASE] % 10);
-    if constexpr (d <= 3) __builtin_amdgcn_s_setprio(d);
+    constexpr int t[] = {PV_PT};
+    static_assert(sizeof(t) / sizeof(t[0]) == PH_COUNT, "PV_PT needs one level per phase");
+    if constexpr (t[PHASE] <= 3) __builtin_amdgcn_s_setprio(t[PHASE]);
 }
 #define pv_prio(PHASE) pv_prio_t<PHASE>()
-#define PV_PRIO_XCH(on, INV) pv_prio_t<(on) ? ((INV) ? PH_IX : PH_FX) : ((INV) ? PH_IA : PH_FA)>()
 
 // ---- transpose 1 of the wave FFTs in registers (round 3) ----
 // [reg k0][lane (n1, n0)] -> [reg n1][lane (k0, n0)] exchanges the register index with the HIGH three lane bits, one bit per stage: bit 5 with
@@ -115,14 +122,14 @@ __device__ __forceinline__ void fft512_wave(typename v2t<T>::type (&a)[8], typen
             a[k].y = (T)__builtin_bit_cast(double, uint2{w[k][2], w[k][3]});
         }
     } else if (XPOSE) {
-        PV_PRIO_XCH(1, 0);
+        pv_prio(PH_FX);
 #pragma unroll
         for (int k = 0; k < 8; k++) S[k * TP + l] = a[k];
         wave_sync();
 #pragma unroll
         for (int n = 0; n < 8; n++) a[n] = S[lh * TP + 8 * n + ll];
         wave_sync();
-        PV_PRIO_XCH(0, 0);
+        pv_prio(PH_FA);
     }
     st(1);
     // pass 2: DFT over n1; twiddle W_64^{n0*k1}
@@ -134,14 +141,14 @@ __device__ __forceinline__ void fft512_wave(typename v2t<T>::type (&a)[8], typen
     st(2);
     // transpose 2: [reg k1][lane (k0,n0)] -> [reg n0][lane (k1,k0)], skewed rows
     if (XPOSE) {
-        PV_PRIO_XCH(1, 0);
+        pv_prio(PH_FX);
 #pragma unroll
         for (int k = 0; k < 8; k++) S[k * TP + lh * 8 + ((ll + lh) & 7)] = a[k];
         wave_sync();
 #pragma unroll
         for (int n = 0; n < 8; n++) a[n] = S[lh * TP + ll * 8 + ((n + ll) & 7)];
         wave_sync();
-        PV_PRIO_XCH(0, 0);
+        pv_prio(PH_FP3);
     }
     st(3);
     // pass 3: DFT over n0 -> k2; lane l now holds X[l + 64 k2]
@@ -182,14 +189,14 @@ __device__ __forceinline__ void fft512_wave_inv_pk(pk::c32 (&a)[8], pk::c32 *S, 
 #pragma unroll
         for (int k = 0; k < 8; k++) a[k] = pk::c32{__uint_as_float(w[k][0]), __uint_as_float(w[k][1])};
     } else if (XPOSE) {
-        PV_PRIO_XCH(1, 1);
+        pv_prio(PH_IX);
 #pragma unroll
         for (int j = 0; j < 4; j++) S4[j * TPP + l] = v4f{a[2 * j].x, a[2 * j].y, a[2 * j + 1].x, a[2 * j + 1].y};
         wave_sync();
 #pragma unroll
         for (int n = 0; n < 8; n++) a[n] = S[2 * ((lh >> 1) * TPP + 8 * n + ll) + (lh & 1)];
         wave_sync();
-        PV_PRIO_XCH(0, 1);
+        pv_prio(PH_IA);
     }
     st(1);
     if (MATH) {
@@ -204,14 +211,14 @@ __device__ __forceinline__ void fft512_wave_inv_pk(pk::c32 (&a)[8], pk::c32 *S, 
     st(2);
     // transpose 2: [reg k1][lane (k0,n0)] -> [reg n0][lane (k1,k0)], skewed columns
     if (XPOSE) {
-        PV_PRIO_XCH(1, 1);
+        pv_prio(PH_IX);
 #pragma unroll
         for (int j = 0; j < 4; j++) S4[j * TPP + lh * 8 + ((ll + lh) & 7)] = v4f{a[2 * j].x, a[2 * j].y, a[2 * j + 1].x, a[2 * j + 1].y};
         wave_sync();
 #pragma unroll
         for (int n = 0; n < 8; n++) a[n] = S[2 * ((lh >> 1) * TPP + ll * 8 + ((n + ll) & 7)) + (lh & 1)];
         wave_sync();
-        PV_PRIO_XCH(0, 1);
+        pv_prio(PH_IP3);
     }
     st(3);
     if (MATH) pk::radix8_inv(a);

@@ -105,7 +105,9 @@ struct Stamps {
 // f < 1: regions compress and `+=` collisions happen (pv:169-170).  LDS float atomics serialise per lane (measured: half of the frame
 // time), so collisions are resolved by CLAIM ROUNDS: every pending source writes its id to CLAIM[target], the id that sticks wins the
 // round and does a plain read-modify-write on Y; losers retry.  Rounds = max multiplicity of a target (2-3 for f >= 0.3).
-template <int NS>
+// YZERO: the caller guarantees that Y is still all zero (first scatter of a frame): the winners of round 1 then store their value instead
+// of a read-modify-write (0 + v == v bit for bit, also for v = -0: Y is +0 and +0 + -0 = +0 -- so a -0 component is stored as +0 explicitly).
+template <int NS, bool YZERO>
 __device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned short *CLAIM)
 {
     unsigned pend = 0;                                                     // (a bool per source would be carried through the loop as 0/1 VGPRs: slower)
@@ -116,6 +118,22 @@ __device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const flo
         const bool ok = t < 513u;                                          // valid route <=> target field < H
         pend |= ok ? (1u << r) : 0u;
         tg[r] = ok ? t : 0u;                                               // in-range address for the unconditional reads below
+    }
+    if (YZERO) {
+#pragma unroll
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[tg[r]] = (unsigned short)id[r];
+        wave_sync();
+        unsigned short c[NS];
+#pragma unroll
+        for (int r = 0; r < NS; r++) c[r] = CLAIM[tg[r]];
+#pragma unroll
+        for (int r = 0; r < NS; r++) {
+            if ((pend & (1u << r)) && c[r] == (unsigned short)id[r]) {
+                Y[tg[r]] = float2{0.f + ys[r].x, 0.f + ys[r].y};           // what the reference's += leaves in a zeroed bin (pv:121,169-170)
+                pend &= ~(1u << r);
+            }
+        }
+        wave_sync();
     }
     while (__any(pend != 0u)) {
 #pragma unroll
@@ -155,17 +173,12 @@ constexpr int WAVE_LDS = OFF_PSH + 1024;   // 11360: 22016 + 12 * 11360 = 158336
 // while the last region ends at or below position 641 (f >= 0.75 always; lower f when the last peak sits low enough); the general path
 // below covers the rest.  Sources b = 513 + l + 64 j, j < 2, all owned by the last peak (pv:133): b -> b + up_delta.
 template <int R_>
-__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_fast_1024(const float2 *__restrict__ tw32, unsigned wave_off, int l, int upper_end, int up_delta,
-                                                                          unsigned up_ridx, double *dbg_X)
+__device__ __forceinline__ void residue_fast_1024(const float2 *__restrict__ tw32, unsigned wave_off, int l, int upper_end, int up_delta,
+                                                  unsigned up_ridx, double *dbg_X, unsigned (&rt)[2], float2 (&ys)[2], int (&id)[2])
 {
     constexpr int H = 513;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    float2 *Y = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_Y);
-    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + OFF_ROUTE);
     const float2 *XS = reinterpret_cast<const float2 *>(smem_all + wave_off + OFF_XS);
-    unsigned rt[2];
-    float2 ys[2];
-    int id[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int k = 1 + l + 64 * j, b = 512 + k, tgt = b + up_delta;        // k in [1, 128]
@@ -184,7 +197,6 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_fast_1024(const
         id[j] = b;
         if (dbg_X && b < upper_end) { dbg_X[2 * b] = s2.x; dbg_X[2 * b + 1] = s2.y; }
     }
-    claim_rounds<2>(rt, ys, id, Y, CLAIM);
 }
 
 // Rare path (f < 1 frames whose last region reads above Nyquist): rebuild what fft.js's in-place real DIT leaves at positions
@@ -261,7 +273,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(co
             ys[j] = rotate_route<R_, 10>(rt[j], Q[l + 64 * j], tw32);
             id[j] = b;
         }
-        claim_rounds<4>(rt, ys, id, Y, CLAIM);
+        claim_rounds<4, false>(rt, ys, id, Y, CLAIM);
     }
 }
 
@@ -287,8 +299,11 @@ __device__ __attribute__((noinline)) void build_shift_table_1024(float f, unsign
 // the batched claim reads) do not count against the main pipeline, whose f >= 1 path needs every one of its 168 VGPRs.
 struct Spectrum9 { float2 a[4], b[4], h; };     // bins l + 64 r, 512 - l - 64 r (r < 4), and 256 (lane 0)
 
+#ifndef PV_COLLIDE_ATTR
+#define PV_COLLIDE_ATTR __attribute__((noinline))
+#endif
 template <int R_>
-__device__ __attribute__((noinline)) PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 X, unsigned wave_off, int l, int tmod, int last_peak, int upper_end,
+__device__ PV_COLLIDE_ATTR PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 X, unsigned wave_off, int l, int tmod, int last_peak, int upper_end,
                                                                                const float *in, const float *hist, int hist_len, long s0,
                                                                                const float *__restrict__ hann, const float2 *__restrict__ tw32, double *dbg_X)
 {
@@ -321,22 +336,35 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void scatter_colliding_1024(
 #pragma unroll
         for (int r = 0; r < 9; r++) ys[r] = rotate_route<R_, 10>(rt[r], ys[r], tw32);
     }
-    const bool need_res = upper_end > H;
+    const bool need_res = upper_end > H && !(PV_ABL & 32);
     const bool fast_res = need_res && (upper_end <= H + 128);
-    if (fast_res) {                                                    // stash the fp32 spectrum for residue_fast_1024
+    // sources above Nyquist, all owned by the last peak (pv:133)
+    const int up_delta = need_res ? (int)DSH[last_peak < 0 ? 0 : last_peak] : 0;
+    const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+    if (fast_res) {
+        // fast form of the residue: stash the fp32 spectrum, run the nine ordinary sources through their claim rounds, then the two residue
+        // sources of every lane through a series of their own.  (Measured in round 3: ONE series over eleven sources is 9 % slower at f = 0.8 --
+        // the eleven-wide round spills inside this function -- and forming the residue sources inline instead of in a nested call is worth 2 %.)
         float2 *XS = reinterpret_cast<float2 *>(smem + OFF_XS);
 #pragma unroll
         for (int r = 0; r < 4; r++) { XS[l + 64 * r] = X.a[r]; XS[512 - l - 64 * r] = X.b[r]; }
         if (l == 0) XS[256] = X.h;
+        wave_sync();                                                   // (also: routes are in registers, CLAIM may overwrite ROUTE)
+        claim_rounds<9, true>(rt, ys, id, Y, CLAIM);
+        unsigned rt2[2];
+        float2 ys2[2];
+        int id2[2];
+        residue_fast_1024<R_>(tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X, rt2, ys2, id2);
+        claim_rounds<2, false>(rt2, ys2, id2, Y, CLAIM);
+        return;
     }
     wave_sync();                                                       // routes are in registers: CLAIM may overwrite ROUTE
-    claim_rounds<9>(rt, ys, id, Y, CLAIM);
-    if (need_res) {                                                    // sources above Nyquist, all owned by the last peak (pv:133)
-        const int up_delta = (int)DSH[last_peak < 0 ? 0 : last_peak];
-        const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
-        if (fast_res) residue_fast_1024<R_>(tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
-        else residue_scatter_1024<R_>(in, hist, hist_len, s0, hann, tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
-    }
+    if (PV_ABL & 64) {                                                 // timing-only build: plain stores (collisions lose contributions)
+#pragma unroll
+        for (int r = 0; r < 9; r++) if ((rt[r] & 0xFFFFu) < 513u) Y[rt[r] & 0xFFFFu] = ys[r];
+    } else
+    claim_rounds<9, true>(rt, ys, id, Y, CLAIM);
+    if (need_res) residue_scatter_1024<R_>(in, hist, hist_len, s0, hann, tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
 }
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
@@ -486,7 +514,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
         // ---- split pass in conjugate pairs: with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved),
         //      X[k] = E - j W^k O and X[512-k] = conj(E + j W^k O).  Lane l owns the pairs k = l + 64 r, r < 4 (partner value from lane
         //      64-l, register 7-r), i.e. bins XA[r] = X[l + 64 r] and XB[r] = X[512 - l - 64 r]; lane 0 also owns the self-paired bin 256.
-        pv_prio(PH_SPLIT);
+        pv_prio(PH_SPLITX);
         float2 XA[4], XB[4];               // fp32 copy of the spectrum: the only thing the shift needs after the decisions
         float2 x256f{0.f, 0.f};
         {
@@ -496,6 +524,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
 #pragma unroll
             for (int r = 4; r < 8; r++) S64[(r - 4) * 64 + l] = z[r];
             wave_sync();
+            pv_prio(PH_SPLITM);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 double2 xa, xb;
