@@ -41,7 +41,7 @@ int main(int argc, char **argv)
     unsigned s = 12345u;
     int c, m, rc;
     size_t i;
-    pv_config cfg;
+    pv_config cfg = PV_CONFIG_INIT;
     pv_handle *h = NULL;
     pv_info info;
     double t0, t_stream, t_batch;
@@ -54,7 +54,6 @@ int main(int argc, char **argv)
         }
     for (m = 0; m < hops; m++) pf[m] = pitch;
 
-    memset(&cfg, 0, sizeof cfg);
     cfg.fft_size = fft; cfg.hop_size = hop; cfg.max_channels = nch; cfg.max_hops = hops; cfg.device_id = 0;
     rc = pv_create(&cfg, &h);
     if (rc != PV_OK) return die(h, "pv_create", rc);

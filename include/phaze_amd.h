@@ -43,10 +43,16 @@ enum {
 
 typedef struct pv_handle pv_handle;
 
+/* Version of this header's binary interface (struct layouts + semantics).  pv_abi_version() returns the value the LIBRARY was built with;
+ * 2 = round 3: pv_config carries its own size, unknown pv_config.flags bits are rejected, PV_FLAG_PERSISTENT_STREAM. */
+#define PV_ABI_VERSION 2
+
 /* Construction options.  Replaces `new PhaseVocoderProcessor(options)` (phase-vocoder.js:24-43,
  * ola-processor.js:7-34).  The reference hard-codes fft_size 2048 (phase-vocoder.js:6) and hop 128
  * (ola-processor.js:3); both are options here; the host layer (phaze_amd/node/phase-vocoder.js) supplies the reference's values when omitted. */
 typedef struct pv_config {
+    int32_t struct_size;     /* sizeof(pv_config) as the CALLER compiled it (PV_CONFIG_INIT sets it).  pv_create rejects any other value with
+                              * PV_ERR_ARGUMENT: a caller built against another layout would otherwise have trailing fields (flags!) read as garbage */
     int32_t fft_size;        /* N, power of two > 1 (else PV_ERR_FFT_SIZE); kernels cover 64..8192        */
     int32_t hop_size;        /* h >= 2, divides N.  nbOverlaps R = N / h (ola-processor.js:17)           */
     int32_t max_channels;    /* channel slots owned by this handle (streams x channels); 0 => 2.  One launch
@@ -56,6 +62,8 @@ typedef struct pv_config {
     int32_t frames_per_chunk;/* batch kernel: output hops per workgroup (0 => auto)                      */
     int32_t flags;           /* PV_FLAG_* bits, 0 for production use                                     */
 } pv_config;
+/* pv_config cfg = PV_CONFIG_INIT; cfg.fft_size = ...;  (every other field 0 = its default) */
+#define PV_CONFIG_INIT { (int32_t)sizeof(pv_config), 0, 0, 0, 0, 0, 0, 0 }
 
 /* pv_config.flags: explicit A/B switches for tests and measurements (the library reads NO environment
  * variables).  All select complete, parity-tested implementations of the same path. */
@@ -63,8 +71,9 @@ enum {
     PV_FLAG_GENERIC_KERNEL = 1, /* always launch the LDS-staged fallback kernel (pv_chain_kernel)        */
     PV_FLAG_STREAM_COPY = 2,    /* streaming quantum through H2D + kernel + D2H copies instead of the
                                  * zero-copy mapping of the pinned staging buffer                         */
-    PV_FLAG_WORKGROUP_KERNEL = 4 /* N = 2048 / 4096: the workgroup-per-frame kernel (pv_wg_kernel) instead of the
+    PV_FLAG_WORKGROUP_KERNEL = 4, /* N = 2048 / 4096: the workgroup-per-frame kernel (pv_wg_kernel) instead of the
                                   * one-wave (pv_wave2k_kernel) / wave-pair (pv_pair_kernel) kernels      */
+    PV_FLAG_ALL = 7              /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
 };
 
 typedef struct pv_info {
@@ -82,12 +91,17 @@ typedef struct pv_info {
 /* Allocates device state (zeroed input history + overlap-add accumulators, timeCursor = 0) and the
  * FFT/Hann tables.  Replaces the constructor chain phase-vocoder.js:24-43 -> ola-processor.js:7-34.  */
 PV_API int pv_create(const pv_config *cfg, pv_handle **out);
+/* PV_ABI_VERSION of the loaded library (a binding checks it against the header it was generated from). */
+PV_API int pv_abi_version(void);
 PV_API int pv_destroy(pv_handle *h);
 
 /* Human-readable text of the last failure on this handle (h == NULL: of the last failed pv_create). */
 PV_API const char *pv_last_error(const pv_handle *h);
 PV_API const char *pv_status_string(int status);
 PV_API int pv_get_info(const pv_handle *h, pv_info *out);
+/* Number of HIP devices this process can create handles on (pv_config.device_id in [0, count)): what a host needs to shard streams over the
+ * GPUs of a node (stream s -> device s mod count; streams are independent processors, nothing is exchanged). */
+PV_API int pv_device_count(int32_t *out);
 
 /* ---- state ------------------------------------------------------------------------------------- */
 /* Zero history + accumulators of ALL channels and set timeCursor = 0 (a freshly constructed processor). */
@@ -122,6 +136,15 @@ PV_API int pv_import_state(pv_handle *h, int32_t ch, const float *hist, const fl
  * reference's `return true`. */
 PV_API int pv_process(pv_handle *h, const float *const *in, float *const *out, int32_t nch,
                       int32_t nsamples, float pitch_factor);
+
+/* The same quantum split into its launch and its wait, for a host that drives SEVERAL handles (the inputs of one processor with
+ * numberOfInputs > 1, phase-vocoder.js:49-50, or handles on different GPUs): call pv_process_begin on every handle -- each copies its
+ * blocks to pinned memory and launches on its own stream, nothing waits -- then pv_process_end on every handle.  All launches are in
+ * flight before the first wait.  pv_process(h, in, out, ...) == pv_process_begin(h, in, ...) + pv_process_end(h, out).  Between the two calls
+ * the handle accepts no other call; pv_process_end without a pending quantum returns PV_ERR_ARGUMENT.  When the wait fails the handle is
+ * rolled back to its state before pv_process_begin. */
+PV_API int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t nsamples, float pitch_factor);
+PV_API int pv_process_end(pv_handle *h, float *const *out);
 
 /* ---- the hot call, batch (throughput) form ------------------------------------------------------- */
 /* nhops consecutive process() calls for nch channel slots in one launch.  Planar layout: channel c

@@ -20,7 +20,8 @@ PV_OK, PV_ERR_FFT_SIZE, PV_ERR_ARGUMENT, PV_ERR_UNSUPPORTED, PV_ERR_CAPACITY, PV
 EXPORTS = [
     "pv_create", "pv_destroy", "pv_last_error", "pv_status_string", "pv_get_info", "pv_reset", "pv_reset_channels",
     "pv_get_time_cursor", "pv_set_time_cursor", "pv_process", "pv_process_batch", "pv_process_batch_device",
-    "pv_set_stream", "pv_synchronize", "pv_debug_frame", "pv_export_state", "pv_import_state",
+    "pv_set_stream", "pv_synchronize", "pv_debug_frame", "pv_export_state", "pv_import_state", "pv_abi_version",
+    "pv_process_begin", "pv_process_end", "pv_device_count",
 ]
 
 
@@ -31,7 +32,15 @@ class PvError(RuntimeError):
 
 
 class _Config(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("fft_size", "hop_size", "max_channels", "max_hops", "device_id", "frames_per_chunk", "flags")]
+    _fields_ = [(n, C.c_int32) for n in ("struct_size", "fft_size", "hop_size", "max_channels", "max_hops", "device_id", "frames_per_chunk", "flags")]
+
+
+def make_config(fft_size, hop_size, max_channels=1, max_hops=1, device_id=0, frames_per_chunk=0, flags=0):
+    """pv_config with struct_size filled in (the C side's PV_CONFIG_INIT)."""
+    return _Config(C.sizeof(_Config), fft_size, hop_size, max_channels, max_hops, device_id, frames_per_chunk, flags)
+
+
+ABI_VERSION = 2          # PV_ABI_VERSION of include/phaze_amd.h this binding was written against (checked at load time)
 
 
 # pv_config.flags (include/phaze_amd.h): explicit A/B switches; the library reads no environment variables
@@ -98,6 +107,12 @@ def load_library():
     for n in EXPORTS:
         if n not in ("pv_last_error", "pv_status_string"):
             getattr(L, n).restype = C.c_int
+    L.pv_process_begin.argtypes = [vp, C.POINTER(fp), C.c_int32, C.c_int32, C.c_float]
+    L.pv_process_end.argtypes = [vp, C.POINTER(fp)]
+    L.pv_device_count.argtypes = [C.POINTER(C.c_int32)]
+    L.pv_abi_version.argtypes = []
+    if L.pv_abi_version() != ABI_VERSION:
+        raise PvError(PV_ERR_ARGUMENT, f"{_LIB_PATH} has PV_ABI_VERSION {L.pv_abi_version()}, this binding expects {ABI_VERSION}: rebuild the library")
     _lib = L
     return L
 
@@ -114,7 +129,7 @@ class PhaseVocoder:
     def __init__(self, fft_size=2048, hop_size=128, max_channels=2, max_hops=1, device_id=0, frames_per_chunk=0, flags=0):
         self._L = load_library()
         self._h = C.c_void_p()
-        cfg = _Config(fft_size, hop_size, max_channels, max_hops, device_id, frames_per_chunk, flags)
+        cfg = make_config(fft_size, hop_size, max_channels, max_hops, device_id, frames_per_chunk, flags)
         rc = self._L.pv_create(C.byref(cfg), C.byref(self._h))
         if rc != PV_OK:
             msg = self._L.pv_last_error(None).decode()

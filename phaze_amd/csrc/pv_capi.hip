@@ -43,6 +43,9 @@ struct pv_handle {
 #endif
     int64_t time_cursor;
     int active_nch;
+    int pending_nch;                             // > 0: a quantum launched by pv_process_begin waits for pv_process_end
+    int pending_cur, pending_active_nch;         // ... and what to restore if that wait fails
+    int64_t pending_time_cursor;
     bool use_wave;                               // N = 1024: wave-per-frame kernel (pv_wave_kernel.hip)
     bool use_wg;                                 // N = 2048..8192, R <= 8: register-resident workgroup kernel (pv_wg_kernel.hip)
     bool use_wave2k;                             // N = 2048, hop 128..2048: one wave per frame (pv_wave2k_kernel.hip)
@@ -52,6 +55,11 @@ struct pv_handle {
 };
 
 namespace {
+
+// What run_chain() commits (ping-pong half of the channel state, timeCursor, channel count).  The synchronous entry points take a snapshot
+// first and restore it when a later step -- the stream sync, a copy -- fails, so that a failed call leaves the handle as it was
+// (pv_get_time_cursor and the next output unchanged); the asynchronous pv_process_batch_device cannot know, its errors surface in pv_synchronize.
+struct Commit { int cur; int64_t time_cursor; int active_nch; };
 
 int fail(pv_handle *h, int code, const char *msg)
 {
@@ -180,10 +188,25 @@ const char *pv_status_string(int status)
 
 const char *pv_last_error(const pv_handle *h) { return live(h) ? h->err : g_create_err; }
 
+int pv_abi_version(void) { return PV_ABI_VERSION; }
+
+int pv_device_count(int32_t *out)
+{
+    if (!out) return PV_ERR_ARGUMENT;
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    (void)hipGetLastError();
+    *out = (e == hipSuccess && n > 0) ? n : 0;
+    return PV_OK;
+}
+
 int pv_create(const pv_config *cfg, pv_handle **out)
 {
     if (!cfg || !out) return fail(nullptr, PV_ERR_ARGUMENT, "pv_create: null argument");
     *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(pv_config))
+        return fail(nullptr, PV_ERR_ARGUMENT, "pv_create: pv_config.struct_size does not match this library (start from PV_CONFIG_INIT; PV_ABI_VERSION mismatch?)");
+    if (cfg->flags & ~(int32_t)PV_FLAG_ALL) return fail(nullptr, PV_ERR_ARGUMENT, "pv_create: unknown bits in pv_config.flags");
     const int N = cfg->fft_size;                                 // the host passes 2048 for the reference default (phase-vocoder.js:6)
     const int hop = cfg->hop_size;                               // ... and 128 (ola-processor.js:3)
     if (N <= 1 || (N & (N - 1)) != 0)                            // bundle:6-7
@@ -208,6 +231,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, PV_ERR_ARGUMENT, "device_id out of range");
 
     pv_handle *h = (pv_handle *)calloc(1, sizeof(pv_handle));
+    if (!h) return fail(nullptr, PV_ERR_DEVICE, "pv_create: out of host memory");
     h->magic = kMagic;
     h->N = N; h->hop = hop; h->L = N - hop; h->R = N / hop; h->log2n = log2n;
     h->max_channels = maxch; h->max_hops = maxhops; h->device = cfg->device_id;
@@ -351,6 +375,7 @@ int pv_reset(pv_handle *h)
     if (rc != PV_OK) return rc;
     h->time_cursor = 0;
     h->active_nch = -1;
+    h->pending_nch = 0;                                          // a quantum still in flight is abandoned (the memsets above queue behind it)
     return PV_OK;
 }
 
@@ -375,6 +400,7 @@ int pv_export_state(pv_handle *h, int32_t ch, float *hist, float *acc, int64_t *
 {
     if (!live(h)) return PV_ERR_DESTROYED;
     if (ch < 0 || ch >= h->max_channels) return fail(h, PV_ERR_ARGUMENT, "pv_export_state: channel out of range");
+    if (h->pending_nch > 0) return fail(h, PV_ERR_ARGUMENT, "pv_export_state: a quantum is pending (pv_process_end)");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t bytes = sizeof(float) * (size_t)h->L;
     if (hist && h->L) HIPCHK(h, hipMemcpyAsync(hist, h->d_hist[h->cur] + (size_t)ch * h->L, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -388,6 +414,7 @@ int pv_import_state(pv_handle *h, int32_t ch, const float *hist, const float *ac
 {
     if (!live(h)) return PV_ERR_DESTROYED;
     if (ch < 0 || ch >= h->max_channels) return fail(h, PV_ERR_ARGUMENT, "pv_import_state: channel out of range");
+    if (h->pending_nch > 0) return fail(h, PV_ERR_ARGUMENT, "pv_import_state: a quantum is pending (pv_process_end)");
     if (time_cursor >= 0 && time_cursor % h->hop != 0) return fail(h, PV_ERR_ARGUMENT, "pv_import_state: time_cursor is not a multiple of hop_size");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t bytes = sizeof(float) * (size_t)h->L;
@@ -413,14 +440,16 @@ int pv_synchronize(pv_handle *h)
     return PV_OK;
 }
 
-int pv_process(pv_handle *h, const float *const *in, float *const *out, int32_t nch, int32_t nsamples, float pitch_factor)
+int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t nsamples, float pitch_factor)
 {
     if (!live(h)) return PV_ERR_DESTROYED;
-    if (nch < 0 || (nch > 0 && !out)) return fail(h, PV_ERR_ARGUMENT, "pv_process: bad channel arguments");
+    if (h->pending_nch > 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_begin: the previous quantum has not been collected (pv_process_end)");
+    if (nch < 0) return fail(h, PV_ERR_ARGUMENT, "pv_process: bad channel arguments");
     if (nch > h->max_channels) return fail(h, PV_ERR_CAPACITY, "pv_process: nch exceeds max_channels");
     const bool paused = (nsamples == 0 || in == nullptr);                       // ola-processor.js:93-100
     if (!paused && nsamples != h->hop) return fail(h, PV_ERR_ARGUMENT, "pv_process: nsamples must equal hop_size (or 0 when paused)");
     HIPCHK(h, hipSetDevice(h->device));
+    const Commit before{h->cur, h->time_cursor, h->active_nch};
     if (h->active_nch >= 0 && nch != h->active_nch) {                           // ola-processor.js:38-52
         const int rc = pv_reset_channels(h, 0, h->max_channels);
         if (rc != PV_OK) return rc;
@@ -428,28 +457,60 @@ int pv_process(pv_handle *h, const float *const *in, float *const *out, int32_t 
     h->active_nch = nch;
     if (nch == 0) { h->time_cursor += h->hop; return PV_OK; }                   // pv:71 still advances
     const int hop = h->hop;
-    float *pin_in = h->h_pin + kHdrFloats, *pin_out = pin_in + (size_t)h->max_channels * hop;
+    float *pin_in = h->h_pin + kHdrFloats;
     h->h_pin[0] = pitch_factor;
     for (int c = 0; c < nch; c++) {
         if (paused || !in[c]) memset(pin_in + (size_t)c * hop, 0, sizeof(float) * hop);
         else memcpy(pin_in + (size_t)c * hop, in[c], sizeof(float) * hop);       // host block is only valid during the call (ola:64)
     }
-    if (h->d_pin_mapped) {
-        float *m_in = h->d_pin_mapped + kHdrFloats, *m_out = m_in + (size_t)h->max_channels * hop;
-        const int rc = run_chain(h, m_in, m_out, nch, 1, hop, h->d_pin_mapped, 0, 1, true, -1);
-        if (rc != PV_OK) return rc;
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    } else {
+    auto launch = [&]() -> int {
+        if (h->d_pin_mapped) {
+            float *m_in = h->d_pin_mapped + kHdrFloats, *m_out = m_in + (size_t)h->max_channels * hop;
+            return run_chain(h, m_in, m_out, nch, 1, hop, h->d_pin_mapped, 0, 1, true, -1);
+        }
         float *dq_in = h->d_quantum + kHdrFloats, *dq_out = dq_in + (size_t)h->max_channels * hop;
+        float *pin_out = pin_in + (size_t)h->max_channels * hop;
         HIPCHK(h, hipMemcpyAsync(h->d_quantum, h->h_pin, sizeof(float) * (kHdrFloats + (size_t)nch * hop), hipMemcpyHostToDevice, h->stream));
         const int rc = run_chain(h, dq_in, dq_out, nch, 1, hop, h->d_quantum, 0, 1, true, -1);
         if (rc != PV_OK) return rc;
         HIPCHK(h, hipMemcpyAsync(pin_out, dq_out, sizeof(float) * (size_t)nch * hop, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PV_OK;
+    };
+    const int rc = launch();
+    if (rc != PV_OK) { h->cur = before.cur; h->time_cursor = before.time_cursor; h->active_nch = before.active_nch; return rc; }
+    h->pending_nch = nch;
+    h->pending_cur = before.cur; h->pending_time_cursor = before.time_cursor; h->pending_active_nch = before.active_nch;
+    return PV_OK;
+}
+
+int pv_process_end(pv_handle *h, float *const *out)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    const int nch = h->pending_nch;
+    if (nch == 0 && h->active_nch == 0) return PV_OK;                            // a quantum without channels launched nothing
+    if (nch <= 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_end: no quantum is pending (pv_process_begin)");
+    if (!out) return fail(h, PV_ERR_ARGUMENT, "pv_process: bad channel arguments");
+    h->pending_nch = 0;
+    const int hop = h->hop;
+    const float *pin_out = h->h_pin + kHdrFloats + (size_t)h->max_channels * hop;
+    hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {                                                       // the state is committed only when the whole quantum succeeded
+        h->cur = h->pending_cur; h->time_cursor = h->pending_time_cursor; h->active_nch = h->pending_active_nch;
+        return fail_hip(h, e, "pv_process_end: stream synchronize");
     }
     for (int c = 0; c < nch; c++)
         if (out[c]) memcpy(out[c], pin_out + (size_t)c * hop, sizeof(float) * hop);
     return PV_OK;                                                                // ola-processor.js:170: return true
+}
+
+int pv_process(pv_handle *h, const float *const *in, float *const *out, int32_t nch, int32_t nsamples, float pitch_factor)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    if (nch > 0 && !out) return fail(h, PV_ERR_ARGUMENT, "pv_process: bad channel arguments");
+    const int rc = pv_process_begin(h, in, nch, nsamples, pitch_factor);
+    if (rc != PV_OK || nch == 0) return rc;
+    return pv_process_end(h, out);
 }
 
 int pv_process_batch_device(pv_handle *h, const float *d_in, float *d_out, int32_t nch, int32_t nhops, int64_t ch_stride,
@@ -457,6 +518,7 @@ int pv_process_batch_device(pv_handle *h, const float *d_in, float *d_out, int32
 {
     if (!live(h)) return PV_ERR_DESTROYED;
     if (!d_in || !d_out || !d_pitch || nch <= 0 || nhops <= 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: bad arguments");
+    if (h->pending_nch > 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: a quantum is pending (pv_process_end)");
     if (nch > h->max_channels) return fail(h, PV_ERR_CAPACITY, "pv_process_batch_device: nch exceeds max_channels");
     if (ch_stride < (int64_t)nhops * h->hop) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: ch_stride smaller than nhops*hop");
     if (pitch_stride != 0 && pitch_stride < nhops) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: pitch_stride smaller than nhops");
@@ -470,6 +532,7 @@ int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int
 {
     if (!live(h)) return PV_ERR_DESTROYED;
     if (!in || !out || !pitch || nch <= 0 || nhops <= 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: bad arguments");
+    if (h->pending_nch > 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: a quantum is pending (pv_process_end)");
     if (nch > h->max_channels || nhops > h->max_hops) return fail(h, PV_ERR_CAPACITY, "pv_process_batch: nch/nhops exceed the handle's capacity");
     const size_t row = (size_t)nhops * h->hop;
     if (ch_stride < (int64_t)row) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: ch_stride smaller than nhops*hop");
@@ -478,16 +541,22 @@ int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int
     const int cps = channels_per_stream > 0 ? channels_per_stream : 1;
     const int nrows = pitch_stride ? (nch + cps - 1) / cps : 1;
     if (pitch_stride && pitch_stride < nhops) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: pitch_stride smaller than nhops");
-    HIPCHK(h, hipMemcpy2DAsync(h->d_stage_in, row * sizeof(float), in, (size_t)ch_stride * sizeof(float), row * sizeof(float), nch,
-                               hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpy2DAsync(h->d_pitch, (size_t)nhops * sizeof(float), pitch, (size_t)(pitch_stride ? pitch_stride : nhops) * sizeof(float),
-                               (size_t)nhops * sizeof(float), nrows, hipMemcpyHostToDevice, h->stream));
-    const int rc = run_chain(h, h->d_stage_in, h->d_stage_out, nch, nhops, (long)row, h->d_pitch, pitch_stride ? nhops : 0, cps, true, -1);
-    if (rc != PV_OK) return rc;
-    HIPCHK(h, hipMemcpy2DAsync(out, (size_t)ch_stride * sizeof(float), h->d_stage_out, row * sizeof(float), row * sizeof(float), nch,
-                               hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return PV_OK;
+    const Commit before{h->cur, h->time_cursor, h->active_nch};
+    auto batch = [&]() -> int {
+        HIPCHK(h, hipMemcpy2DAsync(h->d_stage_in, row * sizeof(float), in, (size_t)ch_stride * sizeof(float), row * sizeof(float), nch,
+                                   hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpy2DAsync(h->d_pitch, (size_t)nhops * sizeof(float), pitch, (size_t)(pitch_stride ? pitch_stride : nhops) * sizeof(float),
+                                   (size_t)nhops * sizeof(float), nrows, hipMemcpyHostToDevice, h->stream));
+        const int rc = run_chain(h, h->d_stage_in, h->d_stage_out, nch, nhops, (long)row, h->d_pitch, pitch_stride ? nhops : 0, cps, true, -1);
+        if (rc != PV_OK) return rc;
+        HIPCHK(h, hipMemcpy2DAsync(out, (size_t)ch_stride * sizeof(float), h->d_stage_out, row * sizeof(float), row * sizeof(float), nch,
+                                   hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PV_OK;
+    };
+    const int rc = batch();
+    if (rc != PV_OK) { h->cur = before.cur; h->time_cursor = before.time_cursor; h->active_nch = before.active_nch; }   // a failed call leaves the handle as it was
+    return rc;
 }
 
 int pv_debug_frame(pv_handle *h, int32_t ch, const float *block, float pitch_factor, double *X, float *mag, int32_t *peak_flags, float *Y)

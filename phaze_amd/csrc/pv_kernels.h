@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <atomic>
 
 struct PvKernelParams {
     const float *in;          // planar input, channel c at in + c*ch_stride, nhops*hop samples
@@ -31,6 +32,19 @@ struct PvKernelParams {
     int dbg_ch, dbg_frame;
     unsigned *stamps;         // measurement builds only (-DPV_STAMPS, tools/exp_headline.sh): [chain][16] accumulated s_memtime deltas per phase
 };
+
+// One-time per-device raise of a kernel's dynamic-LDS limit, shared by the launchers.  Handles may be driven from different host threads: the
+// flags are atomics; two threads racing through a first launch both set the same attribute value, which is harmless.
+inline hipError_t pv_set_dynamic_lds_once(std::atomic<bool> (&done)[16], const void *kernel, int bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<bool> &f = done[dev & 15];
+    if (f.load(std::memory_order_acquire)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) f.store(true, std::memory_order_release);
+    return e;
+}
 
 int pv_kernel_threads(int log2n);
 size_t pv_kernel_lds_bytes(int log2n, int hop);

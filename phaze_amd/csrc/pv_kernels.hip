@@ -432,14 +432,11 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
 template <int LOG2N, int THREADS>
 hipError_t launch_one(const PvKernelParams &p, int nch, int nchunks, size_t lds, hipStream_t st)
 {
-    static bool attr_done[16] = {};
+    static std::atomic<bool> attr_done[16];
     auto k = pv_chain_kernel<LOG2N, THREADS>;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_done[dev & 15]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);   // __syncthreads_or keeps a few static bytes
+    {
+        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), 160 * 1024 - 512);   // __syncthreads_or keeps a few static bytes
         if (e != hipSuccess) return e;
-        attr_done[dev & 15] = true;
     }
     hipLaunchKernelGGL(k, dim3(nchunks, nch, 1), dim3(THREADS, 1, 1), lds, st, p);
     return hipGetLastError();

@@ -715,23 +715,23 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
 template <int HOPQ>
 hipError_t launch2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
-    static bool attr_done[16] = {};
+    static std::atomic<bool> attr_done[16];
     auto k = pv_wave2k_kernel<HOPQ>;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_done[dev & 15]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_wave2k_lds_bytes());
+    {
+        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_wave2k_lds_bytes());
         if (e != hipSuccess) return e;
-        attr_done[dev & 15] = true;
     }
     PvKernelParams q = p;
     q.nchunks = nchunks;
     q.nch = nch;
     const long chains = (long)nch * nchunks;
     // a streaming quantum has a handful of chains: spread them over the CUs instead of packing WAVES2 into one workgroup
-    static int cus[16] = {};
-    if (!cus[dev & 15]) { int c = 0; (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); cus[dev & 15] = c > 0 ? c : 1; }
-    long w = (chains + cus[dev & 15] - 1) / cus[dev & 15];
+    static std::atomic<int> cus_of[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int cus = cus_of[dev & 15].load(std::memory_order_relaxed);
+    if (!cus) { int c = 0; (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); cus = c > 0 ? c : 1; cus_of[dev & 15].store(cus, std::memory_order_relaxed); }
+    long w = (chains + cus - 1) / cus;
     if (w < PV_W2K_WMIN) w = PV_W2K_WMIN;
     if (w > WAVES2) w = WAVES2;
     hipLaunchKernelGGL(k, dim3((unsigned)((chains + w - 1) / w), 1, 1), dim3(64 * (unsigned)w, 1, 1), T2_BYTES + (size_t)w * WAVE2_LDS, st, q);

@@ -823,14 +823,11 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
 template <int S_ROWS, bool AUX>
 hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
-    static bool attr_done[16] = {};
+    static std::atomic<bool> attr_done[16];
     auto k = pv_wave_kernel_1024<S_ROWS, AUX>;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_done[dev & 15]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_wave_lds_bytes());
+    {
+        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_wave_lds_bytes());
         if (e != hipSuccess) return e;
-        attr_done[dev & 15] = true;
     }
     PvKernelParams q = p;
     q.nchunks = nchunks;

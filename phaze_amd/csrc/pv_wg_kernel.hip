@@ -831,16 +831,13 @@ template <int LOG2N, int S_ROWS, bool AUX>
 hipError_t launch_wg(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
     constexpr int G = 1 << (LOG2N - 10);
-    static bool attr_done[16] = {};
+    static std::atomic<bool> attr_done[16];
     auto k = pv_wg_kernel<LOG2N, S_ROWS, AUX>;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
     using CR = WgCfg<G, true>;
     constexpr int lds_bytes = S_ROWS ? WgCfg<G>::LDS_BYTES : CR::LDS_BYTES_RING;
-    if (!attr_done[dev & 15]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    {
+        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), lds_bytes);
         if (e != hipSuccess) return e;
-        attr_done[dev & 15] = true;
     }
     hipLaunchKernelGGL(k, dim3(nchunks, nch, 1), dim3(64 * G, 1, 1), lds_bytes, st, p);
     return hipGetLastError();

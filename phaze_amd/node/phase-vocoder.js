@@ -86,10 +86,19 @@ class PhaseVocoderProcessor extends Base {
         const pitchFactor = pf[pf.length - 1];                  // "no automation, take last value" (phase-vocoder.js:47)
         // paused: the newest hop of EVERY input is treated as zeros (ola-processor.js:93-100)
         const paused = inputs.length > 0 && inputs[0].length > 0 && inputs[0][0].length === 0;
+        if (this._handles.length === 1) {
+            const ins = paused ? inputs[0].map(() => PhaseVocoderProcessor._EMPTY) : inputs[0];
+            native.process(this._handles[0], ins, outputs[0] || [], pitchFactor);
+            return true;                                        // ola-processor.js:170
+        }
+        // several inputs = several independent processors (phase-vocoder.js:49-50): launch them all, then collect them all -- every
+        // kernel is in flight before the first wait, a quantum costs one exposed launch + wait instead of one per input
+        const counts = new Array(this._handles.length);
         for (let i = 0; i < this._handles.length; i++) {
             const ins = paused ? inputs[i].map(() => PhaseVocoderProcessor._EMPTY) : inputs[i];
-            native.process(this._handles[i], ins, outputs[i] || [], pitchFactor);
+            counts[i] = native.processBegin(this._handles[i], ins, pitchFactor);
         }
+        for (let i = 0; i < this._handles.length; i++) native.processEnd(this._handles[i], outputs[i] || [], counts[i]);
         return true;                                            // ola-processor.js:170
     }
 
@@ -101,6 +110,19 @@ class PhaseVocoderProcessor extends Base {
         this.reallocateChannelsIfNeeded(fake.concat(this._handles.slice(1).map((_, i) => ({ length: this._channels[i + 1] }))), null);
         return native.processBatch(this._handles[0], input, output, nch, nhops, pitchPerHop, 0, 1);
     }
+
+    /** The same batch on a worker thread: resolves to true when the output is complete.  The handle is busy until then. */
+    processBatchAsync(input, output, nch, nhops, pitchPerHop) {
+        if (nhops > this._maxHops) return Promise.reject(new Error("processBatch: nhops exceeds processorOptions.maxHops"));
+        const fake = [Array.from({ length: nch })];
+        this.reallocateChannelsIfNeeded(fake.concat(this._handles.slice(1).map((_, i) => ({ length: this._channels[i + 1] }))), null);
+        return native.processBatchAsync(this._handles[0], input, output, nch, nhops, pitchPerHop, 0, 1);
+    }
+
+    /** Everything the reference keeps for channel `ch` of input `input` between process() calls: {hist, acc, timeCursor}
+     *  (inputBuffers ola-processor.js:59, outputBuffers :77, timeCursor phase-vocoder.js:31) -- checkpoint / resume / migration. */
+    exportState(ch, input = 0) { return native.exportState(this._handles[input], ch); }
+    importState(ch, state, input = 0) { native.importState(this._handles[input], ch, state.hist || null, state.acc || null, state.timeCursor); }
 
     info() { return this._handles.length ? native.info(this._handles[0]) : null; }
 

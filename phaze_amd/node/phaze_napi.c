@@ -23,6 +23,10 @@
 typedef struct pv_slot {
     pv_handle *h;
     int32_t hop;
+    int32_t fft;
+    int busy;          /* an asynchronous batch runs on a worker thread: the handle accepts no other call until its promise settles */
+    int doomed;        /* destroy() arrived while busy: the completion callback destroys the handle */
+    int orphan;        /* the JS handle object was collected while busy: the completion callback also frees this slot */
 } pv_slot;
 
 #define NAPI_OK_OR_THROW(env, call, msg)                         \
@@ -48,6 +52,7 @@ static void finalize_handle(napi_env env, void *data, void *hint)
     (void)env; (void)hint;
     pv_slot *slot = (pv_slot *)data;
     if (slot) {
+        if (slot->busy) { slot->doomed = 1; slot->orphan = 1; return; }      /* the worker thread still owns it: batch_complete cleans up */
         if (slot->h) pv_destroy(slot->h);
         free(slot);
     }
@@ -78,6 +83,10 @@ static pv_slot *unwrap(napi_env env, napi_value v)
         napi_throw_error(env, "PV_6", pv_status_string(PV_ERR_DESTROYED));
         return NULL;
     }
+    if (slot->busy) {
+        napi_throw_error(env, "PV_BUSY", "handle is busy: an asynchronous batch has not settled yet (one caller per handle, ola-processor.js runs on one thread)");
+        return NULL;
+    }
     return slot;
 }
 
@@ -88,8 +97,7 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     napi_value argv[1];
     NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
     if (argc < 1) { napi_throw_type_error(env, NULL, "create(options) needs an options object"); return NULL; }
-    pv_config cfg;
-    memset(&cfg, 0, sizeof cfg);
+    pv_config cfg = PV_CONFIG_INIT;
     cfg.fft_size = get_i32_prop(env, argv[0], "fftSize", 2048);          /* phase-vocoder.js:6  */
     cfg.hop_size = get_i32_prop(env, argv[0], "hopSize", 128);           /* ola-processor.js:3  */
     cfg.max_channels = get_i32_prop(env, argv[0], "maxChannels", 2);
@@ -103,6 +111,10 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     pv_slot *slot = (pv_slot *)malloc(sizeof(pv_slot));
     slot->h = h;
     slot->hop = cfg.hop_size;
+    slot->fft = cfg.fft_size;
+    slot->busy = 0;
+    slot->doomed = 0;
+    slot->orphan = 0;
     napi_value ext;
     NAPI_OK_OR_THROW(env, napi_create_external(env, slot, finalize_handle, NULL, &ext), "napi_create_external failed");
     return ext;
@@ -116,7 +128,8 @@ static napi_value js_destroy(napi_env env, napi_callback_info info)
     void *p = NULL;
     if (argc >= 1 && napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
         pv_slot *slot = (pv_slot *)p;
-        if (slot->h) { pv_destroy(slot->h); slot->h = NULL; }
+        if (slot->busy) slot->doomed = 1;                   /* the worker thread still uses the handle: destroyed when its batch completes */
+        else if (slot->h) { pv_destroy(slot->h); slot->h = NULL; }
     }
     return NULL;
 }
@@ -213,6 +226,233 @@ static napi_value js_process_batch(napi_env env, napi_callback_info info)
     return t;
 }
 
+
+/* processBegin(handle, inputChannels, pitchFactor) / processEnd(handle, outputChannels) -> true: the quantum split into launch and wait
+ * (pv_process_begin / pv_process_end) so that a processor with several inputs -- one handle each, phase-vocoder.js:49-50 -- has every launch
+ * in flight before it waits for the first. */
+static napi_value js_process_begin(napi_env env, napi_callback_info info)
+{
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
+    if (argc < 3) { napi_throw_type_error(env, NULL, "processBegin(handle, inputs, pitchFactor)"); return NULL; }
+    pv_slot *slot = unwrap(env, argv[0]);
+    if (!slot) return NULL;
+    float *in[MAX_CH];
+    size_t inlen[MAX_CH];
+    const int nin = gather_channels(env, argv[1], in, inlen, MAX_CH);
+    if (nin < 0) { napi_throw_type_error(env, NULL, "inputs must be an array of Float32Array (<= 64 channels)"); return NULL; }
+    double pf = 1.0;
+    napi_get_value_double(env, argv[2], &pf);
+    int nsamples = slot->hop;
+    if (nin > 0 && inlen[0] == 0) nsamples = 0;                               /* paused (ola-processor.js:93) */
+    for (int c = 0; c < nin; c++)
+        if (nsamples && inlen[c] != (size_t)slot->hop) { napi_throw_range_error(env, NULL, "input block length must equal hopSize"); return NULL; }
+    const int rc = pv_process_begin(slot->h, (const float *const *)in, nin, nsamples, (float)pf);
+    if (rc != PV_OK) return throw_status(env, slot->h, rc);
+    napi_value n;
+    napi_create_int32(env, nin, &n);
+    return n;
+}
+
+static napi_value js_process_end(napi_env env, napi_callback_info info)
+{
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
+    if (argc < 2) { napi_throw_type_error(env, NULL, "processEnd(handle, outputs[, nInputChannels])"); return NULL; }
+    pv_slot *slot = unwrap(env, argv[0]);
+    if (!slot) return NULL;
+    float *out[MAX_CH], *outp[MAX_CH];
+    size_t outlen[MAX_CH];
+    const int nout = gather_channels(env, argv[1], out, outlen, MAX_CH);
+    if (nout < 0) { napi_throw_type_error(env, NULL, "outputs must be an array of Float32Array (<= 64 channels)"); return NULL; }
+    int32_t nin = nout;
+    if (argc > 2) napi_get_value_int32(env, argv[2], &nin);
+    if (nin > MAX_CH) nin = MAX_CH;
+    for (int c = 0; c < nin; c++) outp[c] = (c < nout && outlen[c] >= (size_t)slot->hop) ? out[c] : NULL;   /* phase-vocoder.js:51 */
+    const int rc = pv_process_end(slot->h, outp);
+    if (rc != PV_OK) return throw_status(env, slot->h, rc);
+    napi_value t;
+    napi_get_boolean(env, true, &t);
+    return t;
+}
+
+/* processBatchAsync(handle, in, out, nch, nhops, pitch[, pitchStride, channelsPerStream]) -> Promise<true>
+ * The batch of processBatch on a libuv worker thread (napi_async_work): the JS thread returns at once, so ONE Node process keeps a batch in
+ * flight on every GPU of the node (sharded.js: stream s -> handle s mod N).  The typed arrays are referenced until the promise settles. */
+typedef struct batch_job {
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref refs[3];
+    pv_slot *slot;
+    const float *in, *pitch;
+    float *out;
+    int32_t nch, nhops, pstride, cps;
+    int rc;
+    char err[256];
+} batch_job;
+
+static void batch_execute(napi_env env, void *data)
+{
+    (void)env;
+    batch_job *j = (batch_job *)data;
+    j->rc = pv_process_batch(j->slot->h, j->in, j->out, j->nch, j->nhops, (int64_t)j->nhops * j->slot->hop, j->pitch, j->pstride, j->cps);
+    if (j->rc != PV_OK) {
+        const char *m = pv_last_error(j->slot->h);
+        snprintf(j->err, sizeof j->err, "%s", (m && m[0]) ? m : pv_status_string(j->rc));
+    }
+}
+
+static void batch_complete(napi_env env, napi_status status, void *data)
+{
+    batch_job *j = (batch_job *)data;
+    pv_slot *slot = j->slot;
+    slot->busy = 0;
+    if (slot->doomed && slot->h) { pv_destroy(slot->h); slot->h = NULL; }
+    for (int i = 0; i < 3; i++) napi_delete_reference(env, j->refs[i]);
+    if (status == napi_ok && j->rc == PV_OK) {
+        napi_value t;
+        napi_get_boolean(env, true, &t);
+        napi_resolve_deferred(env, j->deferred, t);
+    } else {
+        napi_value msg, err;
+        napi_create_string_utf8(env, status == napi_ok ? j->err : "asynchronous work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &err);
+        napi_reject_deferred(env, j->deferred, err);
+    }
+    napi_delete_async_work(env, j->work);
+    free(j);
+    if (slot->orphan) free(slot);
+}
+
+static napi_value js_process_batch_async(napi_env env, napi_callback_info info)
+{
+    size_t argc = 8;
+    napi_value argv[8];
+    NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
+    if (argc < 6) { napi_throw_type_error(env, NULL, "processBatchAsync(handle, in, out, nch, nhops, pitch[, pitchStride, channelsPerStream])"); return NULL; }
+    pv_slot *slot = unwrap(env, argv[0]);
+    if (!slot) return NULL;
+    napi_typedarray_type ty;
+    size_t nin = 0, nout = 0, npitch = 0, off;
+    void *din = NULL, *dout = NULL, *dp = NULL;
+    napi_value ab;
+    if (napi_get_typedarray_info(env, argv[1], &ty, &nin, &din, &ab, &off) != napi_ok || ty != napi_float32_array ||
+        napi_get_typedarray_info(env, argv[2], &ty, &nout, &dout, &ab, &off) != napi_ok || ty != napi_float32_array ||
+        napi_get_typedarray_info(env, argv[5], &ty, &npitch, &dp, &ab, &off) != napi_ok || ty != napi_float32_array) {
+        napi_throw_type_error(env, NULL, "in, out and pitch must be Float32Array");
+        return NULL;
+    }
+    int32_t nch = 0, nhops = 0, pstride = 0, cps = 1;
+    napi_get_value_int32(env, argv[3], &nch);
+    napi_get_value_int32(env, argv[4], &nhops);
+    if (argc > 6) napi_get_value_int32(env, argv[6], &pstride);
+    if (argc > 7) napi_get_value_int32(env, argv[7], &cps);
+    const size_t need = (size_t)nch * (size_t)nhops * (size_t)slot->hop;
+    const size_t rows = pstride ? (size_t)((nch + (cps > 0 ? cps : 1) - 1) / (cps > 0 ? cps : 1)) : 1;
+    if (nch <= 0 || nhops <= 0 || nin < need || nout < need || npitch < (pstride ? (rows - 1) * (size_t)pstride + (size_t)nhops : (size_t)nhops)) {
+        napi_throw_range_error(env, NULL, "buffer sizes do not match nch*nhops*hopSize");
+        return NULL;
+    }
+    batch_job *j = (batch_job *)calloc(1, sizeof(batch_job));
+    if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    j->slot = slot; j->in = (const float *)din; j->out = (float *)dout; j->pitch = (const float *)dp;
+    j->nch = nch; j->nhops = nhops; j->pstride = pstride; j->cps = cps;
+    napi_value promise, name;
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok) { free(j); napi_throw_error(env, NULL, "napi_create_promise failed"); return NULL; }
+    napi_create_reference(env, argv[1], 1, &j->refs[0]);
+    napi_create_reference(env, argv[2], 1, &j->refs[1]);
+    napi_create_reference(env, argv[5], 1, &j->refs[2]);
+    napi_create_string_utf8(env, "phaze.processBatchAsync", NAPI_AUTO_LENGTH, &name);
+    if (napi_create_async_work(env, NULL, name, batch_execute, batch_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
+        for (int i = 0; i < 3; i++) napi_delete_reference(env, j->refs[i]);
+        free(j);
+        napi_throw_error(env, NULL, "could not queue the asynchronous batch");
+        return NULL;
+    }
+    slot->busy = 1;
+    return promise;
+}
+
+/* exportState(handle, channel) -> {hist: Float32Array(N - hop), acc: Float32Array(N - hop), timeCursor}
+ * importState(handle, channel, hist | null, acc | null[, timeCursor])            (pv_export_state / pv_import_state:
+ * what the reference keeps per channel between process() calls, ola-processor.js:59,77, phase-vocoder.js:31) */
+static napi_value js_export_state(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
+    if (argc < 2) { napi_throw_type_error(env, NULL, "exportState(handle, channel)"); return NULL; }
+    pv_slot *slot = unwrap(env, argv[0]);
+    if (!slot) return NULL;
+    int32_t ch = 0;
+    napi_get_value_int32(env, argv[1], &ch);
+    const size_t L = (size_t)(slot->fft - slot->hop);
+    napi_value abh, aba, hist, acc, o, tc;
+    void *ph = NULL, *pa = NULL;
+    NAPI_OK_OR_THROW(env, napi_create_arraybuffer(env, L * sizeof(float), &ph, &abh), "allocation failed");
+    NAPI_OK_OR_THROW(env, napi_create_arraybuffer(env, L * sizeof(float), &pa, &aba), "allocation failed");
+    int64_t t = 0;
+    const int rc = pv_export_state(slot->h, ch, (float *)ph, (float *)pa, &t);
+    if (rc != PV_OK) return throw_status(env, slot->h, rc);
+    napi_create_typedarray(env, napi_float32_array, L, abh, 0, &hist);
+    napi_create_typedarray(env, napi_float32_array, L, aba, 0, &acc);
+    napi_create_object(env, &o);
+    napi_set_named_property(env, o, "hist", hist);
+    napi_set_named_property(env, o, "acc", acc);
+    napi_create_int64(env, t, &tc);
+    napi_set_named_property(env, o, "timeCursor", tc);
+    return o;
+}
+
+static napi_value js_import_state(napi_env env, napi_callback_info info)
+{
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
+    if (argc < 4) { napi_throw_type_error(env, NULL, "importState(handle, channel, hist, acc[, timeCursor])"); return NULL; }
+    pv_slot *slot = unwrap(env, argv[0]);
+    if (!slot) return NULL;
+    int32_t ch = 0;
+    napi_get_value_int32(env, argv[1], &ch);
+    const size_t L = (size_t)(slot->fft - slot->hop);
+    const float *ptr[2] = {NULL, NULL};
+    for (int i = 0; i < 2; i++) {
+        napi_valuetype vt;
+        napi_typeof(env, argv[2 + i], &vt);
+        if (vt == napi_null || vt == napi_undefined) continue;
+        napi_typedarray_type ty;
+        size_t n = 0, off;
+        void *d = NULL;
+        napi_value ab;
+        if (napi_get_typedarray_info(env, argv[2 + i], &ty, &n, &d, &ab, &off) != napi_ok || ty != napi_float32_array || n != L) {
+            napi_throw_range_error(env, NULL, "hist / acc must be Float32Array(fftSize - hopSize) or null");
+            return NULL;
+        }
+        ptr[i] = (const float *)d;
+    }
+    int64_t t = -1;
+    if (argc > 4) {
+        napi_valuetype vt;
+        napi_typeof(env, argv[4], &vt);
+        if (vt == napi_number) napi_get_value_int64(env, argv[4], &t);
+    }
+    const int rc = pv_import_state(slot->h, ch, ptr[0], ptr[1], t);
+    if (rc != PV_OK) return throw_status(env, slot->h, rc);
+    return NULL;
+}
+
+static napi_value js_device_count(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    int32_t n = 0;
+    pv_device_count(&n);
+    napi_value v;
+    napi_create_int32(env, n, &v);
+    return v;
+}
+
 static napi_value js_reset(napi_env env, napi_callback_info info)
 {
     size_t argc = 3;
@@ -284,6 +524,12 @@ static napi_value init(napi_env env, napi_value exports)
         {"destroy", NULL, js_destroy, NULL, NULL, NULL, napi_enumerable, NULL},
         {"process", NULL, js_process, NULL, NULL, NULL, napi_enumerable, NULL},
         {"processBatch", NULL, js_process_batch, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"processBegin", NULL, js_process_begin, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"processEnd", NULL, js_process_end, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"processBatchAsync", NULL, js_process_batch_async, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"exportState", NULL, js_export_state, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"importState", NULL, js_import_state, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"deviceCount", NULL, js_device_count, NULL, NULL, NULL, napi_enumerable, NULL},
         {"reset", NULL, js_reset, NULL, NULL, NULL, napi_enumerable, NULL},
         {"timeCursor", NULL, js_time_cursor, NULL, NULL, NULL, napi_enumerable, NULL},
         {"info", NULL, js_info, NULL, NULL, NULL, napi_enumerable, NULL},

@@ -47,21 +47,28 @@ def test_errors_without_device():
     from phaze_amd import capi
     L = _lib()
     h = C.c_void_p()
-    cfg = capi._Config(1000, 250, 1, 1, 0, 0, 0)
+    cfg = capi.make_config(1000, 250)
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_FFT_SIZE
     assert L.pv_last_error(None).decode() == "FFT size must be a power of two and bigger than 1"     # bundle:6-7
-    cfg = capi._Config(1024, 300, 1, 1, 0, 0, 0)
+    cfg = capi.make_config(1024, 300)
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_ARGUMENT
-    cfg = capi._Config(16384, 4096, 1, 1, 0, 0, 0)
+    cfg = capi.make_config(16384, 4096)
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_UNSUPPORTED
     assert L.pv_status_string(capi.PV_ERR_DEVICE).decode() == "HIP device error"
+    # ABI guards (round 3): a config of another layout, or flag bits this build does not know, are refused before any device is touched
+    assert L.pv_abi_version() == capi.ABI_VERSION == int(re.search(r"#define PV_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    cfg = capi.make_config(1024, 256)
+    cfg.struct_size -= 4                                           # what a caller compiled against the round-2 header (no struct_size, 28 bytes) would pass
+    assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_ARGUMENT and "struct_size" in L.pv_last_error(None).decode()
+    cfg = capi.make_config(1024, 256, flags=0x40)
+    assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_ARGUMENT and "flags" in L.pv_last_error(None).decode()
     try:
         import torch
         has_gpu = torch.cuda.is_available()
     except Exception:
         has_gpu = False
     if not has_gpu:
-        cfg = capi._Config(1024, 256, 1, 1, 0, 0, 0)
+        cfg = capi.make_config(1024, 256)
         assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_DEVICE                           # fails loudly: no CPU fallback
         with pytest.raises(phaze_amd.PvError):
             phaze_amd.PhaseVocoder(fft_size=1024, hop_size=256)
@@ -95,6 +102,6 @@ def test_flag_constants_match_the_header():
     """The ctypes binding's FLAG_* values are the header's PV_FLAG_* enumerators."""
     hdr = open(os.path.join(ROOT, "include", "phaze_amd.h")).read()
     vals = dict(re.findall(r"(PV_FLAG_[A-Z_]+)\s*=\s*(\d+)", hdr))
-    assert vals == {"PV_FLAG_GENERIC_KERNEL": "1", "PV_FLAG_STREAM_COPY": "2", "PV_FLAG_WORKGROUP_KERNEL": "4"}
+    assert vals == {"PV_FLAG_GENERIC_KERNEL": "1", "PV_FLAG_STREAM_COPY": "2", "PV_FLAG_WORKGROUP_KERNEL": "4", "PV_FLAG_ALL": "7"}
     import phaze_amd
     assert (phaze_amd.FLAG_GENERIC_KERNEL, phaze_amd.FLAG_STREAM_COPY, phaze_amd.FLAG_WORKGROUP_KERNEL) == (1, 2, 4)

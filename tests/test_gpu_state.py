@@ -125,3 +125,29 @@ def test_colliding_scatter_is_reproducible_for_every_f(fft, hop, flags, pf):
     assert np.array_equal(np.concatenate(parts, axis=1), ref)
     yo = oracle_lib.Oracle(fft, hop, 2).process_planar(x, p)
     assert S.rms(ref.astype(np.float64) - yo) < REGRESSION_RMS
+
+
+def test_failed_call_leaves_the_handle_as_it_was():
+    """A synchronous entry point commits its state (ping-pong half, timeCursor) only when the whole call succeeded.  A launch the library must
+    refuse -- more than 65535 channel slots on a kernel that maps channels to grid.y -- returns an error, and the handle continues exactly like
+    one that never saw the call."""
+    import phaze_amd
+    fft, hop, T = 256, 64, 12                      # pv_chain_kernel (not a wave kernel): channels sit on grid.y
+    big = 65540
+    x = np.stack([S.make_signal("tonal", c, 2 * T * hop) for c in range(2)])
+    p = np.full(T, 1.3, np.float32)
+    pv = _pv(fft_size=fft, hop_size=hop, max_channels=big, max_hops=T)
+    ref = _pv(fft_size=fft, hop_size=hop, max_channels=2, max_hops=T)
+    y0 = pv.process_batch(x[:, :T * hop], p)
+    r0 = ref.process_batch(x[:, :T * hop], p)
+    assert np.array_equal(y0, r0)
+    cursor = pv.time_cursor
+    xb = np.zeros((big, T * hop), np.float32)
+    with pytest.raises(phaze_amd.PvError) as ei:
+        pv.process_batch(xb, p)
+    assert ei.value.status == phaze_amd.capi.PV_ERR_CAPACITY
+    assert pv.time_cursor == cursor == T * hop
+    y1 = pv.process_batch(x[:, T * hop:], p)
+    r1 = ref.process_batch(x[:, T * hop:], p)
+    pv.close(); ref.close()
+    assert np.array_equal(y1, r1)

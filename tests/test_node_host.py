@@ -42,7 +42,8 @@ def test_addon_loads_and_exports_surface():
       }));""")
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout)
-    assert d["native"] == sorted(["create", "destroy", "process", "processBatch", "reset", "timeCursor", "info"])
+    assert d["native"] == sorted(["create", "destroy", "process", "processBatch", "reset", "timeCursor", "info", "processBegin", "processEnd",
+                                  "processBatchAsync", "exportState", "importState", "deviceCount"])
     assert d["desc"] == [{"name": "pitchFactor", "defaultValue": 1}]          # phase-vocoder.js:17-22
     assert d["registered"] and d["hasProcess"]
 
@@ -145,3 +146,57 @@ def test_wav_cli_shifts_pitch(tmp_path):
         assert 600 < f_peak < 720, f_peak
         assert 0.5 < S.rms(y[8192:-8192]) / S.rms(x[8192:-8192]) < 1.5
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fft,hop,streams,cps,shards,pf", [(4096, 1024, 16, 8, 2, 1.25), (1024, 256, 5, 2, 3, 0.8)])
+def test_node_sharded_streams_in_flight_together(fft, hop, streams, cps, shards, pf, tmp_path):
+    """Multi-GPU through the product boundary (independence: phase-vocoder.js:49-50,71): ONE Node process, stream s -> handle s mod G,
+    every handle's batch started through the addon's asynchronous entry before the first wait.  On the one-GPU box the G handles share device 0
+    (two kernels in flight on two HIP streams).  The gathered result equals ONE handle bit for bit and the oracle to 2e-6; the busy guard,
+    the async/sync equivalence and a mid-stream migration through exportState / importState are checked on the way."""
+    _build()
+    T = 12
+    x = np.stack([S.make_signal("tonal", c + 100 * s, T * hop) for s in range(streams) for c in range(cps)])
+    p = np.stack([np.full(T, pf + 0.01 * s, np.float32) for s in range(streams)])
+    x.astype("<f4").tofile(tmp_path / "in.f32")
+    p.astype("<f4").tofile(tmp_path / "pitch.f32")
+    spec = {"fft": fft, "hop": hop, "nhops": T, "streams": streams, "cps": cps, "shards": shards, "in_file": str(tmp_path / "in.f32"),
+            "pitch_file": str(tmp_path / "pitch.f32"), "out_file": str(tmp_path / "out.f32")}
+    (tmp_path / "spec.json").write_text(json.dumps(spec))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node", "run_sharded.js"), str(tmp_path / "spec.json")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["shards"] == shards and res["requested"] == shards and res["replicas"] == min(shards, res["devices"])
+    assert res["equal_to_one_handle"] is True and res["async_equals_sync"] is True
+    assert res["busy_guard"] == "PV_BUSY"
+    assert res["state_cursor"] == T * hop and res["state_len"] == fft - hop and res["migrated_stream_continues_bit_exact"] is True
+    import oracle_lib
+    got = np.fromfile(tmp_path / "out.f32", dtype="<f4").reshape(streams * cps, T * hop)
+    for s in (0, streams - 1):
+        ref = oracle_lib.Oracle(fft, hop, cps).process_planar(x[s * cps:(s + 1) * cps], p[s])
+        assert S.rms(got[s * cps:(s + 1) * cps].astype(np.float64) - ref) < 2e-6
+
+
+@pytest.mark.gpu
+def test_node_sharded_bench_reports_what_it_measured():
+    """tools/bench_node_sharded.js: the Node-side counterpart of `bench.py --gpus N` -- asks for 8 GPUs, measures the devices that exist and says so."""
+    _build()
+    r = subprocess.run([NODE, os.path.join(ROOT, "tools", "bench_node_sharded.js"), "--gpus", "8", "--streams", "16", "--channels", "2", "--fft", "1024", "--hop", "256",
+                        "--hops", "64", "--steps", "3"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr + r.stdout
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["requested_gpus"] == 8 and j["replicas_measured"] == j["n_gpus"] == min(8, j["devices_present"]) and j["shards"] == 8
+    assert j["frames_per_s"] > 1e4 and j["output_rms_stream0"] > 1e-3
+
+
+@pytest.mark.gpu
+def test_node_two_inputs_cost_one_exposed_wait():
+    """numberOfInputs: 2 launches both handles before it waits (processBegin / processEnd): the quantum must be clearly cheaper than the two
+    launch + wait pairs of the sequential form (same process, same handles, measured back to back)."""
+    _build()
+    r = subprocess.run([NODE, os.path.join(ROOT, "tools", "bench_latency_node.js"), "600", "--inputs", "2"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr + r.stdout
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["inputs"] == 2 and j["sequential_p50"] is not None
+    assert j["p50"] < 0.85 * j["sequential_p50"], (j["p50"], j["sequential_p50"])
