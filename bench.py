@@ -116,7 +116,7 @@ def cpu_baseline(fft, hop, pitch, target_seconds=12.0):
 
 
 def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmup, label, local_rank, frames_per_chunk=0,
-            pitch_stride=0, ch_per_stream=1, parity_hops=0, seed=0):
+            pitch_stride=0, ch_per_stream=1, parity_hops=0, seed=0, repeats=1):
     """One workload: resident input, `warmup` + `steps` launches bracketed by HIP events on the launch stream.  Returns a dict."""
     import numpy as np
     from phaze_amd import shard
@@ -151,26 +151,31 @@ def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmu
                 break                       # a few streams are enough for a spot check
         parity = float(np.sqrt(err2 / cnt))
     pv.reset()
+    regions = []
     with torch.cuda.stream(stream):
         for _ in range(warmup):
             step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        for _ in range(steps):
-            step()
-        ev1.record(stream)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / steps                 # HIP events on the launch stream: average launch duration
-    elapsed, kernel_ms = shard.reduce_max([elapsed, kernel_ms], dist, dev)      # MAX over ranks
+        for _ in range(max(1, repeats)):          # every region: EXACTLY `steps` launches between barrier + synchronize on both sides
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record(stream)
+            for _ in range(steps):
+                step()
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            km = ev0.elapsed_time(ev1) / steps                # HIP events on the launch stream: average launch duration
+            regions.append(tuple(shard.reduce_max([el, km], dist, dev)))      # MAX over ranks
+    # the line reports the MEDIAN region (box noise is 1-2 % between regions, 3-4 % between boxes), all regions are listed next to it
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    elapsed, kernel_ms = regions[order[len(order) // 2]]
     info = pv.info()
     pv.close()
     frames = nch * T
@@ -178,7 +183,8 @@ def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmu
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     del x, y
     return {"label": label, "frames_per_step_rank": frames, "elapsed": elapsed, "kernel_ms": kernel_ms, "info": info,
-            "alg_bytes": alg_bytes, "achieved_gbs": achieved, "parity": parity}
+            "alg_bytes": alg_bytes, "achieved_gbs": achieved, "parity": parity,
+            "regions_ms_per_step": [r[0] / steps * 1e3 for r in regions], "regions_kernel_ms": [r[1] for r in regions]}
 
 
 def synth_stream(torch, nch, n0, n1, device):
@@ -318,6 +324,7 @@ def main():
     ap.add_argument("--hops", type=int, default=1 << 20, help="hops (frames per channel) per step")
     ap.add_argument("--pitch", type=float, default=1.5)
     ap.add_argument("--frames-per-chunk", type=int, default=0)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps launches each; the line reports the median region and lists all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-config lines and the latency histogram (profiling runs)")
     ap.add_argument("--allow-lib-override", action="store_true", help="accept PHAZE_LIB (A/B builds of the same ABI); recorded in the line")
@@ -393,10 +400,10 @@ def main():
         return
     pitch = torch.full((T,), args.pitch, device=dev, dtype=torch.float32)
     head = measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch, args.steps, args.warmup, "headline", local_rank,
-                   frames_per_chunk=args.frames_per_chunk, parity_hops=96 if rank == 0 else 0, seed=rank)
+                   frames_per_chunk=args.frames_per_chunk, parity_hops=96 if rank == 0 else 0, seed=rank, repeats=args.repeats)
 
     sg_ms = None
-    if args.scatter_gather and dist is not None and world > 1:
+    if args.scatter_gather and dist is not None:             # also at world size 1 under torchrun: the collectives still run through RCCL
         # the only exchange a multi-GPU job can have: whole streams out from rank 0 and results back (outside the timed region)
         x_all = (torch.stack([synth_input(torch, nch, T * hop, dev, seed=r) for r in range(world)]) if rank == 0
                  else torch.empty((0, nch, T * hop), device=dev, dtype=torch.float32))
@@ -445,6 +452,9 @@ def main():
                          "algorithmic_bytes_per_launch": head["alg_bytes"], "traffic_source": traffic_src,
                          "note": "algorithmic bytes = 2*hop*4 B per channel-frame; the kernel is issue/LDS-bound (fp64 FFT), see DESIGN.md"},
             "parity_rms_vs_oracle": head["parity"],
+            "timed_regions": {"count": len(head["regions_kernel_ms"]), "steps_each": args.steps, "reported": "median region",
+                              "ms_per_step": head["regions_ms_per_step"], "kernel_ms": head["regions_kernel_ms"],
+                              "kernel_ms_min": min(head["regions_kernel_ms"]), "kernel_ms_max": max(head["regions_kernel_ms"])},
         }
         if requested != world:
             out["requested_gpus"] = requested
@@ -455,6 +465,8 @@ def main():
             out["lib_override"] = os.environ["PHAZE_LIB"]
         if sg_ms is not None:
             out["scatter_gather_ms"] = sg_ms        # one step's input out + back over RCCL, outside the timed region
+        if dist is not None:
+            out["dist_backend"] = dist.get_backend()          # "nccl" = RCCL on ROCm: barrier, all_reduce(MAX) of the timing, scatter / gather
 
     if world == 1 and not args.no_extras:
         # ---- the other BASELINE configs, each a short measured line (same harness, same timing method) ----

@@ -144,9 +144,9 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     const int nchunks = (nhops + p.frames_per_chunk - 1) / p.frames_per_chunk;
     h->last_frames_per_chunk = p.frames_per_chunk;
     hipError_t e = hipSuccess;
-    if (h->use_wave2k && dbg_ch < 0) {
+    if (h->use_wave2k) {                                         // (pv_debug_frame runs the tap instance of the kernel the handle uses)
         e = pv_launch_wave2k(p, nch, nchunks, h->stream);
-    } else if (h->use_pair && dbg_ch < 0) {
+    } else if (h->use_pair) {
         e = pv_launch_pair(p, nch, nchunks, h->stream);
     } else {
         if (!h->use_wave && nch > 65535) return fail(h, PV_ERR_CAPACITY, "more than 65535 channel slots in one launch (grid.y limit): split the call");

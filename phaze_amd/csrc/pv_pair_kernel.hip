@@ -208,7 +208,8 @@ __device__ __forceinline__ int digitrev4_4k(int v, int nd)
 // added into Y.  Both waves of the workgroup run it (barriers inside).  The quarter buffer aliases the claim words: they are refilled afterwards.
 template <int R_>
 __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_pair(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
-                                                                               const float2 *__restrict__ tw32, int t, int upper_end, int up_delta, unsigned up_ridx)
+                                                                               const float2 *__restrict__ tw32, int t, int upper_end, int up_delta, unsigned up_ridx,
+                                                                               double *dbg_X)
 {
     constexpr int N = N4, H = H4, QN = N / 4, T = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -256,6 +257,8 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_pair(co
             }
             __syncthreads();
         }
+        if (dbg_X)
+            for (int i = t; i < QN; i += T) if (base + i >= H) { dbg_X[2 * (base + i)] = Q[i].x; dbg_X[2 * (base + i) + 1] = Q[i].y; }
         unsigned rt[8];
         float2 ys[8];
         int id[8];
@@ -275,7 +278,8 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_pair(co
 }
 
 // S_ROWS = hop / 512
-template <int S_ROWS>
+// AUX = true: test-tap instance (pv_debug_frame); the production instance carries no tap code.
+template <int S_ROWS, bool AUX>
 __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const PvKernelParams p)
 {
     constexpr int N = N4, M = M4, H = H4;
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
     asm volatile("" : "+v"(emit_v));
 
     for (int m = first_frame; m < last_out; ++m) {
+        const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
         int l = lane;
         asm volatile("" : "+v"(l));                                         // LDS addresses are recomputed per frame instead of hoisted (see pv_wg_kernel.hip)
         const int LL = 64 * g + l;                                          // lane id of the 16-bins-per-lane side
@@ -495,6 +500,13 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                 XB[i] = float2{(float)xb.x, (float)xb.y};
                 XC[i] = float2{(float)xc.x, (float)xc.y};
                 XD[i] = float2{(float)xd.x, (float)xd.y};
+                if (dbg) {
+                    const int k = l + 64 * r;
+                    p.dbg_X[2 * k] = xa.x; p.dbg_X[2 * k + 1] = xa.y;
+                    p.dbg_X[2 * (2048 - k)] = xb.x; p.dbg_X[2 * (2048 - k) + 1] = xb.y;
+                    p.dbg_X[2 * (1024 - k)] = xc.x; p.dbg_X[2 * (1024 - k) + 1] = xc.y;
+                    if (k != 0) { p.dbg_X[2 * (1024 + k)] = xd.x; p.dbg_X[2 * (1024 + k) + 1] = xd.y; }
+                }
             }
             if (G == 1 && l == 0) {                                         // k = 512: Z[512] = a0 - j a1, Z[1536] = a0 + j a1, the pair (512, 1536), W_4096^512 = e^{-j pi/4}
                 const double2 a0 = SO64[512], a1 = e512;
@@ -507,6 +519,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                 MAG[MAG0 + 1920] = (float)(x15.x * x15.x + x15.y * x15.y);
                 xm0 = float2{(float)x5.x, (float)x5.y};
                 xm1 = float2{(float)x15.x, (float)x15.y};
+                if (dbg) { p.dbg_X[2 * 512] = x5.x; p.dbg_X[2 * 512 + 1] = x5.y; p.dbg_X[2 * 1536] = x15.x; p.dbg_X[2 * 1536 + 1] = x15.y; }
             }
         };
         if (g == 0) finish_groups(std::integral_constant<int, 0>{});
@@ -564,7 +577,9 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                 cur = fl ? pd[i] : cur;
                 lastown[i] = cur;
                 firstown[i] = fl ? 1 : 0;                                   // flag, turned into the next-peak word below
+                if (dbg) { p.dbg_flags[16 * LL + i] = fl ? 1 : 0; p.dbg_mag[16 * LL + i] = __uint_as_float(mg[i + 2]); }
             }
+            if (dbg && LL == 127) { p.dbg_flags[2048] = 0; p.dbg_mag[2048] = __uint_as_float(mg[18]); }
             int nx = POSPD;
 #pragma unroll
             for (int i = 15; i >= 0; i--) { const bool fl = firstown[i] != 0; firstown[i] = nx; nx = fl ? pd[i] : nx; }
@@ -691,14 +706,21 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                         rt2[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
                         ys2[j] = rotate4k<R>(rt2[j], s2v[j], ROT);
                         id2[j] = b - N / 2;
+                        if (dbg && b < upper_end) { p.dbg_X[2 * b] = s2v[j].x; p.dbg_X[2 * b + 1] = s2v[j].y; }
                     }
                     claim_rounds_pair<4>(rt2, ys2, id2, Y, CLAIM);
                 } else {
-                    residue_scatter_pair<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, (int)threadIdx.x, upper_end, up_delta, up_ridx);
+                    residue_scatter_pair<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, (int)threadIdx.x, upper_end, up_delta, up_ridx,
+                                            dbg ? p.dbg_X : nullptr);
                 }
             }
         }
         __syncthreads();                                                   // barrier 5: Y complete
+        if (dbg) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const int k = (int)threadIdx.x + 128 * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
+            if (threadIdx.x == 0) { p.dbg_Y[2 * M] = Y[M].x; p.dbg_Y[2 * M + 1] = Y[M].y; }
+        }
         pv_prio(PH_C2R);
         // ---- c2r pre-pass (bundle:69-76,102-114 folded) and the decimation-in-frequency stage for this wave's four groups, packed fp32 ----
         //      Zc[k] = SC ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)), m = M - k;  A[q] = Zc[q] + Zc[q + 1024], B[q] = (Zc[q] - Zc[q + 1024]) e^{+2 pi j q / 2048}
@@ -844,11 +866,11 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
     }
 }
 
-template <int S_ROWS>
+template <int S_ROWS, bool AUX>
 hipError_t launch_pair(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
     static std::atomic<bool> attr_done[16];
-    auto k = pv_pair_kernel<S_ROWS>;
+    auto k = pv_pair_kernel<S_ROWS, AUX>;
     {
         const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_pair_lds_bytes());
         if (e != hipSuccess) return e;
@@ -869,11 +891,12 @@ bool pv_pair_supported(int log2n, int hop) { return log2n == 12 && (hop == 512 |
 
 hipError_t pv_launch_pair(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
+    const bool aux = (p.dbg_mag != nullptr);                              // pv_debug_frame: the tap instance of the SAME kernel
     switch (p.hop) {
-    case 512: return launch_pair<1>(p, nch, nchunks, st);
-    case 1024: return launch_pair<2>(p, nch, nchunks, st);
-    case 2048: return launch_pair<4>(p, nch, nchunks, st);
-    case 4096: return launch_pair<8>(p, nch, nchunks, st);
+    case 512: return aux ? launch_pair<1, true>(p, nch, nchunks, st) : launch_pair<1, false>(p, nch, nchunks, st);
+    case 1024: return aux ? launch_pair<2, true>(p, nch, nchunks, st) : launch_pair<2, false>(p, nch, nchunks, st);
+    case 2048: return aux ? launch_pair<4, true>(p, nch, nchunks, st) : launch_pair<4, false>(p, nch, nchunks, st);
+    case 4096: return aux ? launch_pair<8, true>(p, nch, nchunks, st) : launch_pair<8, false>(p, nch, nchunks, st);
     default: return hipErrorInvalidValue;
     }
 }

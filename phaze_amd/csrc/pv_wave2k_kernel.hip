@@ -170,7 +170,7 @@ __device__ __forceinline__ int digitrev4_2k(int v, int nd)
 template <int R_>
 __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
                                                                              const float2 *__restrict__ tw32, unsigned wave_off, int l, int upper_end, int up_delta,
-                                                                             unsigned up_ridx)
+                                                                             unsigned up_ridx, double *dbg_X)
 {
     constexpr int N = N2, H = H2, QN = N / 4, LOG2N = 11;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -212,6 +212,8 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(cons
             }
             wave_sync();
         }
+        if (dbg_X)
+            for (int i = l; i < QN; i += 64) if (base + i >= H) { dbg_X[2 * (base + i)] = Q[i].x; dbg_X[2 * (base + i) + 1] = Q[i].y; }
         unsigned rt[8];
         float2 ys[8];
         int id[8];
@@ -231,7 +233,9 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(cons
 // layouts: on even frames of a chain lane L holds samples 4L.. of its row (as always), on odd frames samples 4(L ^ 32)..; the slide is then a
 // lane-wise select between neighbouring rows, and the synthesis side of an odd frame (c2r, inverse FFTs, window) simply runs with the lane id
 // L ^ 32 -- every exchange there goes through LDS addresses, so relabelling the lanes costs nothing.
-template <int HOPQ>
+// AUX = true: test-tap instance (pv_debug_frame: X / |X|^2 / peak flags / Y of one frame, incl. the above-Nyquist residue); the production
+// instance carries no tap code.
+template <int HOPQ, bool AUX>
 __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kernel(const PvKernelParams p)
 {
     constexpr int N = N2, M = M2, H = H2;
@@ -350,6 +354,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
     for (int r = 0; r < 8; r++) hw[r] = HW4[r * 64 + lane];
 
     for (int m = first_frame; m < last_out; ++m) {
+        const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
         int l = lane;
         asm volatile("" : "+v"(l));                                       // LDS addresses are recomputed per frame instead of hoisted (see pv_wg_kernel.hip)
         const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));
@@ -406,11 +411,17 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
                 MAG[MAG0 + 1280 - ql - 80 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
                 XA[r] = float2{(float)xa.x, (float)xa.y};
                 XB[r] = float2{(float)xb.x, (float)xb.y};
+                if (dbg) {
+                    const int ka = l + 64 * r, kb = 1024 - ka;
+                    p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
+                    p.dbg_X[2 * kb] = xb.x; p.dbg_X[2 * kb + 1] = xb.y;
+                }
             }
             if (l == 0) {
                 const double2 x512{2.0 * zhi[0].x, -2.0 * zhi[0].y};        // k = 512 pairs with itself: X = 2 conj(Z[512])
                 MAG[MAG0 + 640] = (float)(x512.x * x512.x + x512.y * x512.y);
                 x512f = float2{(float)x512.x, (float)x512.y};
+                if (dbg) { p.dbg_X[2 * 512] = x512.x; p.dbg_X[2 * 512 + 1] = x512.y; }
             }
         }
         wave_sync();
@@ -481,6 +492,11 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
                 // candidates are 2 <= k < H - 2 = 1023 (pv:97-100): lane 0 drops i < 2, lane 63 drops i = 15
                 const bool in_range = (i < 2) ? (l != 0) : (i == 15) ? (l != 63) : true;
                 fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
+            }
+            if (dbg) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) { p.dbg_flags[16 * l + i] = fl[i] ? 1 : 0; p.dbg_mag[16 * l + i] = __uint_as_float(mg[i + 2]); }
+                if (l == 63) { p.dbg_flags[1024] = 0; p.dbg_mag[1024] = __uint_as_float(mg[18]); }
             }
             constexpr int NEGPD = -(4096 << 16), POSPD = 8192 << 16;        // "no peak on this side"
             int pd[16];
@@ -589,14 +605,21 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
                         rt2[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
                         ys2[j] = rotate2k<R>(rt2[j], s2v[j], ROT);
                         id2[j] = b;
+                        if (dbg && b < upper_end) { p.dbg_X[2 * b] = s2v[j].x; p.dbg_X[2 * b + 1] = s2v[j].y; }
                     }
                     claim_rounds2<4>(rt2, ys2, id2, Y, CLAIM);
                 } else {
-                    residue_scatter_2k<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, wave_off, l, upper_end, up_delta, up_ridx);
+                    residue_scatter_2k<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, wave_off, l, upper_end, up_delta, up_ridx,
+                                          dbg ? p.dbg_X : nullptr);
                 }
             }
         }
         wave_sync();
+        if (dbg) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const int k = l + 64 * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
+            if (l == 0) { p.dbg_Y[2048] = Y[1024].x; p.dbg_Y[2049] = Y[1024].y; }
+        }
         pv_prio(PH_C2R);
         // ---- c2r pre-pass in conjugate pairs (bundle:69-76,102-114 folded), packed fp32: Zc[k] = SC ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)), m = M - k ----
         pk::c32 zA[8], zB[8];                                              // Zc[l + 64 r], Zc[l + 64 r + 512]
@@ -712,11 +735,11 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
 #ifndef PV_W2K_WMIN
 #define PV_W2K_WMIN 2
 #endif
-template <int HOPQ>
+template <int HOPQ, bool AUX>
 hipError_t launch2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
     static std::atomic<bool> attr_done[16];
-    auto k = pv_wave2k_kernel<HOPQ>;
+    auto k = pv_wave2k_kernel<HOPQ, AUX>;
     {
         const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_wave2k_lds_bytes());
         if (e != hipSuccess) return e;
@@ -745,12 +768,13 @@ int pv_wave2k_threads() { return 64 * WAVES2; }
 bool pv_wave2k_supported(int log2n, int hop) { return log2n == 11 && (hop == 128 || hop == 256 || hop == 512 || hop == 1024 || hop == 2048); }
 hipError_t pv_launch_wave2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
+    const bool aux = (p.dbg_mag != nullptr);                              // pv_debug_frame: the tap instance of the SAME kernel
     switch (p.hop) {
-    case 128: return launch2k<1>(p, nch, nchunks, st);
-    case 256: return launch2k<2>(p, nch, nchunks, st);
-    case 512: return launch2k<4>(p, nch, nchunks, st);
-    case 1024: return launch2k<8>(p, nch, nchunks, st);
-    case 2048: return launch2k<16>(p, nch, nchunks, st);
+    case 128: return aux ? launch2k<1, true>(p, nch, nchunks, st) : launch2k<1, false>(p, nch, nchunks, st);
+    case 256: return aux ? launch2k<2, true>(p, nch, nchunks, st) : launch2k<2, false>(p, nch, nchunks, st);
+    case 512: return aux ? launch2k<4, true>(p, nch, nchunks, st) : launch2k<4, false>(p, nch, nchunks, st);
+    case 1024: return aux ? launch2k<8, true>(p, nch, nchunks, st) : launch2k<8, false>(p, nch, nchunks, st);
+    case 2048: return aux ? launch2k<16, true>(p, nch, nchunks, st) : launch2k<16, false>(p, nch, nchunks, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -9,15 +9,17 @@ from typing import List, Sequence
 
 
 def stream_partition(nstreams: int, world: int, rank: int) -> List[int]:
-    """Stream s runs on rank s mod world."""
+    """THE partition rule: stream s runs on rank s mod world.  Compute placement, scatter_streams / gather_streams and the Node host
+    (phaze_amd/node/sharded.js) all use it; round 2's second, contiguous-block rule is gone."""
     if world <= 0 or not (0 <= rank < world):
         raise ValueError("bad world/rank")
     return list(range(rank, nstreams, world))
 
 
 def reduce_max(values: Sequence[float], dist=None, device=None) -> List[float]:
-    """Element-wise MAX over ranks (identity without a process group)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    """Element-wise MAX over ranks (identity without a process group; WITH one the collective runs even at world size 1, so that a one-rank
+    torchrun exercises the backend -- RCCL on the GPU box)."""
+    if dist is None or not dist.is_initialized():
         return [float(v) for v in values]
     import torch
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
@@ -30,30 +32,21 @@ def aggregate_rate(units_per_rank: int, world: int, seconds_max: float) -> float
     return units_per_rank * world / seconds_max
 
 
-def block_partition(nstreams: int, world: int, rank: int) -> range:
-    """Contiguous block of streams for `rank` (the first `nstreams % world` ranks get one more): the layout scatter/gather move."""
-    if world <= 0 or not (0 <= rank < world):
-        raise ValueError("bad world/rank")
-    q, r = divmod(nstreams, world)
-    lo = rank * q + min(rank, r)
-    return range(lo, lo + q + (1 if rank < r else 0))
-
-
 def scatter_streams(x_all, nstreams: int, dist, src: int = 0):
-    """Rank `src` holds x_all = [nstreams, ...]; every rank returns its block_partition slice (a new tensor on x_all's device / dtype).
-    Other ranks pass a tensor of the right trailing shape, dtype and device (its contents are ignored; nstreams rows are not required)."""
+    """Rank `src` holds x_all = [nstreams, ...]; every rank returns the streams stream_partition gives it, in ascending order (a new tensor on
+    x_all's device / dtype).  Other ranks pass a tensor of the right trailing shape, dtype and device (contents ignored, no rows required)."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return x_all[:nstreams].clone()
     world, rank = dist.get_world_size(), dist.get_rank()
-    mine = block_partition(nstreams, world, rank)
+    mine = stream_partition(nstreams, world, rank)
     out = torch.empty((len(mine),) + tuple(x_all.shape[1:]), dtype=x_all.dtype, device=x_all.device)
     pieces = None
     if rank == src:
-        pieces = [x_all[block_partition(nstreams, world, r).start:block_partition(nstreams, world, r).stop].contiguous() for r in range(world)]
+        pieces = [x_all[r:nstreams:world].contiguous() for r in range(world)]
     if nstreams % world == 0:
         dist.scatter(out, pieces, src=src)
-    else:                                                    # unequal blocks: point-to-point (scatter wants equal sizes)
+    else:                                                    # unequal shares: point-to-point (scatter wants equal sizes)
         if rank == src:
             for r in range(world):
                 if r == src:
@@ -68,17 +61,17 @@ def scatter_streams(x_all, nstreams: int, dist, src: int = 0):
 def gather_streams(y_mine, nstreams: int, dist, dst: int = 0):
     """Inverse of scatter_streams: rank `dst` returns [nstreams, ...] in stream order, the others None."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return y_mine
     world, rank = dist.get_world_size(), dist.get_rank()
+    pieces = None
     if nstreams % world == 0:
         pieces = [torch.empty_like(y_mine) for _ in range(world)] if rank == dst else None
         dist.gather(y_mine.contiguous(), pieces, dst=dst)
-        return torch.cat(pieces, dim=0) if rank == dst else None
-    if rank == dst:
+    elif rank == dst:
         pieces = []
         for r in range(world):
-            n = len(block_partition(nstreams, world, r))
+            n = len(stream_partition(nstreams, world, r))
             if r == dst:
                 pieces.append(y_mine)
             else:
@@ -86,7 +79,11 @@ def gather_streams(y_mine, nstreams: int, dist, dst: int = 0):
                 if buf.numel():
                     dist.recv(buf, src=r)
                 pieces.append(buf)
-        return torch.cat(pieces, dim=0)
-    if y_mine.numel():
+    elif y_mine.numel():
         dist.send(y_mine.contiguous(), dst=dst)
-    return None
+    if rank != dst:
+        return None
+    out = torch.empty((nstreams,) + tuple(y_mine.shape[1:]), dtype=y_mine.dtype, device=y_mine.device)
+    for r in range(world):
+        out[r:nstreams:world] = pieces[r]
+    return out

@@ -32,7 +32,7 @@ x = shard.scatter_streams(x_all, nstreams, dist)                 # host tensors 
 n = x.shape[0]
 xd = x.reshape(n * nch, T * hop).to(dev).contiguous()
 yd = torch.empty_like(xd)
-pitch = torch.stack([torch.full((T,), 0.8 + 0.1 * (s % 7), dtype=torch.float32) for s in shard.block_partition(nstreams, world, rank)]).to(dev) if n else None
+pitch = torch.stack([torch.full((T,), 0.8 + 0.1 * (s % 7), dtype=torch.float32) for s in shard.stream_partition(nstreams, world, rank)]).to(dev) if n else None
 if n:
     pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=n * nch, max_hops=1, device_id=0)
     pv.process_batch_device(xd.data_ptr(), yd.data_ptr(), n * nch, T, T * hop, pitch.data_ptr(), T, nch)
@@ -82,3 +82,17 @@ def test_bench_time_shard_span_is_bit_exact():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["span_starts_bit_exact_vs_processed_lead_in"] is True and j["config"]["rank0_span"] == [49152, 65536] and j["config"]["halo_hops"] == 3
+
+
+def test_rccl_branch_runs_on_hardware_at_world_size_one():
+    """The driver's multi-GPU launch form with ONE rank: torch.distributed.run -> bench.py -> init_process_group("nccl") (= RCCL on ROCm) ->
+    barrier, all_reduce(MAX) of the timing on a device tensor, and scatter_streams / gather_streams of the step's input (--scatter-gather).
+    A one-GPU box cannot show scaling, but every collective of the N > 1 path executes through RCCL here."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29741",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--hops", "4096", "--no-extras", "--no-cpu-baseline",
+                        "--scatter-gather"], capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 1 and j["dist_backend"] == "nccl"
+    assert np.isfinite(j["scatter_gather_ms"]) and j["scatter_gather_ms"] > 0
+    assert j["parity_rms_vs_oracle"] < 2e-6 and len(j["timed_regions"]["kernel_ms"]) == 3

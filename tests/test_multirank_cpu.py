@@ -69,7 +69,7 @@ def _sg_worker(rank, world, port, nstreams, tmpdir):
     else:
         x_all = torch.empty((0, nch, T * hop), dtype=torch.float32)
     x = shard.scatter_streams(x_all, nstreams, dist)
-    assert x.shape[0] == len(shard.block_partition(nstreams, world, rank))
+    assert x.shape[0] == len(shard.stream_partition(nstreams, world, rank))
     y = torch.stack([torch.from_numpy(oracle_lib.Oracle(fft, hop, nch).process_planar(x[i].numpy(), np.full(T, 0.8, np.float32)).astype(np.float32))
                      for i in range(x.shape[0])]) if x.shape[0] else torch.empty((0, nch, T * hop), dtype=torch.float32)
     y_all = shard.gather_streams(y, nstreams, dist)
