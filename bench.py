@@ -491,6 +491,14 @@ def main():
             torch.full((T8,), 1.5, device=dev, dtype=torch.float32))
         add("native", f"the reference's shipped configuration (phase-vocoder.js:6, ola-processor.js:3): stereo 48 kHz FFT=2048 hop=128 (16 overlaps), "
             f"pitchFactor=1.0, 2 ch x {T3} hops resident", 2048, 128, 2, T3, torch.full((T3,), 1.0, device=dev, dtype=torch.float32))
+        # the unfavourable half of the reference's parameter range (sliders give f in [0.33, 3], www/index.html:23,28): f < 1 compresses the
+        # regions, the scatter collides (pv:169-170) and the last region reads above Nyquist
+        T2 = 1 << 20
+        add("f0.8", f"headline shape at pitchFactor=f32(0.8): mono 48 kHz FFT=1024 hop=256, 1 ch x {T2} hops resident", 1024, 256, 1, T2,
+            torch.full((T2,), 0.8, device=dev, dtype=torch.float32), steps=12, warm=4)
+        sw = (0.5 + 1.5 * (torch.arange(T2, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
+        add("sweep", f"headline shape with pitchFactor swept 0.5->2.0 per hop (period 64 hops): mono 48 kHz FFT=1024 hop=256, 1 ch x {T2} hops resident",
+            1024, 256, 1, T2, sw, steps=12, warm=4)
         out["configs"] = extras
         out["latency_us"] = latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True)
 

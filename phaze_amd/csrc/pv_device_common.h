@@ -104,6 +104,37 @@ __device__ __forceinline__ float2 rotate_route(unsigned route, float2 v, const f
 }
 
 
+// Register <-> lane transpose WITHOUT LDS: exchanges the register index (8 registers) with the HIGH three lane bits, one bit per stage (see
+// pv_wave_fft.h, "transpose 1 of the wave FFTs in registers"); used by the wave FFTs and by transpose 2 of the 8192-point workgroup FFT.
+template <int NDW>
+__device__ __forceinline__ void transpose_hi3_regs(unsigned (&w)[8][NDW])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++)                       // reg bit 2 <-> lane bit 5
+#pragma unroll
+        for (int d = 0; d < NDW; d++) {
+            const auto r = __builtin_amdgcn_permlane32_swap(w[k][d], w[k + 4][d], false, false);
+            w[k][d] = r[0]; w[k + 4][d] = r[1];
+        }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {                     // reg bit 1 <-> lane bit 4
+        const int k = (q & 1) | ((q & 2) << 1);       // 0, 1, 4, 5
+#pragma unroll
+        for (int d = 0; d < NDW; d++) {
+            const auto r = __builtin_amdgcn_permlane16_swap(w[k][d], w[k + 2][d], false, false);
+            w[k][d] = r[0]; w[k + 2][d] = r[1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k += 2)                    // reg bit 0 <-> lane bit 3
+#pragma unroll
+        for (int d = 0; d < NDW; d++) {
+            const unsigned a = w[k][d], b = w[k + 1][d];
+            w[k][d] = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xF, 0xC, false);       // lanes 8..15 of every row take B[l ^ 8]
+            w[k + 1][d] = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xF, 0x3, false);   // lanes 0..7 take A[l ^ 8]
+        }
+}
+
 // Wave-local ordering of LDS traffic: LDS instructions of one wave execute in order, so only the compiler must be fenced.
 __device__ __forceinline__ void wave_sync()
 {

@@ -62,35 +62,6 @@ template <int PHASE> __device__ __forceinline__ void pv_prio_t()
 #ifndef PV_PERM_T1
 #define PV_PERM_T1 3
 #endif
-template <int NDW>
-__device__ __forceinline__ void transpose_hi3_regs(unsigned (&w)[8][NDW])
-{
-#pragma unroll
-    for (int k = 0; k < 4; k++)                       // reg bit 2 <-> lane bit 5
-#pragma unroll
-        for (int d = 0; d < NDW; d++) {
-            const auto r = __builtin_amdgcn_permlane32_swap(w[k][d], w[k + 4][d], false, false);
-            w[k][d] = r[0]; w[k + 4][d] = r[1];
-        }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {                     // reg bit 1 <-> lane bit 4
-        const int k = (q & 1) | ((q & 2) << 1);       // 0, 1, 4, 5
-#pragma unroll
-        for (int d = 0; d < NDW; d++) {
-            const auto r = __builtin_amdgcn_permlane16_swap(w[k][d], w[k + 2][d], false, false);
-            w[k][d] = r[0]; w[k + 2][d] = r[1];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k += 2)                    // reg bit 0 <-> lane bit 3
-#pragma unroll
-        for (int d = 0; d < NDW; d++) {
-            const unsigned a = w[k][d], b = w[k + 1][d];
-            w[k][d] = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xF, 0xC, false);       // lanes 8..15 of every row take B[l ^ 8]
-            w[k + 1][d] = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xF, 0x3, false);   // lanes 0..7 take A[l ^ 8]
-        }
-}
-
 // 512-point complex FFT across one wave: in/out layout lane l, reg r <-> element l + 64 r.
 // TW1[k*64 + l] = W_512^{l k}, TW2[k*8 + n0] = W_64^{n0 k} (k = 1..7) live in LDS, shared by the waves of the workgroup,
 // already conjugated / rounded for the inverse fp32 instance.

@@ -350,12 +350,24 @@ __device__ PV_COLLIDE_ATTR PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 
         for (int r = 0; r < 4; r++) { XS[l + 64 * r] = X.a[r]; XS[512 - l - 64 * r] = X.b[r]; }
         if (l == 0) XS[256] = X.h;
         wave_sync();                                                   // (also: routes are in registers, CLAIM may overwrite ROUTE)
+        // The residue sources b = 513 .. upper_end - 1 land on the targets 513 + delta .. upper_end - 1 + delta, above every target of the last
+        // region's ordinary sources (b <= 512).  Unless a source of an EARLIER region reaches up there too (only when the last region is shorter
+        // than the overlap of its neighbour), nothing else touches those bins: they are still zero and the residue is stored, no claim rounds.
+        bool clash = false;
+#pragma unroll
+        for (int r = 0; r < 9; r++) { const unsigned t = rt[r] & 0xFFFFu; clash |= (t < 513u) && ((int)t > 512 + up_delta); }
+        const bool plain_res = !__any(clash);
         claim_rounds<9, true>(rt, ys, id, Y, CLAIM);
         unsigned rt2[2];
         float2 ys2[2];
         int id2[2];
         residue_fast_1024<R_>(tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X, rt2, ys2, id2);
-        claim_rounds<2, false>(rt2, ys2, id2, Y, CLAIM);
+        if (plain_res) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) if ((rt2[j] & 0xFFFFu) < 513u) Y[rt2[j] & 0xFFFFu] = float2{0.f + ys2[j].x, 0.f + ys2[j].y};
+        } else {
+            claim_rounds<2, false>(rt2, ys2, id2, Y, CLAIM);
+        }
         return;
     }
     wave_sync();                                                       // routes are in registers: CLAIM may overwrite ROUTE

@@ -27,6 +27,9 @@ namespace {
 
 // CT (compact twiddles, ring kernels): pass-A twiddle rows k = 1, 2, 4 only, the other four by products -- 8 KB per workgroup at G = 2, which is
 // what lets the native 2048/128 configuration keep 4 workgroups per CU next to its overlap-add ring
+#ifndef PV_WG_REG_T2
+#define PV_WG_REG_T2 1        // G = 8: transpose 2 of both FFTs in registers (0 = the round-2 LDS form, for A/B builds)
+#endif
 template <int G, bool CT = false>
 struct WgCfg {
     static constexpr int T = 64 * G, M = 512 * G, N = 1024 * G, H = M + 1;
@@ -89,15 +92,32 @@ __device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename 
     radix8<T_, INV>(a);
 #pragma unroll
     for (int k = 1; k < 8; k++) a[k] = cmul(a[k], twc<T_, INV>(TWB[(k - 1) * 8 * G + tlo]));
-#pragma unroll
-    for (int k = 0; k < 8; k++) S[k * C::P2 + kA1 * (8 * G + C::A2) + tlo] = a[k];
-    // transpose 2 stays inside the group of 8G <= 64 threads that share kA1, i.e. inside ONE wave: the LDS traffic of a wave executes in
-    // order, so a compiler fence replaces the two workgroup barriers (4 of the ~21 barriers of a frame)
-    wave_sync();
+    // transpose 2 stays inside the group of 8G <= 64 threads that share kA1, i.e. inside ONE wave.
     const int kB2 = tlo / G, ulo = tlo % G;               // destination role of this thread: (kA1, kB2, ulo)
+    if (G == 8 && PV_WG_REG_T2 && sizeof(T_) == 8) {
+        // G = 8: the exchange is register index <-> lane bits 5..3 of a full wave -- the register transpose of the wave FFTs (round 3):
+        // no LDS traffic (64 KB written + read per transform before), and no barrier in front of transpose 3 (nothing of this one is in LDS)
+        unsigned w[8][4];
 #pragma unroll
-    for (int n = 0; n < 8; n++) a[n] = S[kB2 * C::P2 + kA1 * (8 * G + C::A2) + n * G + ulo];
-    __syncthreads();                                      // the next transpose writes rows other waves still read here
+        for (int k = 0; k < 8; k++) {
+            const uint2 x = __builtin_bit_cast(uint2, (double)a[k].x), y = __builtin_bit_cast(uint2, (double)a[k].y);
+            w[k][0] = x.x; w[k][1] = x.y; w[k][2] = y.x; w[k][3] = y.y;
+        }
+        transpose_hi3_regs<4>(w);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            a[k].x = (T_)__builtin_bit_cast(double, uint2{w[k][0], w[k][1]});
+            a[k].y = (T_)__builtin_bit_cast(double, uint2{w[k][2], w[k][3]});
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) S[k * C::P2 + kA1 * (8 * G + C::A2) + tlo] = a[k];
+        // the LDS traffic of a wave executes in order, so a compiler fence replaces the two workgroup barriers (4 of the ~21 barriers of a frame)
+        wave_sync();
+#pragma unroll
+        for (int n = 0; n < 8; n++) a[n] = S[kB2 * C::P2 + kA1 * (8 * G + C::A2) + n * G + ulo];
+        __syncthreads();                                  // the next transpose writes rows other waves still read here
+    }
     // ---- pass C ----
     radix8<T_, INV>(a);
 #pragma unroll
@@ -160,13 +180,22 @@ __device__ __forceinline__ void fft_wg_inv_pk(pk::c32 (&a)[8], pk::c32 *S, const
     pk::radix8_inv(a);
 #pragma unroll
     for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], twc_inv_pk(TWB[(k - 1) * 8 * G + tlo]));
-#pragma unroll
-    for (int k = 0; k < 8; k++) S[k * C::P2 + kA1 * (8 * G + C::A2) + tlo] = a[k];
-    wave_sync();                                          // wave-local exchange (see fft_wg)
     const int kB2 = tlo / G, ulo = tlo % G;
+    if (G == 8 && PV_WG_REG_T2) {                         // register transpose, no barrier (see fft_wg)
+        unsigned w[8][2];
 #pragma unroll
-    for (int n = 0; n < 8; n++) a[n] = S[kB2 * C::P2 + kA1 * (8 * G + C::A2) + n * G + ulo];
-    __syncthreads();
+        for (int k = 0; k < 8; k++) { w[k][0] = __float_as_uint(a[k].x); w[k][1] = __float_as_uint(a[k].y); }
+        transpose_hi3_regs<2>(w);
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = pk::c32{__uint_as_float(w[k][0]), __uint_as_float(w[k][1])};
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) S[k * C::P2 + kA1 * (8 * G + C::A2) + tlo] = a[k];
+        wave_sync();                                      // wave-local exchange (see fft_wg)
+#pragma unroll
+        for (int n = 0; n < 8; n++) a[n] = S[kB2 * C::P2 + kA1 * (8 * G + C::A2) + n * G + ulo];
+        __syncthreads();
+    }
     pk::radix8_inv(a);
 #pragma unroll
     for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], twc_inv_pk(TWC[(k - 1) * G + ulo]));
