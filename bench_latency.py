@@ -17,11 +17,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(fft, hop, nch, fs, calls, sweep):
+def run(fft, hop, nch, fs, calls, sweep, flags=0):
     import numpy as np
     import phaze_amd
     import signals as S
-    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1)
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, flags=flags)
     L = pv._L
     x = np.stack([S.make_signal("tonal", c, 64 * hop) for c in range(nch)])
     fpt = C.POINTER(C.c_float)
@@ -44,7 +44,7 @@ def run(fft, hop, nch, fs, calls, sweep):
     hist = np.histogram(lat, bins=edges)[0].tolist()
     budget_us = hop / fs * 1e6
     return {"metric": "stream_call_latency_us", "config": {"workload": f"{nch}-ch {fs // 1000} kHz FFT={fft} hop={hop} " + ("pitchFactor sweep 0.5->2.0" if sweep else "pitchFactor 1.5"),
-                                                            "calls": calls},
+                                                            "calls": calls, "wait": "stream synchronize (PV_FLAG_STREAM_EVENT_WAIT)" if flags & 8 else "completion words in pinned memory (default)"},
             "p50": q(50), "p90": q(90), "p99": q(99), "max": float(lat.max()), "mean": float(lat.mean()),
             "realtime_budget_us": budget_us, "budget_over_p99": budget_us / q(99),
             "histogram_us_edges": edges[:-1] + ["inf"], "histogram_counts": hist,
@@ -54,9 +54,12 @@ def run(fft, hop, nch, fs, calls, sweep):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--calls", type=int, default=3000)
+    ap.add_argument("--event-wait", action="store_true", help="also run every configuration with PV_FLAG_STREAM_EVENT_WAIT (the round-2 wait) for the A/B")
     args = ap.parse_args()
     for cfg in [(8192, 2048, 8, 96000, True), (2048, 128, 2, 48000, False), (1024, 256, 1, 48000, False), (4096, 1024, 8, 48000, False)]:
         print(json.dumps(run(*cfg[:4], args.calls, cfg[4])), flush=True)
+        if args.event_wait:
+            print(json.dumps(run(*cfg[:4], args.calls, cfg[4], flags=8)), flush=True)
 
 
 if __name__ == "__main__":

@@ -73,7 +73,11 @@ enum {
                                  * zero-copy mapping of the pinned staging buffer                         */
     PV_FLAG_WORKGROUP_KERNEL = 4, /* N = 2048 / 4096: the workgroup-per-frame kernel (pv_wg_kernel) instead of the
                                   * one-wave (pv_wave2k_kernel) / wave-pair (pv_pair_kernel) kernels      */
-    PV_FLAG_ALL = 7              /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
+    PV_FLAG_STREAM_EVENT_WAIT = 8, /* streaming quantum: wait through hipStreamSynchronize (round-2 behaviour).  Default since round 3: every
+                                  * frame chain stores a sequence number into pinned host memory when its output is written and pv_process /
+                                  * pv_process_end spin on those words (bounded; falls back to the stream wait) -- the runtime's completion
+                                  * path costs more than the kernel of a quantum */
+    PV_FLAG_ALL = 15             /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
 };
 
 typedef struct pv_info {

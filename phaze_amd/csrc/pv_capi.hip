@@ -10,7 +10,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "../../include/phaze_amd.h"
 #include "pv_kernels.h"
@@ -37,12 +42,17 @@ struct pv_handle {
     float *h_pin;                                // pinned: [hdr | max_channels*hop in | max_channels*hop out]
     float *d_quantum;                            // device twin of h_pin
     float *d_pin_mapped;                         // device view of h_pin (zero-copy streaming quantum); null = stage through d_quantum
+    volatile unsigned *h_done;                   // pinned: completion word of every frame chain of a streaming quantum (PvKernelParams::done)
+    unsigned *d_done;                            // device view of h_done; null = wait through hipStreamSynchronize
+    unsigned quantum_seq;                        // sequence number the chains of the pending quantum store (never 0)
     double *d_dbgX; float *d_dbgMag; int *d_dbgFlags; float *d_dbgY;
 #ifdef PV_STAMPS
     unsigned *d_stamps;                          // measurement builds only: [chain][16] phase clocks of the wave kernel
 #endif
     int64_t time_cursor;
     int active_nch;
+    int used_channels;                           // channel slots [used_channels, max_channels) have not been processed since they were last zeroed:
+                                                 // they are zero in BOTH ping-pong halves and need no copy across a flip
     int pending_nch;                             // > 0: a quantum launched by pv_process_begin waits for pv_process_end
     int pending_cur, pending_active_nch;         // ... and what to restore if that wait fails
     int64_t pending_time_cursor;
@@ -124,7 +134,7 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
 
 // One launch over [nch] channel slots x [nhops] hops; flips the state ping-pong and advances timeCursor.
 int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops, long ch_stride, const float *d_pitch,
-              int pitch_stride, int ch_per_stream, bool commit, int dbg_ch)
+              int pitch_stride, int ch_per_stream, bool commit, int dbg_ch, unsigned done_seq = 0)
 {
     PvKernelParams p;
     memset(&p, 0, sizeof p);
@@ -137,6 +147,7 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     p.t0_mod_n = (int)(h->time_cursor & (int64_t)(h->N - 1));
     p.tw64 = h->d_tw64; p.tw32 = h->d_tw32; p.hann = h->d_hann;
     p.dbg_ch = -1; p.dbg_frame = -1;
+    if (done_seq) { p.done = h->d_done; p.done_seq = done_seq; }
 #ifdef PV_STAMPS
     p.stamps = h->d_stamps;
 #endif
@@ -157,8 +168,9 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
     if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
     if (commit) {
         // channels outside [0, nch) keep their state: copy them across the ping-pong flip
-        if (nch < h->max_channels && h->L > 0) {
-            const size_t off = (size_t)nch * h->L, cnt = (size_t)(h->max_channels - nch) * h->L * sizeof(float);
+        if (nch > h->used_channels) h->used_channels = nch;
+        if (nch < h->used_channels && h->L > 0) {
+            const size_t off = (size_t)nch * h->L, cnt = (size_t)(h->used_channels - nch) * h->L * sizeof(float);
             HIPCHK(h, hipMemcpyAsync(h->d_hist[h->cur ^ 1] + off, h->d_hist[h->cur] + off, cnt, hipMemcpyDeviceToDevice, h->stream));
             HIPCHK(h, hipMemcpyAsync(h->d_acc[h->cur ^ 1] + off, h->d_acc[h->cur] + off, cnt, hipMemcpyDeviceToDevice, h->stream));
         }
@@ -307,6 +319,16 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         (void)hipGetLastError();
     }
     CHK(hipMalloc(&h->d_quantum, quantum));
+    if (h->d_pin_mapped && !(cfg->flags & PV_FLAG_STREAM_EVENT_WAIT)) {
+        // completion words of the streaming quantum, one per channel slot, in pinned host memory the kernels store to
+        unsigned *hd = nullptr;
+        void *dd = nullptr;
+        CHK(hipHostMalloc((void **)&hd, sizeof(unsigned) * (size_t)maxch, hipHostMallocMapped));
+        memset(hd, 0, sizeof(unsigned) * (size_t)maxch);
+        h->h_done = hd;
+        if (hipHostGetDevicePointer(&dd, hd, 0) == hipSuccess) h->d_done = (unsigned *)dd;
+        (void)hipGetLastError();
+    }
     CHK(hipMalloc(&h->d_dbgX, sizeof(double) * 2 * N));
     CHK(hipMalloc(&h->d_dbgMag, sizeof(float) * (N / 2 + 1)));
     CHK(hipMalloc(&h->d_dbgFlags, sizeof(int) * (N / 2 + 1)));
@@ -330,6 +352,7 @@ int pv_destroy(pv_handle *h)
     for (int i = 0; i < 2; i++) { (void)hipFree(h->d_hist[i]); (void)hipFree(h->d_acc[i]); }
     (void)hipFree(h->d_stage_in); (void)hipFree(h->d_stage_out); (void)hipFree(h->d_pitch);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->h_done) (void)hipHostFree((void *)h->h_done);
     (void)hipFree(h->d_quantum);
     (void)hipFree(h->d_dbgX); (void)hipFree(h->d_dbgMag); (void)hipFree(h->d_dbgFlags); (void)hipFree(h->d_dbgY);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -363,8 +386,11 @@ int pv_reset_channels(pv_handle *h, int32_t first, int32_t count)
     if (count == 0 || h->L == 0) return PV_OK;
     HIPCHK(h, hipSetDevice(h->device));
     const size_t off = (size_t)first * h->L, bytes = sizeof(float) * (size_t)count * h->L;
-    HIPCHK(h, hipMemsetAsync(h->d_hist[h->cur] + off, 0, bytes, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_acc[h->cur] + off, 0, bytes, h->stream));
+    for (int i = 0; i < 2; i++) {                                  // both ping-pong halves: a zeroed slot stays zero across flips without a copy
+        HIPCHK(h, hipMemsetAsync(h->d_hist[i] + off, 0, bytes, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_acc[i] + off, 0, bytes, h->stream));
+    }
+    if (first + count >= h->used_channels && first < h->used_channels) h->used_channels = first;
     return PV_OK;
 }
 
@@ -421,6 +447,7 @@ int pv_import_state(pv_handle *h, int32_t ch, const float *hist, const float *ac
     if (hist && h->L) HIPCHK(h, hipMemcpyAsync(h->d_hist[h->cur] + (size_t)ch * h->L, hist, bytes, hipMemcpyHostToDevice, h->stream));
     if (acc && h->L) HIPCHK(h, hipMemcpyAsync(h->d_acc[h->cur] + (size_t)ch * h->L, acc, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));              // the host buffers are the caller's again on return
+    if (ch + 1 > h->used_channels) h->used_channels = ch + 1;
     if (time_cursor >= 0) h->time_cursor = time_cursor;
     return PV_OK;
 }
@@ -466,7 +493,9 @@ int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t 
     auto launch = [&]() -> int {
         if (h->d_pin_mapped) {
             float *m_in = h->d_pin_mapped + kHdrFloats, *m_out = m_in + (size_t)h->max_channels * hop;
-            return run_chain(h, m_in, m_out, nch, 1, hop, h->d_pin_mapped, 0, 1, true, -1);
+            unsigned seq = 0;
+            if (h->d_done) { seq = ++h->quantum_seq; if (seq == 0) seq = h->quantum_seq = 1; }
+            return run_chain(h, m_in, m_out, nch, 1, hop, h->d_pin_mapped, 0, 1, true, -1, seq);
         }
         float *dq_in = h->d_quantum + kHdrFloats, *dq_out = dq_in + (size_t)h->max_channels * hop;
         float *pin_out = pin_in + (size_t)h->max_channels * hop;
@@ -493,8 +522,29 @@ int pv_process_end(pv_handle *h, float *const *out)
     h->pending_nch = 0;
     const int hop = h->hop;
     const float *pin_out = h->h_pin + kHdrFloats + (size_t)h->max_channels * hop;
-    hipError_t e = hipSetDevice(h->device);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipError_t e = hipSuccess;
+    bool done = false;
+    if (h->d_done && h->d_pin_mapped) {
+        // every chain of the quantum stores the sequence number into its word once its output sits in the pinned buffer: spin on them (a
+        // quantum is a few microseconds of kernel; the runtime's own completion path -- signal, interrupt, wake-up -- costs more than that).
+        // Bounded: after 200 ms without completion the stream wait below reports whatever went wrong.
+        const unsigned seq = h->quantum_seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; spins++) {
+            int c = 0;
+            while (c < nch && h->h_done[c] == seq) c++;
+            if (c == nch) { done = true; break; }
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+            if ((spins & 0x3FFu) == 0x3FFu && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!done) {
+        e = hipSetDevice(h->device);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
     if (e != hipSuccess) {                                                       // the state is committed only when the whole quantum succeeded
         h->cur = h->pending_cur; h->time_cursor = h->pending_time_cursor; h->active_nch = h->pending_active_nch;
         return fail_hip(h, e, "pv_process_end: stream synchronize");

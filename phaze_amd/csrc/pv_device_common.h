@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "pv_signal.h"
 
 // Measured on gfx950 (tools/lds_microbench.hip): ds_read2_b64 / ds_read2st64_b64 / ds_read2_b32 occupy the LDS pipe for 8 cycles, twice
 // the cost of the two single reads they replace (2 + 2); ds_write2_b64 is neutral.  The SI load/store optimizer forms them wherever

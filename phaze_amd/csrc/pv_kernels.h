@@ -30,6 +30,10 @@ struct PvKernelParams {
     int *dbg_flags;
     float *dbg_Y;
     int dbg_ch, dbg_frame;
+    // streaming quantum (pv_process): when non-null, every frame chain stores done_seq into done[chain] once its output (and state) is written,
+    // and the host spins on those words in pinned memory instead of going through hipStreamSynchronize (null in batch launches)
+    unsigned *done;
+    unsigned done_seq;
     unsigned *stamps;         // measurement builds only (-DPV_STAMPS, tools/exp_headline.sh): [chain][16] accumulated s_memtime deltas per phase
 };
 

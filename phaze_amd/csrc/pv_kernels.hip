@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "pv_kernels.h"
+#include "pv_signal.h"
 
 namespace {
 
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
             p.hist_out[(long)ch * L + j] = src.at((long)p.nhops * hop - L + j);
         }
     }
+    pv_signal_done<true>(p.done, p.done_seq, (long)ch * gridDim.x + chunk);
 }
 
 template <int LOG2N, int THREADS>

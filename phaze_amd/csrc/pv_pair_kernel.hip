@@ -864,6 +864,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
             hs[0] = src.at(s); hs[1] = src.at(s + 1); hs[4] = src.at(s + 4); hs[5] = src.at(s + 5);
         }
     }
+    pv_signal_done<true>(p.done, p.done_seq, chain);
 }
 
 template <int S_ROWS, bool AUX>

@@ -730,6 +730,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             }
         }
     }
+    pv_signal_done<false>(p.done, p.done_seq, chain);
 }
 
 #ifndef PV_W2K_WMIN

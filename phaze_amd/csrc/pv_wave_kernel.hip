@@ -830,6 +830,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
             hs[0] = src.at(s); hs[1] = src.at(s + 1);
         }
     }
+    pv_signal_done<false>(p.done, p.done_seq, chain);
 }
 
 template <int S_ROWS, bool AUX>

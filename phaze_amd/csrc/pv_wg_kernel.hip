@@ -854,6 +854,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
             hs[0] = src.at(s); hs[1] = src.at(s + 1);
         }
     }
+    pv_signal_done<true>(p.done, p.done_seq, (long)ch * gridDim.x + chunk);
 }
 
 template <int LOG2N, int S_ROWS, bool AUX>
