@@ -261,14 +261,20 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
         }
         __syncthreads();
         // ---- 5. strict +-2 local maxima (pv:95-116) as a local predicate -> bit masks via ballot ----
+        // Non-finite magnitudes (NaN / Inf samples in the window): in the reference every comparison with a NaN fails to REJECT (pv:103,107),
+        // peaks appear at every other bin and the NaNs they move reach every output sample: the frame is NaN.  The predicate below finds no
+        // peak there, so such a frame is detected here and poisoned after the scatter (same rule as the register kernels).
+        bool nonfinite = false;
         for (int w = wave; w < NWORDS; w += NWAVES) {
             const int k = w * 64 + lane;
-            bool f = false;
+            bool f = false, nf = false;
+            if (k < H) nf = !(magv[k] < __builtin_huge_valf());
             if (k >= 2 && k < H - 2) {
                 const float mg = magv[k];
                 f = (magv[k - 1] < mg) && (magv[k - 2] < mg) && (magv[k + 1] < mg) && (magv[k + 2] < mg);
             }
             const unsigned long long bm = __ballot(f);
+            nonfinite |= __any(nf);
             if (lane == 0) masks[w] = bm;
         }
         __syncthreads();
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
                 }
             }
         }
+        if (nonfinite && lane == 0) B[1 + wave] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};
         __syncthreads();
         if (p.dbg_Y && ch == p.dbg_ch && m == p.dbg_frame)
             for (int k = tid; k < H; k += THREADS) { p.dbg_Y[2 * k] = B[k].x; p.dbg_Y[2 * k + 1] = B[k].y; }

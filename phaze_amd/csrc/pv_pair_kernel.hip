@@ -32,7 +32,9 @@
 #include "pv_kernels.h"
 #include "pv_device_common.h"
 #include "pv_pk_math.h"
+#ifndef PV_PT
 #define PV_PT 2, 0, 2, 3, 3, 3, 3, 3, 1, 0, 1, 3     // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C4 0.92 -> 0.83 ms)
+#endif
 #include "pv_wave_fft.h"
 
 namespace {
@@ -543,6 +545,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
         pv_prio(PH_PEAKS);
         // ---- peak flags (pv:95-116) for bins 16 LL .. 16 LL + 15, nearest peaks inside the wave ----
         int last_shift = 0;
+        bool nonfinite = false;                                             // a magnitude of this wave's bins is Inf or NaN (see pv_wave_kernel.hip)
         unsigned rt[16];
         unsigned rtM = NOROUTE;
         int lastown[16], firstown[16], last_in, first_in, cprev, cnext;
@@ -578,6 +581,12 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                 lastown[i] = cur;
                 firstown[i] = fl ? 1 : 0;                                   // flag, turned into the next-peak word below
                 if (dbg) { p.dbg_flags[16 * LL + i] = fl ? 1 : 0; p.dbg_mag[16 * LL + i] = __uint_as_float(mg[i + 2]); }
+            }
+            {
+                unsigned mx = mg[2];
+#pragma unroll
+                for (int j = 3; j < 19; j += 2) mx = max(mx, pm[j]);
+                nonfinite = __any(mx >= 0x7F800000u);
             }
             if (dbg && LL == 127) { p.dbg_flags[2048] = 0; p.dbg_mag[2048] = __uint_as_float(mg[18]); }
             int nx = POSPD;
@@ -715,6 +724,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                 }
             }
         }
+        if (nonfinite && l == 0) Y[1 + g] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};   // the reference's frame is NaN: so is this one
         __syncthreads();                                                   // barrier 5: Y complete
         if (dbg) {
 #pragma unroll

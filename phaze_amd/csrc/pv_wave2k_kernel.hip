@@ -27,7 +27,9 @@
 #include "pv_kernels.h"
 #include "pv_device_common.h"
 #include "pv_pk_math.h"
+#ifndef PV_PT
 #define PV_PT 1, 0, 1, 2, 2, 2, 2, 2, 0, 0, 0, 2     // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C3 3.76 -> 3.31 ms)
+#endif
 #include "pv_wave_fft.h"
 
 namespace {
@@ -469,6 +471,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
         pv_prio(PH_PEAKS);
         // ---- peak flags (pv:95-116) for bins 16l..16l+15, nearest peaks, one ROUTE word per source bin ----
         int last_peak = -1, last_shift = 0;
+        bool nonfinite = false;                                             // a magnitude of this frame is Inf or NaN (see pv_wave_kernel.hip)
         {
             unsigned mg[20];
             typedef const volatile __attribute__((address_space(3))) v2u *lds_v2u;
@@ -492,6 +495,12 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
                 // candidates are 2 <= k < H - 2 = 1023 (pv:97-100): lane 0 drops i < 2, lane 63 drops i = 15
                 const bool in_range = (i < 2) ? (l != 0) : (i == 15) ? (l != 63) : true;
                 fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
+            }
+            {
+                unsigned mx = mg[2];
+#pragma unroll
+                for (int j = 3; j < 19; j += 2) mx = max(mx, pm[j]);
+                nonfinite = __any(mx >= 0x7F800000u);
             }
             if (dbg) {
 #pragma unroll
@@ -614,6 +623,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
                 }
             }
         }
+        if (nonfinite && l == 0) Y[1] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};   // the reference's frame is NaN: so is this one
         wave_sync();
         if (dbg) {
 #pragma unroll

@@ -591,6 +591,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
         pv_prio(PH_PEAKS);
         // ---- peak flags (pv:95-116) for bins 8l..8l+7, nearest peaks by wave scans, then one ROUTE word per source bin ----
         int last_peak = -1, last_shift = 0;
+        bool nonfinite = false;                                             // wave-uniform: a magnitude of this frame is Inf or NaN
         if (!(PV_ABL & 16)) {
             // |X|^2 >= 0, so the fp32 order of two magnitudes is the order of their bit patterns as unsigned integers: the strict test
             // "greater than all four neighbours" (pv:100-110, `>=` rejects) becomes c > max(neighbours) with v_max3_u32 -- two instructions per
@@ -615,6 +616,10 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
                 const bool in_range = (i < 2) ? (l != 0) : (i == 7) ? (l != 63) : true;
                 fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
             }
+            // Non-finite magnitudes (NaN / Inf samples in the window): the order of bit patterns is not the order of floats any more.  In the
+            // reference every comparison with NaN fails to reject (pv:103,107), peaks appear at every other bin and the NaNs they move reach
+            // every output sample of the frame: the frame is NaN.  Detected here (two v_max3_u32 + a compare per frame), poisoned after the scatter.
+            nonfinite = __any(max(max(max(pm[3], pm[5]), max(pm[7], pm[9])), mg[2]) >= 0x7F800000u);
             if (dbg) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) { p.dbg_flags[8 * l + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * l + i] = __uint_as_float(mg[i + 2]); }
@@ -727,6 +732,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
                                           src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, dbg ? p.dbg_X : nullptr);
             }
         }
+        if (nonfinite && l == 0) Y[1] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};   // see "Non-finite magnitudes" above
         wave_sync();
         PV_STAMP(6);
         pv_prio(PH_C2R);

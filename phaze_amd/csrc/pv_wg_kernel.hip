@@ -571,6 +571,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 s2v[j] = cmul(tsum, cconj(p.tw32[2 * k]));
             }
         }
+        bool nonfinite = false;
         // ---- peak flags on bins 8t..8t+7 (pv:95-116) ----
         int lastown[8], firstown[8];                                      // last own peak <= bin i / first own peak > bin i
         int last_in, first_in;
@@ -597,6 +598,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 const bool in_range = (i < 2) ? (tq != 0) : (i == 7) ? (tq != T - 1) : true;
                 fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
             }
+            nonfinite = __any(max(max(max(pm[3], pm[5]), max(pm[7], pm[9])), mg[2]) >= 0x7F800000u);   // Inf / NaN magnitude in this wave's bins (see pv_wave_kernel.hip)
             if (dbg) {
                 for (int i = 0; i < 8; i++) { p.dbg_flags[8 * tq + i] = fl[i] ? 1 : 0; p.dbg_mag[8 * tq + i] = __uint_as_float(mg[i + 2]); }
                 if (tq == T - 1) { p.dbg_flags[M] = 0; p.dbg_mag[M] = __uint_as_float(mg[10]); }
@@ -747,6 +749,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 }
             }
         }
+        if (nonfinite && l == 0) Y[1 + wv] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};   // the reference's frame is NaN: so is this one
         __syncthreads();
         if (dbg) {
 #pragma unroll
