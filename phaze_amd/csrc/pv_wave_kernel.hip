@@ -49,7 +49,13 @@ constexpr int TAB_TW2F = TAB_TW1F + 4 * 64 * 16; // float4[4*8]    conj(W_64^{n0
 constexpr int TAB_HANN = TAB_TW2F + 4 * 8 * 16;  // float4[4*64]   0.5 * Hann at samples 2n, 2n+1 for n = l + 64 r: entry [j*64 + l] = (r = 2j, r = 2j+1).
                                                  //                ONE table serves both windows: the 1/2 of the split pass is folded in for the analysis
                                                  //                window, and the synthesis side folds 2/R into the scale of the c2r pass (all exact)
+#ifndef PV_INV_FP64
 constexpr int TAB_BYTES = TAB_HANN + 4 * 64 * 16;  // 17920
+#else
+constexpr int TAB_TW1C = TAB_HANN + 4 * 64 * 16;   // double2[8*64]  conj(W_512^{l k})   (measurement variant: fp64 inverse)
+constexpr int TAB_TW2C = TAB_TW1C + 8 * 64 * 16;   // double2[8*8]   conj(W_64^{n0 k})
+constexpr int TAB_BYTES = TAB_TW2C + 8 * 8 * 16;
+#endif
 
 // conj(W_512^{l k}) in fp32 from the pair-interleaved table (residue paths)
 __device__ __forceinline__ float2 tw1f_at(int k, int l)
@@ -159,12 +165,24 @@ __device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const flo
 }
 
 // per-wave LDS region (byte offsets): see the carve in the kernel
+#ifndef PV_INV_FP64
 constexpr int OFF_Y = 0;            // float2[513]   shifted spectrum
 constexpr int OFF_ROUTE = 4112;     // u32[528] routes | f32 mags (alias) | u16 claim ids (alias, after the routes are in registers)
 constexpr int OFF_RESQ = 6224;      // float2[256]   one quarter of the above-Nyquist residue at a time (general path) | c2r hand-over
 constexpr int OFF_XS = 6224;        // float2[513]   fp32 spectrum stash of the fast residue path (aliases RESQ: never live together)
 constexpr int OFF_PSH = 10336;      // i16[512]      shift table Math.round(p * f) - p
 constexpr int WAVE_LDS = OFF_PSH + 1024;   // 11360: 22016 + 12 * 11360 = 158336 B per workgroup (<= 160 KB)
+#else
+// Measurement variant (never the product; DESIGN.md section 4, "all-fp64 data point"): shifted spectrum, c2r pass and inverse FFT in fp64 like
+// the reference (freqComplexBufferShifted / inverseTransform are plain JS doubles, bundle:102-114) -- f >= 1 frames only (a frame with f < 1
+// comes out silent).  Y is double2[513] and cannot alias the routes any more; 8 waves per workgroup (build with -DPV_WAVES=8 -DPV_WAVES_PER_SIMD=2).
+constexpr int OFF_Y = 0;            // double2[513]
+constexpr int OFF_ROUTE = 9216;
+constexpr int OFF_RESQ = 11328;     // double2[256] c2r hand-over
+constexpr int OFF_XS = 11328;
+constexpr int OFF_PSH = 15424;
+constexpr int WAVE_LDS = OFF_PSH + 1024;
+#endif
 
 // Above-Nyquist residue, fast path.  What fft.js's in-place real radix-4 DIT leaves at positions 512..640 is the clean first half
 // of the 256-point sub-DFT S2 of xw[4n+2] (its last stage never touches quarter 2, bundle:329-441), and the decimation identity
@@ -410,12 +428,18 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
             const int k = i >> 6, ln = i & 63;
             const double2 w = p.tw64[(2 * ln * k) & (N - 1)];
             t1[i] = w;
+#ifdef PV_INV_FP64
+            reinterpret_cast<double2 *>(smem_all + TAB_TW1C)[i] = double2{w.x, -w.y};
+#endif
             t1f[2 * ((k >> 1) * 64 + ln) + (k & 1)] = float2{(float)w.x, -(float)w.y};
             hh[2 * ((k >> 1) * 64 + ln) + (k & 1)] = float2{0.5f * p.hann[2 * i], 0.5f * p.hann[2 * i + 1]};   // n = i = ln + 64 k: row k
             if (i < 64) {
                 const int k2 = i >> 3, n0 = i & 7;
                 const double2 w2 = p.tw64[(16 * n0 * k2) & (N - 1)];
                 t2[i] = w2;
+#ifdef PV_INV_FP64
+                reinterpret_cast<double2 *>(smem_all + TAB_TW2C)[i] = double2{w2.x, -w2.y};
+#endif
                 t2f[2 * ((k2 >> 1) * 8 + n0) + (k2 & 1)] = float2{(float)w2.x, -(float)w2.y};
             }
         }
@@ -529,6 +553,9 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
         pv_prio(PH_SPLITX);
         float2 XA[4], XB[4];               // fp32 copy of the spectrum: the only thing the shift needs after the decisions
         float2 x256f{0.f, 0.f};
+#ifdef PV_INV_FP64
+        double2 XAd[4], XBd[4], x256d{0.0, 0.0};
+#endif
         {
             // partner values through the (now free) transpose scratch: rows 4..7 written lane-contiguous, read back reversed.  Element
             // 512 - k of the pair k = l + 64 r sits at (3 - r) * 64 + (64 - l) for every lane (lane 0: 64 (8 - r), its own register
@@ -558,6 +585,9 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
                 MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
                 XA[r] = float2{(float)xa.x, (float)xa.y};
                 XB[r] = float2{(float)xb.x, (float)xb.y};
+#ifdef PV_INV_FP64
+                XAd[r] = xa; XBd[r] = xb;
+#endif
                 if (dbg) {
                     const int ka = l + 64 * r, kb = 512 - ka;
                     p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
@@ -568,6 +598,9 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
                 const double2 x256{2.0 * z[4].x, -2.0 * z[4].y};              // k = 256 pairs with itself: W^256 = -j, X = 2 conj(Z)
                 MAG[4 + 256] = (float)(x256.x * x256.x + x256.y * x256.y);
                 x256f = float2{(float)x256.x, (float)x256.y};
+#ifdef PV_INV_FP64
+                x256d = x256;
+#endif
                 if (dbg) { p.dbg_X[2 * 256] = x256.x; p.dbg_X[2 * 256 + 1] = x256.y; }
             }
         }
@@ -690,6 +723,59 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
         pv_prio(PH_SCATTER);
         int upper_end = H;
         if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
+#ifdef PV_INV_FP64
+        pk::c32 zi[8];
+        {
+            double2 *Yd = reinterpret_cast<double2 *>(smem + OFF_Y);
+#pragma unroll
+            for (int r = 0; r < 8; r++) Yd[l + 64 * r] = double2{0.0, 0.0};
+            if (l == 0) Yd[512] = double2{0.0, 0.0};
+            wave_sync();
+            if (pf >= 1.0) {                                                // (this variant moves nothing when f < 1)
+                auto rotd = [&](unsigned rt, double2 v) -> double2 {         // exp(+2 pi j ridx / N), R = 4: j^q exactly; else the fp64 table
+                    const unsigned ridx = (rt >> 16) & (N - 1);
+                    if (R == 4) { const unsigned q = ridx >> 8; return q == 0 ? v : q == 1 ? double2{-v.y, v.x} : q == 2 ? double2{-v.x, -v.y} : double2{v.y, -v.x}; }
+                    return cmul(v, cconj(p.tw64[ridx]));
+                };
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned ra = ROUTE[l + 64 * r], ta = ra & 0xFFFFu;
+                    const unsigned rb = ROUTE[512 - l - 64 * r], tb = rb & 0xFFFFu;
+                    if (ta < (unsigned)H) Yd[ta] = rotd(ra, XAd[r]);
+                    if (tb < (unsigned)H) Yd[tb] = rotd(rb, XBd[r]);
+                }
+                if (l == 0) { const unsigned rt = ROUTE[256], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Yd[tg] = rotd(rt, x256d); }
+            }
+            wave_sync();
+            // c2r pre-pass in fp64: Z[k] = SC ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)), conjugate pairs as in the product
+            double2 zd[8], zb[4];
+            const double sc = (double)SC;
+            const double2 wlc{wl.x, -wl.y};                                 // e^{+2 pi j l / N}
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = l + 64 * r;
+                double2 yk = Yd[k], ym = Yd[M - k];
+                if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
+                const double2 E{yk.x + ym.x, yk.y - ym.y}, O{yk.x - ym.x, yk.y + ym.y};
+                const double2 c = cmul(mul_w16<double, true>(O, r), wlc);
+                zd[r] = double2{(E.x - c.y) * sc, (E.y + c.x) * sc};        // E + j c
+                zb[r] = double2{(E.x + c.y) * sc, -(E.y - c.x) * sc};       // conj(E - j c)
+            }
+            const double2 y256 = Yd[256];
+            double2 *XCHd = reinterpret_cast<double2 *>(smem + OFF_RESQ);
+#pragma unroll
+            for (int r = 0; r < 4; r++) XCHd[r * 64 + l] = zb[r];
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 4; r++) zd[7 - r] = XCHd[r * 64 + 64 - l];
+            if (l == 0) zd[4] = double2{2.0 * y256.x * sc, -2.0 * y256.y * sc};
+            wave_sync();
+            // inverse 512-point FFT in fp64: the forward routine with conjugated twiddles (LDS copies TW1C / TW2C built below the fp64 tables)
+            fft512_wave<double, true>(zd, S64, reinterpret_cast<const double2 *>(smem_all + TAB_TW1C), reinterpret_cast<const double2 *>(smem_all + TAB_TW2C), l);
+#pragma unroll
+            for (int r = 0; r < 8; r++) zi[r] = pk::c32{(float)zd[r].x, (float)zd[r].y};    // fromComplexArray -> Float32Array (bundle:46-51)
+        }
+#else
         // ---- zero Y (pv:121); the transposes of the forward FFT are done with the scratch.  16 bytes per lane and store: four
         //      ds_write_b128 (+ bin 512) instead of eight ds_write_b64 ----
 #pragma unroll
@@ -787,6 +873,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
         fft512_wave_inv_pk<true>(zi, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l, [&](int id) { if (id & 1) stamps.mark(8 + id); else stamps.mark(8 + id, true); });
 #else
         fft512_wave_inv_pk(zi, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l);
+#endif
 #endif
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         pv_prio(PH_OLA);
