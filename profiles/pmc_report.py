@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""pmc_report.py -- turns the rocprofv3 CSVs of profiles/run_profile_r02.sh into the committed round-2 summaries:
+"""pmc_report.py -- turns the rocprofv3 CSVs of profiles/run_profile_r0N.sh into the committed round-2 summaries:
    profiles/<tag>_kernel_trace.md, profiles/<tag>_pmc.md (per-frame counter table of the headline kernel), profiles/<tag>_wg_pmc.md and
    profiles/hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per shape, keyed like bench.py looks them up, stamped with the kernel-source hash).
 usage: python profiles/pmc_report.py <gpurun_out/tag> <tag>"""
@@ -82,7 +82,7 @@ def main():
         frames = hops + (chains - 1) * 3                       # R - 1 = 3 halo frames per chain but the first
     except Exception:
         pass
-    lines = [f"# {tag}: PMC passes of the headline kernel (separate rocprofv3 --pmc runs, profiles/run_profile_r02.sh)", "",
+    lines = [f"# {tag}: PMC passes of the headline kernel (separate rocprofv3 --pmc runs, profiles/run_profile_r0N.sh)", "",
              f"computed frames per launch: {frames}", "", "| counter | mean per dispatch | per computed frame |", "|---|---|---|"]
     for k in sorted(c):
         lines.append(f"| {k} | {c[k]:.6g} | {c[k]/frames:.1f} |" if frames else f"| {k} | {c[k]:.6g} | |")
@@ -112,14 +112,14 @@ def main():
         alg = nch * hops * 2 * hop * 4
         tj[f"{fft}/{hop}/ch{nch}/hops{hops}"] = {"bytes_per_launch": int(fetch + write), "fetch_bytes_corrected_x2": int(fetch), "write_bytes": int(write),
                                                   "algorithmic_bytes": alg, "traffic_over_algorithmic": (fetch + write) / alg, "kernel": (re.search(r"pv_\w+", kname) or [""])[0], "csrc_sha16": sha,
-                                                  "source": f"profiles/run_profile_r02.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE (KiB) doubled per the gfx950 wide-read rule"}
+                                                  "source": f"profiles/run_profile_r0N.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE (KiB) doubled per the gfx950 wide-read rule"}
     tj["_calibration"] = {"what": "torch copy_ of 1 GiB (4 dispatches) under the same counters: largest dispatch", "FETCH_SIZE_KiB": calib.get("FETCH_SIZE"),
                           "WRITE_SIZE_KiB": calib.get("WRITE_SIZE"), "expected_KiB": 1 << 20,
                           "fetch_x2_over_expected": (calib.get("FETCH_SIZE", 0) * 2) / (1 << 20), "write_over_expected": calib.get("WRITE_SIZE", 0) / (1 << 20)}
     json.dump(tj, open(tj_path, "w"), indent=1)
     # ---- workgroup kernel ----
     lines = [f"# {tag}: counters of the other shapes' kernels (pv_wave2k_kernel at N = 2048, pv_wg_kernel above), per computed frame (separate --pmc passes)", ""]
-    for name in ("c3", "c3f15", "c3f07", "c4", "c5", "native"):
+    for name in ("c3", "c3f15", "c3f07", "c4", "c5", "native", "c2f08"):
         c, kname = dominant_counters(os.path.join(d, f"wg_{name}_*", "**", "*counter_collection.csv"))
         if not c:
             continue
