@@ -31,6 +31,9 @@
 #define PV_PT 1, 0, 1, 2, 2, 2, 2, 2, 0, 0, 0, 2     // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C3 3.76 -> 3.31 ms)
 #endif
 #include "pv_wave_fft.h"
+#ifndef PV_PAIRWISE
+#define PV_PAIRWISE 1                               // 0: every f < 1 frame goes through the claim rounds (A/B)
+#endif
 
 namespace {
 
@@ -471,6 +474,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
         pv_prio(PH_PEAKS);
         // ---- peak flags (pv:95-116) for bins 16l..16l+15, nearest peaks, one ROUTE word per source bin ----
         int last_peak = -1, last_shift = 0;
+        bool pairwise = false;                                              // f < 1: every collision is a (falling side, rising side) pair (wave-uniform)
         bool nonfinite = false;                                             // a magnitude of this frame is Inf or NaN (see pv_wave_kernel.hip)
         {
             unsigned mg[20];
@@ -547,6 +551,21 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
 #pragma unroll
                 for (int i = 0; i < 16; i++) rt[i] = route_of(16 * l + i, max(lastown[i], cprev), min(firstown[i], cnext));
                 if (l == 63) rt1024 = route_of(1024, max(last_in, cprev), POSPD);   // source bin N/2: owner is the last peak
+                if (!(pf >= 1.0)) {
+                    // f < 1: bit 31 of a route = "rising side" (source owned by the peak on its right), and the wave-uniform test that lets the
+                    // scatter run as store-then-add instead of claim rounds (pv_wave_kernel.hip, "pairwise"; tests/test_pairwise_rule.py)
+                    rt1024 &= 0x7FFFFFFFu;
+                    bool bad = false;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int pp = max(lastown[i], cprev), pn = min(firstown[i], cnext), b = 16 * l + i;
+                        const bool rising = !(b - (pp >> 16) < (pn >> 16) - b);
+                        rt[i] = (rt[i] & 0x7FFFFFFFu) | (rising ? 0x80000000u : 0u);
+                        const int gap = (pn >> 16) - (pp >> 16), ov = __builtin_amdgcn_sbfe(pp, 0, 16) - __builtin_amdgcn_sbfe(pn, 0, 16);
+                        bad |= ov > (gap >> 1);
+                    }
+                    pairwise = PV_PAIRWISE && !__any(bad);
+                }
             }
             wave_sync();                                                   // MAG is dead (in registers): ROUTE aliases it
 #pragma unroll
@@ -600,11 +619,39 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             ys[16] = rotate2k<R>(rt[16], x512f, ROT);
             id[16] = 512;
             wave_sync();                                                   // routes are in registers: CLAIM may overwrite ROUTE
+            if (pairwise) {
+                // every collision of this frame is one falling-side source against one rising-side source (see the peak search): the falling side
+                // (and the residue, which continues the falling side of the last peak) stores into the zeroed Y, then the rising side adds
+                unsigned key[17];
+#pragma unroll
+                for (int r = 0; r < 17; r++) key[r] = rt[r] & 0x8000FFFFu;
+#pragma unroll
+                for (int r = 0; r < 17; r++) if (key[r] < (unsigned)H) Y[key[r]] = ys[r];
+                wave_sync();
+#pragma unroll
+                for (int h0 = 0; h0 < 17; h0 += 9) {                       // two batches of reads: 34 more live registers would spill the f >= 1 path
+                    float2 o[9];
+#pragma unroll
+                    for (int r = h0; r < 17 && r < h0 + 9; r++) o[r - h0] = Y[min(rt[r] & 0xFFFFu, 1024u)];
+#pragma unroll
+                    for (int r = h0; r < 17 && r < h0 + 9; r++)
+                        if (key[r] - 0x80000000u < (unsigned)H) Y[key[r] - 0x80000000u] = float2{o[r - h0].x + ys[r].x, o[r - h0].y + ys[r].y};
+                }
+                wave_sync();
+            } else
             claim_rounds2<17>(rt, ys, id, Y, CLAIM);
             if (upper_end > H) {
                 const int up_delta = last_shift;
                 const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
-                if (upper_end <= H + N / 8) {                              // always when f >= 0.75; the fast form of the residue (s2v above)
+                if (upper_end <= H + N / 8 && pairwise) {                  // the residue lands above every other target of the last region: plain stores
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int b = 1024 + 1 + l + 64 * j, tgt = b + up_delta;
+                        const unsigned rtj = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+                        if (rtj != NOROUTE) Y[tgt] = rotate2k<R>(rtj, s2v[j], ROT);
+                        if (dbg && b < upper_end) { p.dbg_X[2 * b] = s2v[j].x; p.dbg_X[2 * b + 1] = s2v[j].y; }
+                    }
+                } else if (upper_end <= H + N / 8) {                       // always when f >= 0.75; the fast form of the residue (s2v above)
                     unsigned rt2[4];
                     float2 ys2[4];
                     int id2[4];

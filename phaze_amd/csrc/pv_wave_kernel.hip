@@ -320,8 +320,11 @@ struct Spectrum9 { float2 a[4], b[4], h; };     // bins l + 64 r, 512 - l - 64 r
 #ifndef PV_COLLIDE_ATTR
 #define PV_COLLIDE_ATTR __attribute__((noinline))
 #endif
+#ifndef PV_PAIRWISE
+#define PV_PAIRWISE 1                                                       // 0: every f < 1 frame goes through the claim rounds (A/B, tools/experiments)
+#endif
 template <int R_>
-__device__ PV_COLLIDE_ATTR PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 X, unsigned wave_off, int l, int tmod, int last_peak, int upper_end,
+__device__ PV_COLLIDE_ATTR PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 X, unsigned wave_off, int l, int tmod, int last_peak, int upper_end, bool pairwise,
                                                                                const float *in, const float *hist, int hist_len, long s0,
                                                                                const float *__restrict__ hann, const float2 *__restrict__ tw32, double *dbg_X)
 {
@@ -359,6 +362,37 @@ __device__ PV_COLLIDE_ATTR PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 
     // sources above Nyquist, all owned by the last peak (pv:133)
     const int up_delta = need_res ? (int)DSH[last_peak < 0 ? 0 : last_peak] : 0;
     const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+    if (pairwise) {
+        // Two passes instead of claim rounds (see the peak search: every collision is falling side x rising side): pass A, the falling-side sources
+        // and the residue (it continues the falling side of the last peak) store into the zeroed Y; pass B, the rising-side sources read, add, store.
+        if (fast_res) {
+            float2 *XS = reinterpret_cast<float2 *>(smem + OFF_XS);
+#pragma unroll
+            for (int r = 0; r < 4; r++) { XS[l + 64 * r] = X.a[r]; XS[512 - l - 64 * r] = X.b[r]; }
+            if (l == 0) XS[256] = X.h;
+        }
+        unsigned key[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) key[r] = rt[r] & 0x8000FFFFu;         // side bit | target: < 513 = a valid falling-side source
+#pragma unroll
+        for (int r = 0; r < 9; r++) if (key[r] < 513u) Y[key[r]] = ys[r];
+        wave_sync();
+        float2 o[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) o[r] = Y[rt[r] & 0x3FFu];              // (any address inside the wave's own region will do for the sources that do not add)
+        if (fast_res) {
+            unsigned rt2[2];
+            float2 ys2[2];
+            int id2[2];
+            residue_fast_1024<R_>(tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X, rt2, ys2, id2);
+#pragma unroll
+            for (int j = 0; j < 2; j++) if ((rt2[j] & 0xFFFFu) < 513u) Y[rt2[j] & 0xFFFFu] = ys2[j];
+        }
+#pragma unroll
+        for (int r = 0; r < 9; r++) if (key[r] - 0x80000000u < 513u) Y[rt[r] & 0x3FFu] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
+        if (need_res && !fast_res) residue_scatter_1024<R_>(in, hist, hist_len, s0, hann, tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
+        return;
+    }
     if (fast_res) {
         // fast form of the residue: stash the fp32 spectrum, run the nine ordinary sources through their claim rounds, then the two residue
         // sources of every lane through a series of their own.  (Measured in round 3: ONE series over eleven sources is 9 % slower at f = 0.8 --
@@ -624,6 +658,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
         pv_prio(PH_PEAKS);
         // ---- peak flags (pv:95-116) for bins 8l..8l+7, nearest peaks by wave scans, then one ROUTE word per source bin ----
         int last_peak = -1, last_shift = 0;
+        bool pairwise = false;                                              // wave-uniform, f < 1: every collision of this frame is a (falling side, rising side) pair
         bool nonfinite = false;                                             // wave-uniform: a magnitude of this frame is Inf or NaN
         if (!(PV_ABL & 16)) {
             // |X|^2 >= 0, so the fp32 order of two magnitudes is the order of their bit patterns as unsigned integers: the strict test
@@ -707,6 +742,27 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
 #pragma unroll
                 for (int i = 0; i < 8; i++) rt[i] = route_of(8 * l + i, max(lastown[i], cprev), min(firstown[i], cnext));
                 if (l == 63) rt512 = route_of(512, max(last_in, cprev), POSPD);   // source bin N/2: owner is the last peak
+                if (!(pf >= 1.0)) {
+                    // f < 1: regions compress and their targets overlap (pv:169-170).  The targets of a region are contiguous, so the overlap of two
+                    // neighbours is the LAST ov = delta_i - delta_{i+1} targets of region i against the FIRST ov of region i+1.  While ov <= floor(gap / 2)
+                    // -- the length of the rising side of peak i+1, the shorter of the two sides that meet -- every collision is ONE source from the falling
+                    // side of a peak (owned by the peak on its left, the peak bin included) against ONE from the rising side of the next peak (owned by the
+                    // peak on its right), never two of a kind.  The scatter then needs no claim rounds: falling-side sources store, rising-side sources add
+                    // (scatter_colliding_1024) -- in the reference's order, region i before region i+1 (pv:122,146).  Bit 31 of a route = rising side
+                    // (route_of leaves a stray bit of delta * t there; the rotation ignores it); one gap with a longer overlap (f below ~0.6, or very
+                    // close peaks) sends the whole frame through the claim rounds instead.  tests/test_pairwise_rule.py checks the rule on random peak sets.
+                    rt512 &= 0x7FFFFFFFu;                               // bin N/2: falling side of the last peak
+                    bool bad = false;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int pp = max(lastown[i], cprev), pn = min(firstown[i], cnext), b = 8 * l + i;
+                        const bool rising = !(b - (pp >> 16) < (pn >> 16) - b);
+                        rt[i] = (rt[i] & 0x7FFFFFFFu) | (rising ? 0x80000000u : 0u);
+                        const int gap = (pn >> 16) - (pp >> 16), ov = __builtin_amdgcn_sbfe(pp, 0, 16) - __builtin_amdgcn_sbfe(pn, 0, 16);
+                        bad |= ov > (gap >> 1);                             // (a missing neighbour is a sentinel thousands of bins away)
+                    }
+                    pairwise = PV_PAIRWISE && !__any(bad);
+                }
             }
             // MAG is dead now (every lane has its 12 magnitudes in registers): ROUTE aliases it
             wave_sync();
@@ -814,7 +870,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
                 else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
                 else scatter(std::integral_constant<int, 1>{});
             } else {
-                scatter_colliding_1024<R>(Spectrum9{{XA[0], XA[1], XA[2], XA[3]}, {XB[0], XB[1], XB[2], XB[3]}, x256f}, wave_off, l, tmod, last_peak, upper_end,
+                scatter_colliding_1024<R>(Spectrum9{{XA[0], XA[1], XA[2], XA[3]}, {XB[0], XB[1], XB[2], XB[3]}, x256f}, wave_off, l, tmod, last_peak, upper_end, pairwise,
                                           src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, dbg ? p.dbg_X : nullptr);
             }
         }
