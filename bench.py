@@ -323,6 +323,7 @@ def main():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--hops", type=int, default=1 << 20, help="hops (frames per channel) per step")
     ap.add_argument("--pitch", type=float, default=1.5)
+    ap.add_argument("--pitch-sweep", action="store_true", help="pitchFactor swept 0.5->2.0 per hop, period 64 hops (BASELINE configs[4]'s schedule) instead of --pitch")
     ap.add_argument("--frames-per-chunk", type=int, default=0)
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps launches each; the line reports the median region and lists all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -399,6 +400,11 @@ def main():
             dist.destroy_process_group()
         return
     pitch = torch.full((T,), args.pitch, device=dev, dtype=torch.float32)
+    if args.pitch_sweep:
+        pitch = (0.5 + 1.5 * (torch.arange(T, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
+        args.pitch_num, args.pitch = 1.0, "swept 0.5->2.0 per hop (period 64 hops)"    # (CPU baseline / PCIe legs of a swept run use f = 1.0)
+    else:
+        args.pitch_num = args.pitch
     head = measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch, args.steps, args.warmup, "headline", local_rank,
                    frames_per_chunk=args.frames_per_chunk, parity_hops=96 if rank == 0 else 0, seed=rank, repeats=args.repeats)
 
@@ -433,7 +439,7 @@ def main():
     out = None
     if rank == 0:
         chs = "mono" if nch == 1 else "stereo" if nch == 2 else f"{nch}-ch"
-        is_c1 = (fft, hop, nch) == (1024, 256, 1) and abs(args.pitch - 1.5) < 1e-9
+        is_c1 = (fft, hop, nch) == (1024, 256, 1) and not args.pitch_sweep and abs(args.pitch - 1.5) < 1e-9
         out = {
             "metric": "stft_frames_per_sec_1024pt_hop256_48k" if (fft, hop) == (1024, 256) else f"stft_frames_per_sec_{fft}pt_hop{hop}",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -504,16 +510,16 @@ def main():
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(fft, hop, args.pitch)
+            out["cpu_baseline"] = cpu_baseline(fft, hop, args.pitch_num)
         if args.pcie:
             import signals as S
             Tp = min(T, 1 << 14)
             xh = np.stack([S.make_signal("tonal", c, Tp * hop) for c in range(nch)])
             pv2 = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=Tp, device_id=local_rank)
-            pv2.process_batch(xh, np.full(Tp, args.pitch, np.float32))
+            pv2.process_batch(xh, np.full(Tp, args.pitch_num, np.float32))
             t1 = time.perf_counter()
             for _ in range(3):
-                pv2.process_batch(xh, np.full(Tp, args.pitch, np.float32))
+                pv2.process_batch(xh, np.full(Tp, args.pitch_num, np.float32))
             out["pcie_inclusive_frames_per_s"] = 3 * nch * Tp / (time.perf_counter() - t1)
             pv2.close()
         print(json.dumps(out), flush=True)

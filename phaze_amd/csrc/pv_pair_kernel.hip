@@ -36,6 +36,9 @@
 #define PV_PT 2, 0, 2, 3, 3, 3, 3, 3, 1, 0, 1, 3     // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C4 0.92 -> 0.83 ms)
 #endif
 #include "pv_wave_fft.h"
+#ifndef PV_PAIRWISE
+#define PV_PAIRWISE 1                               // 0: every f < 1 frame goes through the claim rounds (A/B)
+#endif
 
 namespace {
 
@@ -211,8 +214,9 @@ __device__ __forceinline__ int digitrev4_4k(int v, int nd)
 template <int R_>
 __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_pair(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
                                                                                const float2 *__restrict__ tw32, int t, int upper_end, int up_delta, unsigned up_ridx,
-                                                                               double *dbg_X)
+                                                                               double *dbg_X, bool plain)
 {
+    // plain: the frame passed the pairwise test, nothing but the residue lands on the residue's targets (all distinct): stores, no claim rounds
     constexpr int N = N4, H = H4, QN = N / 4, T = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *Y = reinterpret_cast<float2 *>(smem + P_A);
@@ -270,6 +274,11 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_pair(co
             rt[j] = (b >= H && b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
             ys[j] = rotate4k<R_>(rt[j], Q[t + T * j], ROT);
             id[j] = b - N / 2;                                             // ascending with the source bin; the regular sources are done by now
+        }
+        if (plain) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (rt[j] != NOROUTE) Y[rt[j] & 0xFFFFu] = ys[j];
+            continue;                                                      // (the barrier at the top of the next quarter orders the quarter buffer)
         }
         __syncthreads();                                                   // the quarter is in registers: its space becomes the claim words again
 #pragma unroll
@@ -607,6 +616,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
         }
         __syncthreads();                                                   // barrier 3: peak words across the wave boundary; every magnitude read is done; the stash is complete
         float2 s2v[4] = {float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}};
+        bool bad = false;                                                  // f < 1: a gap of this wave's bins overlaps by more than its rising side
         {
             constexpr int NEGPD = -(8192 << 16), POSPD = 16384 << 16;
             const int o_last = BND[2 * (1 - g)], o_first = BND[2 * (1 - g) + 1], my_last = BND[2 * g];
@@ -627,6 +637,19 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
 #pragma unroll
                 for (int i = 0; i < 16; i++) rt[i] = route_of(16 * LL + i, max(lastown[i], cprev), min(firstown[i], cnext));
                 if (LL == 127) rtM = route_of(M, max(last_in, cprev), POSPD);       // source bin N/2: owner is the last peak
+                if (collide) {
+                    // f < 1: bit 31 of a route = "rising side" (source owned by the peak on its right), and this wave's share of the test that lets
+                    // the scatter run as store-then-add instead of claim rounds (pv_wave_kernel.hip, "pairwise"; tests/test_pairwise_rule.py)
+                    rtM &= 0x7FFFFFFFu;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int pp = max(lastown[i], cprev), pn = min(firstown[i], cnext), b = 16 * LL + i;
+                        const bool rising = !(b - (pp >> 16) < (pn >> 16) - b);
+                        rt[i] = (rt[i] & 0x7FFFFFFFu) | (rising ? 0x80000000u : 0u);
+                        const int gap = (pn >> 16) - (pp >> 16), ov = __builtin_amdgcn_sbfe(pp, 0, 16) - __builtin_amdgcn_sbfe(pn, 0, 16);
+                        bad |= ov > (gap >> 1);
+                    }
+                }
             }
             if (collide) {                                                  // fast form of the residue: positions N/2 + kk, kk = 1 + LL + 128 j (see pv_wave_kernel.hip)
                 const float2 *XS = reinterpret_cast<const float2 *>(smem + P_A);
@@ -650,7 +673,9 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
         if (LL == 127) Y[M] = float2{0.f, 0.f};
         int upper_end = H;
         if (last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
+        if (collide) { const bool wbad = __any(bad); if (l == 0) BND[4 + g] = wbad ? 1 : 0; }
         __syncthreads();                                                   // barrier 4
+        const bool pairwise = PV_PAIRWISE && collide && !(BND[4] | BND[5]);  // uniform in the workgroup
         // ---- shiftPeaks (pv:119-173): this lane's sources are the bins its groups produced ----
         if (!collide) {
             auto scatter = [&](auto mode_tag) {
@@ -697,6 +722,40 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
             id[17] = 1536; rs[17] = mid ? ROUTE[1920] : NOROUTE; ys[17] = xm1;
 #pragma unroll
             for (int i = 0; i < 18; i++) ys[i] = rotate4k<R>(rs[i], ys[i], ROT);
+            if (pairwise) {
+                // every collision of this frame is one falling-side source against one rising-side source: the falling side and the residue (it
+                // continues the falling side of the last peak) store into the zeroed Y, one barrier, the rising side adds.  No claim words, one
+                // barrier instead of two per round.
+                unsigned key[18];
+#pragma unroll
+                for (int i = 0; i < 18; i++) key[i] = rs[i] & 0x8000FFFFu;
+#pragma unroll
+                for (int i = 0; i < 18; i++) if (key[i] < (unsigned)H) Y[key[i]] = ys[i];
+                if (upper_end > H && upper_end <= H + N / 8) {
+                    const int up_delta = last_shift;
+                    const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int b = M + 1 + LL + 128 * j, tgt = b + up_delta;
+                        const unsigned rtj = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+                        if (rtj != NOROUTE) Y[tgt] = rotate4k<R>(rtj, s2v[j], ROT);
+                        if (dbg && b < upper_end) { p.dbg_X[2 * b] = s2v[j].x; p.dbg_X[2 * b + 1] = s2v[j].y; }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int h0 = 0; h0 < 18; h0 += 9) {
+                    float2 o[9];
+#pragma unroll
+                    for (int i = h0; i < h0 + 9; i++) o[i - h0] = Y[min(rs[i] & 0xFFFFu, (unsigned)M)];
+#pragma unroll
+                    for (int i = h0; i < h0 + 9; i++)
+                        if (key[i] - 0x80000000u < (unsigned)H) Y[key[i] - 0x80000000u] = float2{o[i - h0].x + ys[i].x, o[i - h0].y + ys[i].y};
+                }
+                if (upper_end > H + N / 8)
+                    residue_scatter_pair<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, (int)threadIdx.x, upper_end, last_shift,
+                                            (unsigned)((last_shift & (N - 1)) * tmod) & (N - 1), dbg ? p.dbg_X : nullptr, true);
+            } else {
             __syncthreads();                                               // every route read is done: the region becomes the claim words
 #pragma unroll
             for (int j = 0; j < 16; j++) CLAIM[threadIdx.x + 128 * j] = 0xFFFFFFFFu;
@@ -720,8 +779,9 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                     claim_rounds_pair<4>(rt2, ys2, id2, Y, CLAIM);
                 } else {
                     residue_scatter_pair<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, (int)threadIdx.x, upper_end, up_delta, up_ridx,
-                                            dbg ? p.dbg_X : nullptr);
+                                            dbg ? p.dbg_X : nullptr, false);
                 }
+            }
             }
         }
         if (nonfinite && l == 0) Y[1 + g] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};   // the reference's frame is NaN: so is this one

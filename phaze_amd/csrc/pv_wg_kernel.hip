@@ -22,6 +22,9 @@
 #include "pv_kernels.h"
 #include "pv_device_common.h"
 #include "pv_pk_math.h"
+#ifndef PV_PAIRWISE
+#define PV_PAIRWISE 1                               // 0: every f < 1 frame goes through the claim rounds (A/B)
+#endif
 
 namespace {
 
@@ -288,8 +291,10 @@ __device__ __forceinline__ int digitrev4_(int v, int nd)
 template <int LOG2N, int R_>
 __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
                                                              const float2 *__restrict__ tw32, int t, int upper_end, int up_delta, unsigned up_ridx,
-                                                             double *dbg_X)
+                                                             double *dbg_X, bool plain)
 {
+    // plain: the frame passed the pairwise test (see the peak search), so nothing but the residue itself lands on the residue's targets -- the
+    // continuation of the last region, all distinct: plain stores instead of claim rounds (two barriers and an atomic per source and round)
     constexpr int G = 1 << (LOG2N - 10);
     using C = WgCfg<G>;
     constexpr int N = C::N, H = C::H, T = C::T, QN = N / 4;
@@ -360,7 +365,12 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(cons
             ys[j] = rotate_route<R_, LOG2N>(rt[j], Q[t + T * j], tw32);
             id[j] = b - N / 2;                                             // ascending with the source bin; regular sources are done by now
         }
-        claim_rounds_wg<4, (1 << (LOG2N - 1)) + 1>(rt, ys, id, Y, CLAIM);
+        if (plain) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (rt[j] != NOROUTE) Y[rt[j] & 0xFFFFu] = ys[j];
+        } else {
+            claim_rounds_wg<4, (1 << (LOG2N - 1)) + 1>(rt, ys, id, Y, CLAIM);
+        }
         __syncthreads();
     }
 }
@@ -653,6 +663,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         {
             unsigned rt[8];
             unsigned rtM = NOROUTE;
+            bool bad = false;                                               // f < 1: a gap next to this thread's bins overlaps by more than its rising side
             if (last_peak < 0) {                                            // no peak at all (workgroup-uniform): nothing moves
 #pragma unroll
                 for (int i = 0; i < 8; i++) rt[i] = NOROUTE;
@@ -667,10 +678,24 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
 #pragma unroll
                 for (int i = 0; i < 8; i++) rt[i] = route_of(8 * tq + i, max(lastown[i], cprev), min(firstown[i], cnext));
                 if (tq == T - 1) rtM = route_of(M, max(last_in, cprev), POSPD);
+                if (!(pf >= 1.0)) {
+                    // f < 1: bit 31 of a route = "rising side" (source owned by the peak on its right), and this thread's share of the test that lets
+                    // the scatter run as store-then-add instead of claim rounds (pv_wave_kernel.hip, "pairwise"; tests/test_pairwise_rule.py)
+                    rtM &= 0x7FFFFFFFu;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int pp = max(lastown[i], cprev), pn = min(firstown[i], cnext), b = 8 * tq + i;
+                        const bool rising = !(b - (pp >> 16) < (pn >> 16) - b);
+                        rt[i] = (rt[i] & 0x7FFFFFFFu) | (rising ? 0x80000000u : 0u);
+                        const int gap = (pn >> 16) - (pp >> 16), ov = __builtin_amdgcn_sbfe(pp, 0, 16) - __builtin_amdgcn_sbfe(pn, 0, 16);
+                        bad |= ov > (gap >> 1);
+                    }
+                }
             }
             *reinterpret_cast<uint4 *>(&ROUTE[8 * tq]) = uint4{rt[0], rt[1], rt[2], rt[3]};
             *reinterpret_cast<uint4 *>(&ROUTE[8 * tq + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
             if (tq == T - 1) ROUTE[M] = rtM;
+            if (!(pf >= 1.0)) { const bool wbad = __any(bad); if (l == 0) ROUTE[M + 4 + wv] = wbad ? 1u : 0u; }   // (words M+1 .. M+15 of the route array are spare)
         }
         int upper_end = H;
         if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
@@ -709,6 +734,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
                 else scatter(std::integral_constant<int, 1>{});
             } else {
+                bool pairwise;
                 unsigned rt[9];
                 float2 ys[9];
                 int id[9];
@@ -720,6 +746,36 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 rt[8] = (tq == 0) ? ROUTE[M / 2] : NOROUTE;
                 ys[8] = rotate_route<R, LOG2N>(rt[8], xHf, p.tw32);
                 id[8] = M / 2;
+                pairwise = PV_PAIRWISE != 0;
+#pragma unroll
+                for (int w = 0; w < G; w++) pairwise = pairwise && (ROUTE[M + 4 + w] == 0u);       // uniform in the workgroup
+                if (pairwise) {
+                    // every collision of this frame is one falling-side source against one rising-side source: the falling side and the residue (it
+                    // continues the falling side of the last peak) store into the zeroed Y, one barrier, the rising side adds.  No claim words, and
+                    // one barrier where every claim round has two.
+                    unsigned key[9];
+#pragma unroll
+                    for (int r = 0; r < 9; r++) key[r] = rt[r] & 0x8000FFFFu;
+#pragma unroll
+                    for (int r = 0; r < 9; r++) if (key[r] < (unsigned)H) Y[key[r]] = ys[r];
+                    const int up_delta = need_res ? (int)DSH[last_peak] : 0;
+                    const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+                    if (need_res && upper_end <= H + N / 8) {
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const int b = H + tq + T * j, tgt = b + up_delta;
+                            const unsigned rtj = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+                            if (rtj != NOROUTE) Y[tgt] = rotate_route<R, LOG2N>(rtj, s2v[j], p.tw32);
+                            if (dbg && b < upper_end) { p.dbg_X[2 * b] = s2v[j].x; p.dbg_X[2 * b + 1] = s2v[j].y; }
+                        }
+                    }
+                    __syncthreads();
+                    float2 o[9];
+#pragma unroll
+                    for (int r = 0; r < 9; r++) o[r] = Y[min(rt[r] & 0xFFFFu, (unsigned)M)];
+#pragma unroll
+                    for (int r = 0; r < 9; r++) if (key[r] - 0x80000000u < (unsigned)H) Y[key[r] - 0x80000000u] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
+                } else {
                 __syncthreads();                                            // every ROUTE read is done: the region becomes the claim words
 #pragma unroll
                 for (int r = 0; r < 8; r++) CLAIM[tq + T * r] = 0xFFFFFFFFu;
@@ -742,10 +798,14 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                             if (dbg && b < upper_end) { p.dbg_X[2 * b] = s2v[j].x; p.dbg_X[2 * b + 1] = s2v[j].y; }
                         }
                         claim_rounds_wg<2, H>(rt2, ys2, id2, Y, CLAIM);
-                    } else {
-                        residue_scatter_wg<LOG2N, R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, tq, upper_end, up_delta, up_ridx,
-                                                     dbg ? p.dbg_X : nullptr);
                     }
+                }
+                }
+                if (need_res && upper_end > H + N / 8) {                    // (one call site for both forms of the scatter: a second one spills the main loop)
+                    __syncthreads();
+                    const int up_delta = (int)DSH[last_peak];
+                    residue_scatter_wg<LOG2N, R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, tq, upper_end, up_delta,
+                                                 (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1), dbg ? p.dbg_X : nullptr, pairwise);
                 }
             }
         }
