@@ -23,7 +23,8 @@
 //
 // Everything between the transforms is pv_wave2k's pipeline with the lane id L = 64 g + l (16 consecutive bins per lane, padded magnitude /
 // route layout, packed peak words, select chains + ballot + bpermute inside a wave, two words handed across the wave boundary), the
-// workgroup kernel's atomic-MIN claim rounds for f < 1 (two waves post on the same target: the order must not depend on timing), the fast
+// workgroup kernel's f < 1 scatter (store / barrier / add on pairwise frames, else atomic-MIN claim rounds: two waves post on the same target,
+// the order must not depend on timing), the fast
 // above-Nyquist residue from a spectrum stash, and the per-quarter rebuild (residue_scatter_pair) when the last region reads beyond N/2 + N/8.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

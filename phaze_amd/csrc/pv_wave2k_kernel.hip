@@ -15,7 +15,7 @@
 //
 // Everything between the FFTs is the wave kernel's pipeline with 16 bins per lane (pv_wave_kernel.hip has the commentary and the reference
 // citations: split pass in conjugate pairs, |X|^2 -> v_max3_u32 peak flags, packed (bin, shift) peak words, select chains + ballot + two
-// bpermutes, one route per source bin, plain-store scatter for f >= 1, claim rounds for f < 1, fast above-Nyquist residue from the
+// bpermutes, one route per source bin, plain-store scatter for f >= 1, store-then-add (pairwise frames) or claim rounds for f < 1, fast above-Nyquist residue from the
 // spectrum, c2r pre-pass, overlap-add accumulator in registers).
 //
 // f < 1 frames whose last region reads beyond N/2 + N/8 (possible below f = 0.75) rebuild the above-Nyquist residue quarter by quarter

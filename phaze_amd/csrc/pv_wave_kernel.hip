@@ -16,7 +16,8 @@
 //     16-byte read of the cached Math.round(p f) - p table, nearest peaks by select chains + one ballot + two bpermutes; owner rule ->
 //     one route per source bin (pv:119-152)
 //   * scatter of the register-resident source bins along their routes (pv:155-170): plain stores when f >= 1 (regions disjoint; frames
-//     with t = 0 or N/2 (mod N) skip / simplify the rotation); f < 1 goes out of line: claim rounds, and the above-Nyquist residue either
+//     with t = 0 or N/2 (mod N) skip / simplify the rotation); f < 1 goes out of line: store-then-add when every collision of the frame is a
+//     (falling side, rising side) pair -- the usual case down to f ~ 0.65 --, claim rounds otherwise; the above-Nyquist residue either
 //     from the spectrum (decimation identity) or by re-running the reference's stage structure on one quarter
 //   * c2r pre-pass (conjugate pairs) + 512-pt inverse FFT in packed fp32 (pv_pk_math.h), Hann, overlap-add accumulator in registers in
 //     reference order (ola:149-157), finished hop stored coalesced, non-temporal
@@ -313,7 +314,7 @@ __device__ __attribute__((noinline)) void build_shift_table_1024(float f, unsign
     }
 }
 
-// f < 1: the whole colliding scatter (claim rounds + residue) lives out of line, so that its registers (nine routes, nine rotated values,
+// f < 1: the whole colliding scatter (two passes or claim rounds, + residue) lives out of line, so that its registers (nine routes, nine rotated values,
 // the batched claim reads) do not count against the main pipeline, whose f >= 1 path needs every one of its 168 VGPRs.
 struct Spectrum9 { float2 a[4], b[4], h; };     // bins l + 64 r, 512 - l - 64 r (r < 4), and 256 (lane 0)
 

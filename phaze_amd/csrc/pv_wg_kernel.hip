@@ -12,7 +12,8 @@
 //   pass C over u_hi         -> digit kC (weight 64),  twiddle W_{8G}^{u_lo kC}       t_lo = u_hi * G + u_lo
 //   pass D over u_lo (radix G) -> digit kD (weight 512)
 // and the result lands again as thread t', register r' <-> bin t' + T r'.  Everything between the two FFTs (split pass, |X|^2, peak
-// flags on 8 consecutive bins per thread, routes, scatter with claim rounds for f < 1, per-quarter residue, c2r pre-pass) and the
+// flags on 8 consecutive bins per thread, routes, scatter -- for f < 1: store / barrier / add on pairwise frames, else claim rounds --,
+// per-quarter residue, c2r pre-pass) and the
 // register-resident overlap-add follow the wave kernel; exchanges that were wave-local there (bpermute, ballot) go through LDS here.
 // Reference citations are those of pv_kernels.hip / pv_wave_kernel.hip.
 #include <hip/hip_runtime.h>

@@ -56,6 +56,7 @@ wg c5 --fft 8192 --hop 2048 --channels 8 --hops 16384 --pitch 1.5
 wg c3f07 --fft 2048 --hop 512 --channels 2 --hops 262144 --pitch 0.7
 wg native --fft 2048 --hop 128 --channels 2 --hops 262144 --pitch 1.0
 wg c2f08 --pitch 0.8
+wg c5f08 --fft 8192 --hop 2048 --channels 8 --hops 16384 --pitch 0.8
 # the calibrated pipe microbenchmark (tools/r03_pipe_microbench.hip): every row timed by s_memtime, s_memrealtime and HIP events
 [ -x $ROOT/tools/r03_pipe_microbench ] && timeout 300 $ROOT/tools/r03_pipe_microbench > "$OUT/pipe_microbench.txt" 2>&1
 ls "$OUT" | wc -l
