@@ -77,7 +77,12 @@ enum {
                                   * frame chain stores a sequence number into pinned host memory when its output is written and pv_process /
                                   * pv_process_end spin on those words (bounded; falls back to the stream wait) -- the runtime's completion
                                   * path costs more than the kernel of a quantum */
-    PV_FLAG_ALL = 15             /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
+    PV_FLAG_STREAM_PINNED_INPUT = 16, /* streaming quantum: the kernel READS its hop from pinned host memory over PCIe (the round-2/3 form).  Default
+                                  * since round 3 on a large-BAR device (hipDeviceAttributeIsLargeBar; every MI355X): a quantum of up to 16 KB of input
+                                  * is written by the HOST into device memory through the BAR (posted writes, ordered before the launch doorbell),
+                                  * so the kernel starts on local HBM instead of a PCIe read round trip; larger quanta and other devices keep the
+                                  * pinned-memory read.  The output always goes to pinned host memory (posted device writes) */
+    PV_FLAG_ALL = 31             /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
 };
 
 typedef struct pv_info {

@@ -52,14 +52,17 @@ def test_batch_matches_reference_golden(name):
     pv.close()
 
 
+@pytest.mark.parametrize("flags", [0, 16, 2 | 8], ids=["default", "pinned_input", "copy_nodes_event_wait"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_streaming_process_matches_reference_golden(name):
-    """process(inputs, outputs, parameters) one render quantum at a time, incl. pause / channel-change / a-rate."""
+def test_streaming_process_matches_reference_golden(name, flags):
+    """process(inputs, outputs, parameters) one render quantum at a time, incl. pause / channel-change / a-rate -- in the default form (small
+    quanta written by the host into device memory through the BAR, completion words), with PV_FLAG_STREAM_PINNED_INPUT (kernel reads the hop
+    from pinned host memory) and with PV_FLAG_STREAM_COPY | PV_FLAG_STREAM_EVENT_WAIT (copy nodes + stream wait: the round-1 form)."""
     case = CASES[name]
     sig, pitch = _inputs(case)
     T, h = min(case["store_hops"], 24), case["hop"]
     nmax = S.case_max_channels(case)
-    pv = _pv(fft_size=case["fft"], hop_size=h, max_channels=nmax, max_hops=1)
+    pv = _pv(fft_size=case["fft"], hop_size=h, max_channels=nmax, max_hops=1, flags=flags)
     out = np.zeros((nmax, T * h), np.float32)
     nch = case["nch"]
     for m in range(T):
