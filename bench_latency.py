@@ -44,7 +44,7 @@ def run(fft, hop, nch, fs, calls, sweep, flags=0):
     hist = np.histogram(lat, bins=edges)[0].tolist()
     budget_us = hop / fs * 1e6
     return {"metric": "stream_call_latency_us", "config": {"workload": f"{nch}-ch {fs // 1000} kHz FFT={fft} hop={hop} " + ("pitchFactor sweep 0.5->2.0" if sweep else "pitchFactor 1.5"),
-                                                            "calls": calls, "wait": "stream synchronize (PV_FLAG_STREAM_EVENT_WAIT)" if flags & 8 else "completion words in pinned memory (default)",
+                                                            "calls": calls, "wait": "stream synchronize (PV_FLAG_STREAM_EVENT_WAIT)" if flags & 8 else "resident kernel (PV_FLAG_PERSISTENT_STREAM)" if flags & 32 else "completion words in pinned memory (default)",
                                                             "input": "kernel reads pinned host memory (PV_FLAG_STREAM_PINNED_INPUT)" if flags & 16 else
                                                                      "host writes device memory through the BAR when the quantum is <= 16 KB (default on a large-BAR device)"},
             "p50": q(50), "p90": q(90), "p99": q(99), "max": float(lat.max()), "mean": float(lat.mean()),
@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--calls", type=int, default=3000)
     ap.add_argument("--event-wait", action="store_true", help="also run every configuration with PV_FLAG_STREAM_EVENT_WAIT (the round-2 wait) for the A/B")
     ap.add_argument("--pinned-input", action="store_true", help="also run every configuration with PV_FLAG_STREAM_PINNED_INPUT (kernel reads the hop over PCIe) for the A/B")
+    ap.add_argument("--resident", action="store_true", help="also run every configuration with PV_FLAG_PERSISTENT_STREAM (resident kernel where the shape supports it)")
     args = ap.parse_args()
     for cfg in [(8192, 2048, 8, 96000, True), (2048, 128, 2, 48000, False), (1024, 256, 1, 48000, False), (4096, 1024, 8, 48000, False)]:
         print(json.dumps(run(*cfg[:4], args.calls, cfg[4])), flush=True)
@@ -65,6 +66,8 @@ def main():
             print(json.dumps(run(*cfg[:4], args.calls, cfg[4], flags=8)), flush=True)
         if args.pinned_input:
             print(json.dumps(run(*cfg[:4], args.calls, cfg[4], flags=16)), flush=True)
+        if args.resident:
+            print(json.dumps(run(*cfg[:4], args.calls, cfg[4], flags=32)), flush=True)
 
 
 if __name__ == "__main__":

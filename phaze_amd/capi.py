@@ -44,7 +44,7 @@ ABI_VERSION = 2          # PV_ABI_VERSION of include/phaze_amd.h this binding wa
 
 
 # pv_config.flags (include/phaze_amd.h): explicit A/B switches; the library reads no environment variables
-FLAG_GENERIC_KERNEL, FLAG_STREAM_COPY, FLAG_WORKGROUP_KERNEL, FLAG_STREAM_EVENT_WAIT, FLAG_STREAM_PINNED_INPUT = 1, 2, 4, 8, 16
+FLAG_GENERIC_KERNEL, FLAG_STREAM_COPY, FLAG_WORKGROUP_KERNEL, FLAG_STREAM_EVENT_WAIT, FLAG_STREAM_PINNED_INPUT, FLAG_PERSISTENT_STREAM = 1, 2, 4, 8, 16, 32
 
 
 class _Info(C.Structure):

@@ -46,6 +46,11 @@ struct pv_handle {
     volatile unsigned *h_done;                   // pinned: completion word of every frame chain of a streaming quantum (PvKernelParams::done)
     unsigned *d_done;                            // device view of h_done; null = wait through hipStreamSynchronize
     unsigned quantum_seq;                        // sequence number the chains of the pending quantum store (never 0)
+    volatile unsigned *h_ctl;                    // pinned control block of the resident streaming kernel {seq, nch, t0 mod N, cur, stop, slots in use}; null = not used
+    unsigned *d_ctl;
+    bool resident_bar;                           // the resident kernel's control block and input live in DEVICE memory, written by the host through the BAR
+    bool resident_on;                            // a resident kernel has been launched on the stream and not been stopped since
+    std::chrono::steady_clock::time_point last_quantum;   // ... and when it was last given work (its waves leave after ~50 ms without)
     double *d_dbgX; float *d_dbgMag; int *d_dbgFlags; float *d_dbgY;
 #ifdef PV_STAMPS
     unsigned *d_stamps;                          // measurement builds only: [chain][16] phase clocks of the wave kernel
@@ -178,6 +183,47 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
         h->cur ^= 1;
         h->time_cursor += (int64_t)nhops * h->hop;
     }
+    return PV_OK;
+}
+
+// ---- resident streaming kernel (PV_FLAG_PERSISTENT_STREAM) ----
+// Asks the resident waves to leave and waits for them: required before anything else is put on the handle's stream (it would queue behind them).
+int resident_stop(pv_handle *h)
+{
+    if (!h->resident_on) return PV_OK;
+    h->h_ctl[4] = 1u;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+#if defined(__x86_64__)
+    _mm_sfence();
+#endif
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->h_ctl[4] = 0u;
+    h->resident_on = false;
+    return PV_OK;
+}
+
+// (Re)starts the resident waves: `last_seq` is the last sequence number that has been completed (they react to the next one).
+int resident_start(pv_handle *h, unsigned last_seq)
+{
+    PvKernelParams p;
+    memset(&p, 0, sizeof p);
+    const int hop = h->hop;
+    float *stage = h->resident_bar ? h->d_quantum : h->d_pin_mapped;         // where the host puts pitchFactor + input (see pv_process_begin)
+    p.in = stage + kHdrFloats; p.out = h->d_pin_mapped + kHdrFloats + (size_t)h->max_channels * hop; p.ch_stride = hop;
+    p.nhops = 1; p.hop = hop; p.frames_per_chunk = 1;
+    p.pitch = stage; p.pitch_stride = 0; p.ch_per_stream = 1;
+    p.hist_in = h->d_hist[0]; p.hist_out = h->d_hist[1]; p.acc_in = h->d_acc[0]; p.acc_out = h->d_acc[1];
+    for (int i = 0; i < 2; i++) { p.hist2[i] = h->d_hist[i]; p.acc2[i] = h->d_acc[i]; }
+    p.tw64 = h->d_tw64; p.tw32 = h->d_tw32; p.hann = h->d_hann;
+    p.dbg_ch = -1; p.dbg_frame = -1;
+    p.done = h->d_done; p.done_seq = last_seq;
+    p.ctl = h->d_ctl;
+    h->h_ctl[4] = 0u;
+    const hipError_t e = pv_launch_wave_resident(p, h->max_channels, h->stream);
+    if (e != hipSuccess) return fail_hip(h, e, "resident kernel launch");
+    h->resident_on = true;
+    h->last_frames_per_chunk = 1;
     return PV_OK;
 }
 
@@ -334,6 +380,27 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         h->h_done = hd;
         if (hipHostGetDevicePointer(&dd, hd, 0) == hipSuccess) h->d_done = (unsigned *)dd;
         (void)hipGetLastError();
+        if (h->d_done && (cfg->flags & PV_FLAG_PERSISTENT_STREAM) && h->use_wave && maxch <= 64) {
+            // Control block: in DEVICE memory when the host can write it through the BAR and the largest quantum is small enough to travel the same
+            // way -- the waves then poll their own HBM and find the input there too, the only PCIe traffic of a quantum being posted writes in both
+            // directions (tools/bar_probe.hip: 1 KB handed over and acknowledged in 3.5 us, 7.2 us with the block and the input in pinned host memory)
+            h->resident_bar = h->bar_input && sizeof(float) * (size_t)maxch * hop <= 16384;
+            if (h->resident_bar) {
+                void *dc = nullptr;
+                CHK(hipMalloc(&dc, 64));
+                CHK(hipMemset(dc, 0, 64));
+                h->d_ctl = (unsigned *)dc;
+                h->h_ctl = (volatile unsigned *)dc;                          // (written, never read, by the host)
+            } else {
+                unsigned *hc = nullptr;
+                void *dc = nullptr;
+                CHK(hipHostMalloc((void **)&hc, 64, hipHostMallocMapped));
+                memset(hc, 0, 64);
+                h->h_ctl = hc;
+                if (hipHostGetDevicePointer(&dc, hc, 0) == hipSuccess) h->d_ctl = (unsigned *)dc; else h->h_ctl = nullptr;
+                (void)hipGetLastError();
+            }
+        }
     }
     CHK(hipMalloc(&h->d_dbgX, sizeof(double) * 2 * N));
     CHK(hipMalloc(&h->d_dbgMag, sizeof(float) * (N / 2 + 1)));
@@ -353,12 +420,14 @@ int pv_destroy(pv_handle *h)
     if (!h) return PV_OK;
     if (h->magic != kMagic) return PV_ERR_DESTROYED;
     (void)hipSetDevice(h->device);
+    (void)resident_stop(h);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     (void)hipFree(h->d_tw64); (void)hipFree(h->d_tw32); (void)hipFree(h->d_hann);
     for (int i = 0; i < 2; i++) { (void)hipFree(h->d_hist[i]); (void)hipFree(h->d_acc[i]); }
     (void)hipFree(h->d_stage_in); (void)hipFree(h->d_stage_out); (void)hipFree(h->d_pitch);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_done) (void)hipHostFree((void *)h->h_done);
+    if (h->h_ctl) { if (h->resident_bar) (void)hipFree((void *)h->h_ctl); else (void)hipHostFree((void *)h->h_ctl); }
     (void)hipFree(h->d_quantum);
     (void)hipFree(h->d_dbgX); (void)hipFree(h->d_dbgMag); (void)hipFree(h->d_dbgFlags); (void)hipFree(h->d_dbgY);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -388,6 +457,7 @@ int pv_get_info(const pv_handle *h, pv_info *out)
 int pv_reset_channels(pv_handle *h, int32_t first, int32_t count)
 {
     if (!live(h)) return PV_ERR_DESTROYED;
+    { const int rs_ = resident_stop(h); if (rs_ != PV_OK) return rs_; }
     if (first < 0 || count < 0 || first + count > h->max_channels) return fail(h, PV_ERR_ARGUMENT, "pv_reset_channels: range out of bounds");
     if (count == 0 || h->L == 0) return PV_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -431,6 +501,7 @@ int pv_set_time_cursor(pv_handle *h, int64_t value)
 int pv_export_state(pv_handle *h, int32_t ch, float *hist, float *acc, int64_t *time_cursor)
 {
     if (!live(h)) return PV_ERR_DESTROYED;
+    { const int rs_ = resident_stop(h); if (rs_ != PV_OK) return rs_; }
     if (ch < 0 || ch >= h->max_channels) return fail(h, PV_ERR_ARGUMENT, "pv_export_state: channel out of range");
     if (h->pending_nch > 0) return fail(h, PV_ERR_ARGUMENT, "pv_export_state: a quantum is pending (pv_process_end)");
     HIPCHK(h, hipSetDevice(h->device));
@@ -445,6 +516,7 @@ int pv_export_state(pv_handle *h, int32_t ch, float *hist, float *acc, int64_t *
 int pv_import_state(pv_handle *h, int32_t ch, const float *hist, const float *acc, int64_t time_cursor)
 {
     if (!live(h)) return PV_ERR_DESTROYED;
+    { const int rs_ = resident_stop(h); if (rs_ != PV_OK) return rs_; }
     if (ch < 0 || ch >= h->max_channels) return fail(h, PV_ERR_ARGUMENT, "pv_import_state: channel out of range");
     if (h->pending_nch > 0) return fail(h, PV_ERR_ARGUMENT, "pv_import_state: a quantum is pending (pv_process_end)");
     if (time_cursor >= 0 && time_cursor % h->hop != 0) return fail(h, PV_ERR_ARGUMENT, "pv_import_state: time_cursor is not a multiple of hop_size");
@@ -461,6 +533,7 @@ int pv_import_state(pv_handle *h, int32_t ch, const float *hist, const float *ac
 int pv_set_stream(pv_handle *h, void *hip_stream)
 {
     if (!live(h)) return PV_ERR_DESTROYED;
+    { const int rs_ = resident_stop(h); if (rs_ != PV_OK) return rs_; }
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return PV_OK;
 }
@@ -468,6 +541,7 @@ int pv_set_stream(pv_handle *h, void *hip_stream)
 int pv_synchronize(pv_handle *h)
 {
     if (!live(h)) return PV_ERR_DESTROYED;
+    { const int rs_ = resident_stop(h); if (rs_ != PV_OK) return rs_; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PV_OK;
@@ -496,7 +570,7 @@ int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t 
     // Above kBarInputMax the BAR write itself (~1.4 GB/s from one core) costs more than the waves' parallel reads.  The previous quantum's kernel
     // has finished (pv_process_end) before this buffer is written again.
     constexpr size_t kBarInputMax = 16384;
-    const bool bar = h->bar_input && sizeof(float) * (size_t)nch * hop <= kBarInputMax;
+    const bool bar = h->h_ctl ? h->resident_bar : (h->bar_input && sizeof(float) * (size_t)nch * hop <= kBarInputMax);   // (a resident kernel's pointers are fixed)
     float *stage = bar ? h->d_quantum : h->h_pin;
     float *pin_in = stage + kHdrFloats;
     stage[0] = pitch_factor;
@@ -508,6 +582,33 @@ int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t 
     if (bar) _mm_sfence();                                                       // write-combining buffers drained before the doorbell
 #endif
     auto launch = [&]() -> int {
+        if (h->d_pin_mapped && h->h_ctl) {
+            // resident kernel: no launch -- start the waves if none are there (first quantum, or they left after their idle time-out), then publish the
+            // quantum: its parameters first, the sequence number last
+            const auto now = std::chrono::steady_clock::now();
+            if (h->resident_on && now - h->last_quantum > std::chrono::milliseconds(20)) {   // long pause: the waves may have left
+                if (hipStreamQuery(h->stream) == hipSuccess) h->resident_on = false;
+                (void)hipGetLastError();
+            }
+            h->last_quantum = now;
+            if (!h->resident_on) { const int rc = resident_start(h, h->quantum_seq); if (rc != PV_OK) return rc; }
+            unsigned seq = (h->quantum_seq + 1u) & 0xFFFFu;                  // the resident protocol carries 16 bits of it (never 0)
+            if (seq == 0) seq = 1;
+            h->quantum_seq = seq;
+            if (nch > h->used_channels) h->used_channels = nch;
+            h->h_ctl[5] = (unsigned)h->used_channels;
+            std::atomic_thread_fence(std::memory_order_seq_cst);            // inputs, pitch and parameters are in memory before the waves see the word
+#if defined(__x86_64__)
+            _mm_sfence();
+#endif
+            h->h_ctl[0] = seq | ((unsigned)nch << 16) | ((unsigned)h->cur << 23) | ((unsigned)((h->time_cursor / hop) % h->R) << 24);
+#if defined(__x86_64__)
+            _mm_sfence();                                                    // (through the BAR: out of the write-combining buffer now, not when it fills)
+#endif
+            h->cur ^= 1;                                                     // what run_chain() commits for a launched quantum
+            h->time_cursor += hop;
+            return PV_OK;
+        }
         if (h->d_pin_mapped) {
             float *m_in = (bar ? h->d_quantum : h->d_pin_mapped) + kHdrFloats, *m_out = h->d_pin_mapped + kHdrFloats + (size_t)h->max_channels * hop;
             unsigned seq = 0;
@@ -554,13 +655,24 @@ int pv_process_end(pv_handle *h, float *const *out)
 #if defined(__x86_64__)
             _mm_pause();
 #endif
-            if ((spins & 0x3FFu) == 0x3FFu && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+            if ((spins & 0x3FFu) == 0x3FFu) {
+                const auto waited = std::chrono::steady_clock::now() - t0;
+                if (h->h_ctl && h->resident_on && waited > std::chrono::milliseconds(2) && hipStreamQuery(h->stream) == hipSuccess) {
+                    // the resident waves left (idle time-out) just as this quantum was published: start new ones, they pick it up
+                    h->resident_on = false;
+                    if (resident_start(h, seq - 1u) != PV_OK) break;
+                }
+                (void)hipGetLastError();
+                if (waited > std::chrono::milliseconds(200)) break;
+            }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
     if (!done) {
+        if (h->resident_on) { h->h_ctl[4] = 1u; std::atomic_thread_fence(std::memory_order_seq_cst); }   // ask the resident waves to leave: the wait below must end
         e = hipSetDevice(h->device);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (h->resident_on) { h->h_ctl[4] = 0u; h->resident_on = false; if (e == hipSuccess) e = hipErrorLaunchFailure; }   // the quantum did not complete
     }
     if (e != hipSuccess) {                                                       // the state is committed only when the whole quantum succeeded
         h->cur = h->pending_cur; h->time_cursor = h->pending_time_cursor; h->active_nch = h->pending_active_nch;
@@ -584,6 +696,7 @@ int pv_process_batch_device(pv_handle *h, const float *d_in, float *d_out, int32
                             const float *d_pitch, int32_t pitch_stride, int32_t channels_per_stream)
 {
     if (!live(h)) return PV_ERR_DESTROYED;
+    { const int rs_ = resident_stop(h); if (rs_ != PV_OK) return rs_; }
     if (!d_in || !d_out || !d_pitch || nch <= 0 || nhops <= 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: bad arguments");
     if (h->pending_nch > 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch_device: a quantum is pending (pv_process_end)");
     if (nch > h->max_channels) return fail(h, PV_ERR_CAPACITY, "pv_process_batch_device: nch exceeds max_channels");
@@ -598,6 +711,7 @@ int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int
                      int32_t pitch_stride, int32_t channels_per_stream)
 {
     if (!live(h)) return PV_ERR_DESTROYED;
+    { const int rs_ = resident_stop(h); if (rs_ != PV_OK) return rs_; }
     if (!in || !out || !pitch || nch <= 0 || nhops <= 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: bad arguments");
     if (h->pending_nch > 0) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: a quantum is pending (pv_process_end)");
     if (nch > h->max_channels || nhops > h->max_hops) return fail(h, PV_ERR_CAPACITY, "pv_process_batch: nch/nhops exceed the handle's capacity");
@@ -629,6 +743,7 @@ int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int
 int pv_debug_frame(pv_handle *h, int32_t ch, const float *block, float pitch_factor, double *X, float *mag, int32_t *peak_flags, float *Y)
 {
     if (!live(h)) return PV_ERR_DESTROYED;
+    { const int rs_ = resident_stop(h); if (rs_ != PV_OK) return rs_; }
     if (ch < 0 || ch >= h->max_channels || !block) return fail(h, PV_ERR_ARGUMENT, "pv_debug_frame: bad arguments");
     HIPCHK(h, hipSetDevice(h->device));
     const int hop = h->hop, N = h->N, H = N / 2 + 1;

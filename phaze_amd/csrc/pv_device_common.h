@@ -84,7 +84,12 @@ struct WaveSrc {
     const float *in;
     const float *hist;
     int hist_len;
-    __device__ __forceinline__ float at(long s) const { return s < 0 ? hist[s + hist_len] : in[s]; }
+    bool sys = false;      // resident streaming kernel: `in` is pinned host memory the host rewrites between quanta WITHIN one launch -> system-scope loads
+    __device__ __forceinline__ float at(long s) const
+    {
+        if (s < 0) return hist[s + hist_len];
+        return sys ? __hip_atomic_load(in + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : in[s];
+    }
 };
 
 constexpr unsigned NOROUTE = 0xFFFFFFFFu;        // route = (rotation index << 16) | target bin

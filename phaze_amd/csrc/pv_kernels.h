@@ -34,6 +34,10 @@ struct PvKernelParams {
     // and the host spins on those words in pinned memory instead of going through hipStreamSynchronize (null in batch launches)
     unsigned *done;
     unsigned done_seq;
+    // resident streaming kernel (PV_FLAG_PERSISTENT_STREAM): the kernel does not end after its quantum but polls ctl[0] (pinned host memory) for the
+    // next sequence number.  ctl = {seq, nch, t0_mod_n, cur, stop}; state2[] = both halves of the state ping-pong (cur selects hist_in / acc_in).
+    const unsigned *ctl;
+    float *hist2[2], *acc2[2];
     unsigned *stamps;         // measurement builds only (-DPV_STAMPS, tools/exp_headline.sh): [chain][16] accumulated s_memtime deltas per phase
 };
 
@@ -59,6 +63,8 @@ size_t pv_wave_lds_bytes();
 int pv_wave_threads();
 bool pv_wave_supported(int log2n, int hop);
 hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
+// resident form of the same kernel for streaming quanta (p.ctl != null): one wave per channel slot, nslots of them, polling p.ctl until ctl[4] (stop) or ~50 ms idle
+hipError_t pv_launch_wave_resident(const PvKernelParams &p, int nslots, hipStream_t st);
 
 // one wavefront per 2048-point frame (pv_wave2k_kernel.hip): N = 2048, hop in {128, 256, 512, 1024, 2048}, every pitchFactor
 bool pv_wave2k_supported(int log2n, int hop);

@@ -41,6 +41,7 @@ namespace {
 #define PV_WAVES_PER_SIMD 3
 #endif
 constexpr int WAVES = PV_WAVES;                  // independent frame chains per workgroup (they only share the LDS tables)
+constexpr int RES_WAVES = 4;                    // ... of the resident streaming instance: one wave per SIMD, i.e. the whole register file (no spills on the latency path)
 constexpr int TAB_TW1 = 0;                       // double2[8*64]  W_512^{l k}
 constexpr int TAB_TW2 = TAB_TW1 + 8 * 64 * 16;   // double2[8*8]   W_64^{n0 k}
 // The fp32 tables are stored in PAIRS of rows (a ds_read costs the LDS pipe the same ~3 cycles whether it returns 8 or 16 bytes per lane,
@@ -223,7 +224,7 @@ __device__ __forceinline__ void residue_fast_1024(const float2 *__restrict__ tw3
 // by re-running the reference's stage structure (bundle:306-442,468-508) on that quarter in fp32 -- and add those sources into Y.
 // Kept out of line so that its registers do not count against the main pipeline (3 waves per SIMD need <= 168 VGPRs).
 template <int R_>
-__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(const float *in, const float *hist, int hist_len, bool sys, long s0, const float *__restrict__ hann,
                                                                const float2 *__restrict__ tw32, unsigned wave_off, int l, int upper_end, int up_delta,
                                                                unsigned up_ridx, double *dbg_X)
 {
@@ -236,7 +237,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(co
     const float *HWf = reinterpret_cast<const float *>(smem_all + TAB_HANN);
     auto hw_at = [&](int smp) { const int n = smp >> 1, ln = n & 63, r = n >> 6; return HWf[4 * ((r >> 1) * 64 + ln) + 2 * (r & 1) + (smp & 1)]; };
     (void)hann;
-    const WaveSrc src{in, hist, hist_len};
+    const WaveSrc src{in, hist, hist_len, sys};
     for (int base = N / 2; base < N && base < upper_end; base += N / 4) {
         {   // base stage: radix-4 blocks t = base/4 + l (bundle:468-508), input index = base-4 digit reversal of t
             const int t = base / 4 + l;
@@ -326,7 +327,7 @@ struct Spectrum9 { float2 a[4], b[4], h; };     // bins l + 64 r, 512 - l - 64 r
 #endif
 template <int R_>
 __device__ PV_COLLIDE_ATTR PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 X, unsigned wave_off, int l, int tmod, int last_peak, int upper_end, bool pairwise,
-                                                                               const float *in, const float *hist, int hist_len, long s0,
+                                                                               const float *in, const float *hist, int hist_len, bool sys, long s0,
                                                                                const float *__restrict__ hann, const float2 *__restrict__ tw32, double *dbg_X)
 {
     constexpr int N = 1024, H = 513;
@@ -391,7 +392,7 @@ __device__ PV_COLLIDE_ATTR PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 
         }
 #pragma unroll
         for (int r = 0; r < 9; r++) if (key[r] - 0x80000000u < 513u) Y[rt[r] & 0x3FFu] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
-        if (need_res && !fast_res) residue_scatter_1024<R_>(in, hist, hist_len, s0, hann, tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
+        if (need_res && !fast_res) residue_scatter_1024<R_>(in, hist, hist_len, sys, s0, hann, tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
         return;
     }
     if (fast_res) {
@@ -429,21 +430,24 @@ __device__ PV_COLLIDE_ATTR PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 
         for (int r = 0; r < 9; r++) if ((rt[r] & 0xFFFFu) < 513u) Y[rt[r] & 0xFFFFu] = ys[r];
     } else
     claim_rounds<9, true>(rt, ys, id, Y, CLAIM);
-    if (need_res) residue_scatter_1024<R_>(in, hist, hist_len, s0, hann, tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
+    if (need_res) residue_scatter_1024<R_>(in, hist, hist_len, sys, s0, hann, tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
 }
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
 // AUX = true: test-tap instance (pv_debug_frame); the production instance carries no tap code.
-template <int S_ROWS, bool AUX>
-__global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void pv_wave_kernel_1024(const PvKernelParams p)
+// RESIDENT = true: streaming instance that stays on the GPU (PV_FLAG_PERSISTENT_STREAM): after its quantum a wave polls the control block in pinned host memory
+// for the next sequence number instead of ending (pv_capi.hip: persist_*); a quantum then costs no launch.  One wave per channel slot, 1 hop per quantum.
+template <int S_ROWS, bool AUX, bool RESIDENT = false>
+__global__ __launch_bounds__(64 * (RESIDENT ? RES_WAVES : WAVES), RESIDENT ? 1 : PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void pv_wave_kernel_1024(const PvKernelParams p)
 {
+    constexpr int WGW = RESIDENT ? RES_WAVES : WAVES;                    // waves per workgroup of this instance
     constexpr int N = 1024, M = 512, H = 513;
     constexpr int HOP = 128 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;    // LROWS rows of carried accumulator
     const int l = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // chains are numbered channel-major over (channel, chunk) and packed 12 to a workgroup regardless of the channel they belong to: many short
     // streams (one chunk per channel) fill the workgroups exactly like one long stream does
-    const long chain = (long)blockIdx.x * WAVES + wv;
+    const long chain = (long)blockIdx.x * WGW + wv;
     const int ch = (int)(chain / p.nchunks), chunk = (int)(chain - (long)ch * p.nchunks);
 
     // ---- LDS carve (all dynamic, 16-byte aligned): shared tables, then one private region per wave ----
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
         float2 *t1f = reinterpret_cast<float2 *>(smem_all + TAB_TW1F);     // pair-interleaved: [((k >> 1) * 64 + l) * 2 + (k & 1)]
         float2 *t2f = reinterpret_cast<float2 *>(smem_all + TAB_TW2F);     // [((k >> 1) * 8 + n0) * 2 + (k & 1)]
         float2 *hh = reinterpret_cast<float2 *>(smem_all + TAB_HANN);      // [((r >> 1) * 64 + l) * 2 + (r & 1)]
-        for (int i = threadIdx.x; i < 512; i += 64 * WAVES) {
+        for (int i = threadIdx.x; i < 512; i += 64 * WGW) {
             const int k = i >> 6, ln = i & 63;
             const double2 w = p.tw64[(2 * ln * k) & (N - 1)];
             t1[i] = w;
@@ -481,6 +485,40 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
     }
     __syncthreads();                                                     // the only workgroup-wide barrier
     if (ch >= p.nch) return;
+    // what changes from quantum to quantum in the resident form (constants of the launch otherwise)
+    const float *hist_in = p.hist_in, *acc_in = p.acc_in;
+    float *hist_out = p.hist_out, *acc_out = p.acc_out;
+    int t0_mod_n = p.t0_mod_n;
+    unsigned done_seq = p.done_seq;
+    unsigned last_seq = p.done_seq;                                      // resident: the last quantum completed before this launch
+resident_top:
+    if (RESIDENT) {
+        // ctl[0] carries the whole quantum in ONE word -- sequence number (low 16 bits, never 0), channel count (7 bits), ping-pong half (1 bit),
+        // timeCursor / hop mod R (8 bits) -- so that a successful poll needs no second round trip over PCIe before the input can be requested
+        unsigned word, idle = 0;
+        for (;;) {
+            word = __hip_atomic_load(p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((word & 0xFFFFu) != (last_seq & 0xFFFFu)) break;
+            // leave when asked to, or after ~50 ms without work (the host relaunches on demand: a resident wave must never outlive its user)
+            if (__hip_atomic_load(p.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || ++idle > 60000u) return;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                    // system scope: what the host wrote before the word
+        const unsigned seq = word & 0xFFFFu, nch_now = (word >> 16) & 0x7Fu, cur = (word >> 23) & 1u;
+        t0_mod_n = (int)(((word >> 24) & 0xFFu) * HOP) & (N - 1);
+        hist_in = p.hist2[cur]; hist_out = p.hist2[cur ^ 1u];
+        acc_in = p.acc2[cur]; acc_out = p.acc2[cur ^ 1u];
+        done_seq = last_seq = seq;
+        if ((unsigned)ch >= nch_now) {
+            // this channel slot is not part of the quantum: if it holds state (ctl[5] = slots in use), carry it across the ping-pong flip
+            if ((unsigned)ch < __hip_atomic_load(p.ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+                for (int j = l; j < N - HOP; j += 64) {
+                    hist_out[(long)ch * (N - HOP) + j] = hist_in[(long)ch * (N - HOP) + j];
+                    acc_out[(long)ch * (N - HOP) + j] = acc_in[(long)ch * (N - HOP) + j];
+                }
+            goto resident_top;
+        }
+    }
 
 #ifdef PV_PT_STATIC
     {   // experiment: static priority by the wave's rank on its SIMD (waves wv, wv + 4, wv + 8 share one)
@@ -507,7 +545,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
     if (from_state) first_frame = 0;
 
     const long cbase = (long)ch * p.ch_stride;
-    const WaveSrc src{p.in + cbase, p.hist_in + (long)ch * (N - HOP), N - HOP};
+    const WaveSrc src{p.in + cbase, hist_in + (long)ch * (N - HOP), N - HOP, RESIDENT};
     float *outp = p.out + cbase;
     const bool vec_out = (reinterpret_cast<uintptr_t>(outp) & 7u) == 0;           // 8-byte aligned channel base: float2 stores
     const bool vec_in = ((reinterpret_cast<uintptr_t>(src.in) | reinterpret_cast<uintptr_t>(src.hist)) & 7u) == 0;
@@ -527,7 +565,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
     if (from_state) {
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
-            const float *a = p.acc_in + (long)ch * (N - HOP) + 2 * l + 128 * r;
+            const float *a = acc_in + (long)ch * (N - HOP) + 2 * l + 128 * r;
             acc[r] = float2{a[0], a[1]};
         }
     }
@@ -539,7 +577,10 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
 #pragma unroll
         for (int r = 0; r < nrows; r++) {
             const long sx = s0 + 128 * (first_row + r);
-            if (vec_in) w[r] = *reinterpret_cast<const float2 *>(sx < 0 ? src.hist + sx + src.hist_len : src.in + sx);
+            if (RESIDENT && vec_in && sx >= 0) {                           // the host's hop of this quantum: never from a cache
+                const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src.in + sx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w[r] = float2{__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32))};
+            } else if (vec_in) w[r] = *reinterpret_cast<const float2 *>(sx < 0 ? src.hist + sx + src.hist_len : src.in + sx);
             else w[r] = float2{src.at(sx), src.at(sx + 1)};
         }
     };
@@ -550,7 +591,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
     // s_waitcnt vmcnt(#stores) at the top of the next frame.  A load in mid-frame (the pitch row used to be read where it was needed) or a
     // wave-uniform branch around the stores makes the compiler wait with vmcnt(0) -- for the prefetch it has just issued and for the
     // acknowledgement of the stores -- and every frame of every wave then sits out two exposed HBM round trips.
-    float pf_next = pitch_row[first_frame];
+    float pf_next = RESIDENT ? __hip_atomic_load(pitch_row + first_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : pitch_row[first_frame];
     int emit_v = first_out;
     asm volatile("" : "+v"(emit_v));                                     // opaque VGPR copy of first_out: keeps the store predicate divergent
     // 0.5 * Hann rows of this lane: read at the END of a frame (4 ds_read_b128) for the synthesis window and kept across the loop edge for
@@ -567,7 +608,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
     for (int m = first_frame; m < last_out; ++m) {
         const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));   // k-rate pitchFactor (pv:47), wave-uniform
         const double pf = (double)pfm;
-        const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
+        const int tmod = (int)(((long)t0_mod_n + (long)m * HOP) & (N - 1));
         const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
 
         pv_prio(PH_FA);
@@ -872,7 +913,7 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
                 else scatter(std::integral_constant<int, 1>{});
             } else {
                 scatter_colliding_1024<R>(Spectrum9{{XA[0], XA[1], XA[2], XA[3]}, {XB[0], XB[1], XB[2], XB[3]}, x256f}, wave_off, l, tmod, last_peak, upper_end, pairwise,
-                                          src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, dbg ? p.dbg_X : nullptr);
+                                          src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw32, dbg ? p.dbg_X : nullptr);
             }
         }
         if (nonfinite && l == 0) Y[1] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};   // see "Non-finite magnitudes" above
@@ -973,14 +1014,15 @@ __global__ __launch_bounds__(64 * WAVES, PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void 
     if (chunk == p.nchunks - 1) {
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
-            float *a = p.acc_out + (long)ch * (N - HOP) + 2 * l + 128 * r;
+            float *a = acc_out + (long)ch * (N - HOP) + 2 * l + 128 * r;
             a[0] = acc[r].x; a[1] = acc[r].y;
-            float *hs = p.hist_out + (long)ch * (N - HOP) + 2 * l + 128 * r;
+            float *hs = hist_out + (long)ch * (N - HOP) + 2 * l + 128 * r;
             const long s = (long)p.nhops * HOP - (N - HOP) + 2 * l + 128 * r;
             hs[0] = src.at(s); hs[1] = src.at(s + 1);
         }
     }
-    pv_signal_done<false>(p.done, p.done_seq, chain);
+    pv_signal_done<false>(p.done, done_seq, chain);
+    if (RESIDENT) goto resident_top;
 }
 
 template <int S_ROWS, bool AUX>
@@ -1000,6 +1042,24 @@ hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_
     return hipGetLastError();
 }
 
+template <int S_ROWS>
+hipError_t launch_wave_resident(const PvKernelParams &p, int nslots, hipStream_t st)
+{
+    static std::atomic<bool> attr_done[16];
+    auto k = pv_wave_kernel_1024<S_ROWS, false, true>;
+    {
+        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_wave_lds_bytes());
+        if (e != hipSuccess) return e;
+    }
+    PvKernelParams q = p;
+    q.nchunks = 1;
+    q.nch = nslots;                                                        // waves beyond the handle's channel slots leave at once
+    q.nhops = 1;
+    q.frames_per_chunk = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)((nslots + RES_WAVES - 1) / RES_WAVES), 1, 1), dim3(64 * RES_WAVES, 1, 1), pv_wave_lds_bytes(), st, q);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 #ifndef PV_LDS_PAD
@@ -1010,6 +1070,17 @@ size_t pv_wave_lds_bytes() { return TAB_BYTES + WAVES * WAVE_LDS + PV_LDS_PAD; }
 int pv_wave_threads() { return 64 * WAVES; }
 
 bool pv_wave_supported(int log2n, int hop) { return log2n == 10 && (hop == 128 || hop == 256 || hop == 512 || hop == 1024); }
+
+hipError_t pv_launch_wave_resident(const PvKernelParams &p, int nslots, hipStream_t st)
+{
+    switch (p.hop) {
+    case 128: return launch_wave_resident<1>(p, nslots, st);
+    case 256: return launch_wave_resident<2>(p, nslots, st);
+    case 512: return launch_wave_resident<4>(p, nslots, st);
+    case 1024: return launch_wave_resident<8>(p, nslots, st);
+    default: return hipErrorInvalidValue;
+    }
+}
 
 hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {

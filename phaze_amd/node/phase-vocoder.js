@@ -45,6 +45,7 @@ class PhaseVocoderProcessor extends Base {
         this.fftSize = this.blockSize;
         this.nbOverlaps = this.blockSize / this.hopSize;       // ola-processor.js:17
         this.deviceId = po.deviceId | 0;
+        this._flags = po.flags | 0;                                     // PV_FLAG_* of include/phaze_amd.h (e.g. 32 = resident streaming kernel); 0 in normal use
         this._maxHops = Math.max(1, po.maxHops | 0);                   // staging size of the throughput entry point (processBatch)
         this._handles = [];
         this._channels = [];
@@ -54,7 +55,7 @@ class PhaseVocoderProcessor extends Base {
             // re-create for the common mono->stereo switch.  Throws Error('FFT size must be a power of two and
             // bigger than 1') for bad sizes, as `new FFT(n)` does (bundle:6-7).
             this._capacity.push(2);
-            this._handles.push(native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: 2, maxHops: this._maxHops, deviceId: this.deviceId }));
+            this._handles.push(native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: 2, maxHops: this._maxHops, deviceId: this.deviceId, flags: this._flags }));
             this._channels.push(1);
         }
     }
@@ -70,7 +71,7 @@ class PhaseVocoderProcessor extends Base {
                     const t = native.timeCursor(this._handles[i]);
                     native.destroy(this._handles[i]);
                     this._capacity[i] = Math.max(nb, 2 * this._capacity[i]);
-                    this._handles[i] = native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: this._capacity[i], maxHops: this._maxHops, deviceId: this.deviceId });
+                    this._handles[i] = native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: this._capacity[i], maxHops: this._maxHops, deviceId: this.deviceId, flags: this._flags });
                     native.timeCursor(this._handles[i], t);     // timeCursor survives a reallocation (phase-vocoder.js:31,71)
                 } else {
                     native.reset(this._handles[i], 0, this._capacity[i]);

@@ -103,7 +103,7 @@ def test_flag_constants_match_the_header():
     hdr = open(os.path.join(ROOT, "include", "phaze_amd.h")).read()
     vals = dict(re.findall(r"(PV_FLAG_[A-Z_]+)\s*=\s*(\d+)", hdr))
     assert vals == {"PV_FLAG_GENERIC_KERNEL": "1", "PV_FLAG_STREAM_COPY": "2", "PV_FLAG_WORKGROUP_KERNEL": "4", "PV_FLAG_STREAM_EVENT_WAIT": "8", "PV_FLAG_STREAM_PINNED_INPUT": "16",
-                    "PV_FLAG_ALL": "31"}
+                    "PV_FLAG_PERSISTENT_STREAM": "32", "PV_FLAG_ALL": "63"}
     import phaze_amd
     assert (phaze_amd.FLAG_GENERIC_KERNEL, phaze_amd.FLAG_STREAM_COPY, phaze_amd.FLAG_WORKGROUP_KERNEL, phaze_amd.FLAG_STREAM_EVENT_WAIT,
             phaze_amd.FLAG_STREAM_PINNED_INPUT) == (1, 2, 4, 8, 16)

@@ -52,12 +52,14 @@ def test_batch_matches_reference_golden(name):
     pv.close()
 
 
-@pytest.mark.parametrize("flags", [0, 16, 2 | 8], ids=["default", "pinned_input", "copy_nodes_event_wait"])
+@pytest.mark.parametrize("flags", [0, 16, 2 | 8, 32, 32 | 16], ids=["default", "pinned_input", "copy_nodes_event_wait", "resident", "resident_pinned_input"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_streaming_process_matches_reference_golden(name, flags):
     """process(inputs, outputs, parameters) one render quantum at a time, incl. pause / channel-change / a-rate -- in the default form (small
     quanta written by the host into device memory through the BAR, completion words), with PV_FLAG_STREAM_PINNED_INPUT (kernel reads the hop
-    from pinned host memory) and with PV_FLAG_STREAM_COPY | PV_FLAG_STREAM_EVENT_WAIT (copy nodes + stream wait: the round-1 form)."""
+    from pinned host memory), with PV_FLAG_STREAM_COPY | PV_FLAG_STREAM_EVENT_WAIT (copy nodes + stream wait: the round-1 form) and on the
+    resident kernel (PV_FLAG_PERSISTENT_STREAM; shapes it does not cover fall back to the launch form), handed its quanta through the BAR or
+    through pinned memory."""
     case = CASES[name]
     sig, pitch = _inputs(case)
     T, h = min(case["store_hops"], 24), case["hop"]

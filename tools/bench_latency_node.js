@@ -13,6 +13,9 @@
 const path = require("path");
 const { PhaseVocoderProcessor } = require(path.join(__dirname, "..", "phaze_amd", "node", "phase-vocoder.js"));
 const argv = process.argv.slice(2);
+const ri = argv.indexOf("--resident");
+const resident = ri >= 0;
+if (ri >= 0) argv.splice(ri, 1);
 const ki = argv.indexOf("--inputs");
 const extraInputs = ki >= 0 ? Number(argv[ki + 1]) : 0;
 if (ki >= 0) argv.splice(ki, 2);
@@ -25,6 +28,7 @@ function run(cfg) {
   const nin = cfg.inputs || 1;
   const opts = { numberOfInputs: nin, numberOfOutputs: nin };
   if (!(fft === 2048 && hop === 128)) opts.processorOptions = { fftSize: fft, hopSize: hop };     // native shape: the reference's own defaults
+  if (cfg.flags) opts.processorOptions = Object.assign(opts.processorOptions || {}, { flags: cfg.flags });
   const proc = new PhaseVocoderProcessor(opts);
   const L = 64, sig = [];
   for (let c = 0; c < nch; c++) { const nz = lcg(2000 + c, L * hop, 1 / 64), x = new Float32Array(L * hop); for (let i = 0; i < x.length; i++) x[i] = 0.25 * Math.sin(i * 0.031 * (c + 1)) + nz[i]; sig.push(x); }
@@ -61,11 +65,12 @@ function run(cfg) {
   const mean = a.reduce((s, v) => s + v, 0) / a.length, budget = hop / fs * 1e6;
   return { metric: "stream_call_latency_us", boundary: "PhaseVocoderProcessor.process (Node host -> N-API -> C ABI)", config: { workload: label, calls, kernel: info.kernelName },
            p50: q(50), p90: q(90), p99: q(99), max: a[a.length - 1], mean, realtime_budget_us: budget, budget_over_p99: budget / q(99),
-           histogram_us_edges: edges.concat(["inf"]).slice(0, edges.length).map(String), histogram_counts: hist, frames_per_s_streaming: nin * nch / (mean * 1e-6), inputs: nin, sequential_p50: seqP50, node: process.version };
+           histogram_us_edges: edges.concat(["inf"]).slice(0, edges.length).map(String), histogram_counts: hist, frames_per_s_streaming: nin * nch / (mean * 1e-6), inputs: nin, sequential_p50: seqP50, flags: cfg.flags | 0, node: process.version };
 }
 for (const cfg of [
   { fft: 8192, hop: 2048, nch: 8, fs: 96000, sweep: true, label: "BASELINE configs[4]: 8-ch 96 kHz FFT=8192 hop=2048, pitchFactor swept 0.5->2.0 per hop" },
   { fft: 2048, hop: 128, nch: 2, fs: 48000, sweep: false, label: "reference native shape: stereo 48 kHz FFT=2048 hop=128 (processor defaults), pitchFactor 1.5" },
   { fft: 1024, hop: 256, nch: 1, fs: 48000, sweep: false, label: "BASELINE configs[1] shape, streaming: mono 48 kHz FFT=1024 hop=256, pitchFactor 1.5" },
-].concat(extraInputs > 1 ? [{ fft: 2048, hop: 128, nch: 2, fs: 48000, sweep: false, inputs: extraInputs,
+].concat(resident ? [{ fft: 1024, hop: 256, nch: 1, fs: 48000, sweep: false, flags: 32, label: "BASELINE configs[1] shape, streaming on the RESIDENT kernel (PV_FLAG_PERSISTENT_STREAM): mono 48 kHz FFT=1024 hop=256, pitchFactor 1.5" },
+  { fft: 1024, hop: 256, nch: 2, fs: 48000, sweep: true, flags: 32, label: "stereo 48 kHz FFT=1024 hop=256 on the resident kernel, pitchFactor swept 0.5->2.0" }] : []).concat(extraInputs > 1 ? [{ fft: 2048, hop: 128, nch: 2, fs: 48000, sweep: false, inputs: extraInputs,
     label: `reference native shape with numberOfInputs = ${extraInputs}: ${extraInputs} x stereo 48 kHz FFT=2048 hop=128, pitchFactor 1.5` }] : [])) console.log(JSON.stringify(run(cfg)));
