@@ -220,7 +220,7 @@ int resident_start(pv_handle *h, unsigned last_seq)
     p.done = h->d_done; p.done_seq = last_seq;
     p.ctl = h->d_ctl;
     h->h_ctl[4] = 0u;
-    const hipError_t e = pv_launch_wave_resident(p, h->max_channels, h->stream);
+    const hipError_t e = h->use_wave2k ? pv_launch_wave2k_resident(p, h->max_channels, h->stream) : pv_launch_wave_resident(p, h->max_channels, h->stream);
     if (e != hipSuccess) return fail_hip(h, e, "resident kernel launch");
     h->resident_on = true;
     h->last_frames_per_chunk = 1;
@@ -380,7 +380,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         h->h_done = hd;
         if (hipHostGetDevicePointer(&dd, hd, 0) == hipSuccess) h->d_done = (unsigned *)dd;
         (void)hipGetLastError();
-        if (h->d_done && (cfg->flags & PV_FLAG_PERSISTENT_STREAM) && h->use_wave && maxch <= 64) {
+        if (h->d_done && (cfg->flags & PV_FLAG_PERSISTENT_STREAM) && (h->use_wave || h->use_wave2k) && maxch <= 64) {
             // Control block: in DEVICE memory when the host can write it through the BAR and the largest quantum is small enough to travel the same
             // way -- the waves then poll their own HBM and find the input there too, the only PCIe traffic of a quantum being posted writes in both
             // directions (tools/bar_probe.hip: 1 KB handed over and acknowledged in 3.5 us, 7.2 us with the block and the input in pinned host memory)

@@ -65,6 +65,7 @@ bool pv_wave_supported(int log2n, int hop);
 hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
 // resident form of the same kernel for streaming quanta (p.ctl != null): one wave per channel slot, nslots of them, polling p.ctl until ctl[4] (stop) or ~50 ms idle
 hipError_t pv_launch_wave_resident(const PvKernelParams &p, int nslots, hipStream_t st);
+hipError_t pv_launch_wave2k_resident(const PvKernelParams &p, int nslots, hipStream_t st);
 
 // one wavefront per 2048-point frame (pv_wave2k_kernel.hip): N = 2048, hop in {128, 256, 512, 1024, 2048}, every pitchFactor
 bool pv_wave2k_supported(int log2n, int hop);

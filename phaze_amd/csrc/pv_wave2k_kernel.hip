@@ -173,7 +173,7 @@ __device__ __forceinline__ int digitrev4_2k(int v, int nd)
 // stages with their predicated stores, bundle:329-441) -- and its sources, all owned by the last peak (pv:133), added into Y.  One wave, so
 // the stages are separated by wave_sync only; out of line so that its registers and its global loads stay out of the main loop.
 template <int R_>
-__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(const float *in, const float *hist, int hist_len, bool sys, long s0, const float *__restrict__ hann,
                                                                              const float2 *__restrict__ tw32, unsigned wave_off, int l, int upper_end, int up_delta,
                                                                              unsigned up_ridx, double *dbg_X)
 {
@@ -182,7 +182,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(cons
     float2 *Y = reinterpret_cast<float2 *>(smem_all + wave_off + O2_S);
     unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + O2_ROUTE);
     float2 *Q = reinterpret_cast<float2 *>(smem_all + wave_off + O2_RESQ);
-    const WaveSrc src{in, hist, hist_len};
+    const WaveSrc src{in, hist, hist_len, sys};
     for (int base = N / 2; base < N && base < upper_end; base += QN) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {                                      // QN / 2 = 256 radix-2 blocks per quarter; input index = base-4 digit reversal of the block
@@ -240,8 +240,9 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(cons
 // L ^ 32 -- every exchange there goes through LDS addresses, so relabelling the lanes costs nothing.
 // AUX = true: test-tap instance (pv_debug_frame: X / |X|^2 / peak flags / Y of one frame, incl. the above-Nyquist residue); the production
 // instance carries no tap code.
-template <int HOPQ, bool AUX>
-__global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kernel(const PvKernelParams p)
+// RESIDENT = true: streaming instance that stays on the GPU (PV_FLAG_PERSISTENT_STREAM; see pv_wave_kernel.hip): one wave per channel slot, 1 hop per quantum.
+template <int HOPQ, bool AUX, bool RESIDENT = false>
+__global__ __launch_bounds__(RESIDENT ? 128 : 64 * WAVES2, RESIDENT ? 1 : 2) PV_NO_DS_MERGE void pv_wave2k_kernel(const PvKernelParams p)   // (resident: 2-wave workgroups, one wave per SIMD, the whole register file)
 {
     constexpr int N = N2, M = M2, H = H2;
     constexpr bool HALF = (HOPQ == 1);
@@ -281,6 +282,34 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
     }
     __syncthreads();                                                     // the only workgroup-wide barrier
     if (ch >= p.nch) return;
+    // what changes from quantum to quantum in the resident form (constants of the launch otherwise)
+    const float *hist_in = p.hist_in, *acc_in = p.acc_in;
+    float *hist_out = p.hist_out, *acc_out = p.acc_out;
+    int t0_mod_n = p.t0_mod_n;
+    unsigned done_seq = p.done_seq;
+    unsigned last_seq = p.done_seq;                                      // resident: the last quantum completed before this launch
+resident_top:
+    if (RESIDENT) {
+        // the control word of pv_wave_kernel_1024's resident form: sequence number (16 bits, never 0) | channel count (7) | ping-pong half (1) | timeCursor / hop mod R (8)
+        unsigned word, idle = 0;
+        for (;;) {
+            word = __hip_atomic_load(p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((word & 0xFFFFu) != (last_seq & 0xFFFFu)) break;
+            if (__hip_atomic_load(p.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || ++idle > 60000u) return;   // asked to leave, or ~50 ms without work
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        const unsigned seq = word & 0xFFFFu, nch_now = (word >> 16) & 0x7Fu, cur = (word >> 23) & 1u;
+        t0_mod_n = (int)(((word >> 24) & 0xFFu) * HOP) & (N - 1);
+        hist_in = p.hist2[cur]; hist_out = p.hist2[cur ^ 1u];
+        acc_in = p.acc2[cur]; acc_out = p.acc2[cur ^ 1u];
+        done_seq = last_seq = seq;
+        if ((unsigned)ch >= nch_now) {                                   // a slot outside this quantum: carry its state across the ping-pong flip
+            if ((unsigned)ch < __hip_atomic_load(p.ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+                for (int j = lane; j < L; j += 64) { hist_out[(long)ch * L + j] = hist_in[(long)ch * L + j]; acc_out[(long)ch * L + j] = acc_in[(long)ch * L + j]; }
+            goto resident_top;
+        }
+    }
 
     const unsigned wave_off = T2_BYTES + wv * WAVE2_LDS;
     unsigned char *smem = smem_all + wave_off;
@@ -301,7 +330,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
     if (from_state) first_frame = 0;
 
     const long cbase = (long)ch * p.ch_stride;
-    const WaveSrc src{p.in + cbase, p.hist_in + (long)ch * L, L};
+    const WaveSrc src{p.in + cbase, hist_in + (long)ch * L, L, RESIDENT};
     float *outp = p.out + cbase;
     const bool vec_out = (reinterpret_cast<uintptr_t>(outp) & 15u) == 0;
     const bool vec_in = ((reinterpret_cast<uintptr_t>(src.in) | reinterpret_cast<uintptr_t>(src.hist)) & 15u) == 0;
@@ -326,15 +355,20 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
     if (from_state) {
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
-            const float *a = p.acc_in + (long)ch * L + 4 * lane + 256 * r;
+            const float *a = acc_in + (long)ch * L + 4 * lane + 256 * r;
             if (4 * lane + 256 * r < L) acc[r] = v4f{a[0], a[1], a[2], a[3]};
         }
     }
     // A frame that lies inside the input takes wave-uniform row bases plus ONE lane offset (no per-row 64-bit address arithmetic); only the first
     // R - 1 frames of a stream reach back into the carried history and pick a pointer per row.
+    auto ld_sys4 = [&](const float *q) -> v4f {                           // resident form: the host rewrites the hop between quanta of ONE launch: never from a cache
+        const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(q) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return v4f{__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32))};
+    };
     auto load_rows = [&](v4f *w, int frame) {
         const long s0u = (long)(frame + 1) * HOP - N;                       // wave-uniform
-        if (HALF && s0u >= 0 && vec_in) {                                   // (hop 128 only: -3 % there; at hop 512 the f < 1 path lost 3 % to the changed register allocation)
+        if (!RESIDENT && HALF && s0u >= 0 && vec_in) {                                   // (hop 128 only: -3 % there; at hop 512 the f < 1 path lost 3 % to the changed register allocation)
             const unsigned ob = 16u * (unsigned)lane;
 #pragma unroll
             for (int r = 0; r < 8; r++) w[r] = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(src.in + s0u + 256 * r) + ob);
@@ -344,14 +378,15 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
             for (int r = 0; r < 8; r++) {
                 const long sx = s0 + 256 * r;                               // a multiple of 4: the four samples never straddle history / input
                 const float *q = sx < 0 ? src.hist + sx + src.hist_len : src.in + sx;
-                if (vec_in) w[r] = *reinterpret_cast<const v4f *>(q);
+                if (RESIDENT && sx >= 0) w[r] = vec_in ? ld_sys4(q) : v4f{src.at(sx), src.at(sx + 1), src.at(sx + 2), src.at(sx + 3)};
+                else if (vec_in) w[r] = *reinterpret_cast<const v4f *>(q);
                 else w[r] = v4f{q[0], q[1], q[2], q[3]};
             }
         }
     };
     v4f raw[8];
     load_rows(raw, first_frame);
-    float pf_next = pitch_row[first_frame];
+    float pf_next = RESIDENT ? __hip_atomic_load(pitch_row + first_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : pitch_row[first_frame];
     int emit_v = first_out;
     asm volatile("" : "+v"(emit_v));
     v4f hw[8];
@@ -364,7 +399,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
         asm volatile("" : "+v"(l));                                       // LDS addresses are recomputed per frame instead of hoisted (see pv_wg_kernel.hip)
         const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));
         const double pf = (double)pfm;
-        const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
+        const int tmod = (int)(((long)t0_mod_n + (long)m * HOP) & (N - 1));
         const int pl = l + 4 * (l >> 4), ql = l + 4 * ((l + 15) >> 4);     // padded positions of the bins this lane's FFT registers hold (see P above)
         const int par = HALF ? ((m - first_frame) & 1) : 0;                // accumulator layout of this frame (wave-uniform)
         const int li = l ^ (par << 5);                                    // lane id of the synthesis side
@@ -665,7 +700,7 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
                     }
                     claim_rounds2<4>(rt2, ys2, id2, Y, CLAIM);
                 } else {
-                    residue_scatter_2k<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, wave_off, l, upper_end, up_delta, up_ridx,
+                    residue_scatter_2k<R>(src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw32, wave_off, l, upper_end, up_delta, up_ridx,
                                           dbg ? p.dbg_X : nullptr);
                 }
             }
@@ -776,18 +811,19 @@ __global__ __launch_bounds__(64 * WAVES2, 2) PV_NO_DS_MERGE void pv_wave2k_kerne
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
             if (4 * lend + 256 * r < L) {
-                float *a = p.acc_out + (long)ch * L + 4 * lend + 256 * r;
+                float *a = acc_out + (long)ch * L + 4 * lend + 256 * r;
                 a[0] = acc[r].x; a[1] = acc[r].y; a[2] = acc[r].z; a[3] = acc[r].w;
             }
             if (4 * lane + 256 * r < L) {
-                float *hs = p.hist_out + (long)ch * L + 4 * lane + 256 * r;
+                float *hs = hist_out + (long)ch * L + 4 * lane + 256 * r;
                 const long s = (long)p.nhops * HOP - L + 4 * lane + 256 * r;
 #pragma unroll
                 for (int i = 0; i < 4; i++) hs[i] = src.at(s + i);
             }
         }
     }
-    pv_signal_done<false>(p.done, p.done_seq, chain);
+    pv_signal_done<false>(p.done, done_seq, chain);
+    if (RESIDENT) goto resident_top;
 }
 
 #ifndef PV_W2K_WMIN
@@ -819,7 +855,35 @@ hipError_t launch2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t s
     return hipGetLastError();
 }
 
+template <int HOPQ>
+hipError_t launch2k_resident(const PvKernelParams &p, int nslots, hipStream_t st)
+{
+    static std::atomic<bool> attr_done[16];
+    auto k = pv_wave2k_kernel<HOPQ, false, true>;
+    {
+        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_wave2k_lds_bytes());
+        if (e != hipSuccess) return e;
+    }
+    PvKernelParams q = p;
+    q.nchunks = 1; q.nch = nslots; q.nhops = 1; q.frames_per_chunk = 1;
+    constexpr int w = 2;                                                   // two channel slots per workgroup: the slots spread over the CUs
+    hipLaunchKernelGGL(k, dim3((unsigned)((nslots + w - 1) / w), 1, 1), dim3(64 * w, 1, 1), T2_BYTES + (size_t)w * WAVE2_LDS, st, q);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+hipError_t pv_launch_wave2k_resident(const PvKernelParams &p, int nslots, hipStream_t st)
+{
+    switch (p.hop) {
+    case 128: return launch2k_resident<1>(p, nslots, st);
+    case 256: return launch2k_resident<2>(p, nslots, st);
+    case 512: return launch2k_resident<4>(p, nslots, st);
+    case 1024: return launch2k_resident<8>(p, nslots, st);
+    case 2048: return launch2k_resident<16>(p, nslots, st);
+    default: return hipErrorInvalidValue;
+    }
+}
 
 size_t pv_wave2k_lds_bytes() { return T2_BYTES + WAVES2 * WAVE2_LDS; }
 int pv_wave2k_threads() { return 64 * WAVES2; }
