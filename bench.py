@@ -18,7 +18,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   "cpu_baseline": the CPU oracle (a C port of the reference JS, kind "port") timed on ONE host core on a bounded sample of the same
                   workload, plus the estimate for the reference's own Node.js path (ratio measured by tools/time_reference.js)
   "configs":      one short measured line per other BASELINE config (C3, a C4 share, C5 with its pitch sweep, the 8-channel form of the
-                  headline shape) and "latency_us": the streaming-quantum histogram of C5 -- N = 1 only, skipped with --no-extras
+                  headline shape) and "latency_us": the streaming-quantum histogram of C5, "latency_us_headline_shape": mono 1024/256 per quantum (launch form / resident kernel) -- N = 1 only, skipped with --no-extras
 """
 import argparse
 import hashlib
@@ -274,12 +274,12 @@ def measure_time_shard(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_valu
             "alg_bytes": nch * (hi - lo) * 2 * hop * 4, "achieved_gbs": nch * (hi - lo) * 2 * hop * 4 / (kernel_ms * 1e-3) / 1e9}
 
 
-def latency_histogram(phaze_amd, fft, hop, nch, calls, local_rank, sweep):
+def latency_histogram(phaze_amd, fft, hop, nch, calls, local_rank, sweep, flags=0, fs=96000.0):
     """Streaming form (one render quantum per call): per-call wall latency of pv_process through the C ABI."""
     import ctypes as C
     import numpy as np
     import signals as S
-    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, device_id=local_rank)
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, device_id=local_rank, flags=flags)
     L = pv._L
     x = np.stack([S.make_signal("tonal", c, 64 * hop) for c in range(nch)])
     fpt = C.POINTER(C.c_float)
@@ -298,8 +298,9 @@ def latency_histogram(phaze_amd, fft, hop, nch, calls, local_rank, sweep):
             lat[m - 30] = (t1 - t0) * 1e-3
     pv.close()
     return {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max()), "calls": calls,
-            "form": f"pv_process through the C ABI (ctypes), {nch}-ch {fft}/{hop} @ 96 kHz, pitchFactor swept per hop, one hop per call "
-                    "(launch + stream sync, zero-copy pinned staging)", "realtime_budget_us": hop / 96000.0 * 1e6}
+            "form": f"pv_process through the C ABI (ctypes), {nch}-ch {fft}/{hop} @ {fs / 1000:g} kHz, pitchFactor " + ("swept per hop" if sweep else "1.5") + ", one hop per call "
+                    + ("(resident kernel, PV_FLAG_PERSISTENT_STREAM: quantum handed over through the BAR, no launch)" if flags & 32 else
+                       "(one launch per quantum, completion words in pinned memory)"), "realtime_budget_us": hop / fs * 1e6}
 
 
 def spawn_ranks(args, n):
@@ -507,6 +508,9 @@ def main():
             1024, 256, 1, T2, sw, steps=12, warm=4)
         out["configs"] = extras
         out["latency_us"] = latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True)
+        # the headline shape as a stream: launch per quantum, and on the resident kernel (opt-in flag of the C ABI / `processorOptions.flags` in Node)
+        out["latency_us_headline_shape"] = {"launch": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, fs=48000.0),
+                                            "resident": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, flags=32, fs=48000.0)}
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
