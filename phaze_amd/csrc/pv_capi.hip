@@ -43,6 +43,7 @@ struct pv_handle {
     float *d_quantum;                            // device twin of h_pin
     float *d_pin_mapped;                         // device view of h_pin (zero-copy streaming quantum); null = stage through d_quantum
     bool bar_input;                              // large-BAR device: the host writes small quanta straight into d_quantum (PV_FLAG_STREAM_PINNED_INPUT: off)
+    volatile unsigned *hdp_flush;                // HDP_MEM_COHERENCY_FLUSH_CNTL of the device, mapped by the runtime (null: not exposed): written after host stores through the BAR
     volatile unsigned *h_done;                   // pinned: completion word of every frame chain of a streaming quantum (PvKernelParams::done)
     unsigned *d_done;                            // device view of h_done; null = wait through hipStreamSynchronize
     unsigned quantum_seq;                        // sequence number the chains of the pending quantum store (never 0)
@@ -370,6 +371,13 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         int large_bar = 0;
         if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) != hipSuccess) { large_bar = 0; (void)hipGetLastError(); }
         h->bar_input = large_bar == 1 && h->d_pin_mapped != nullptr && !(cfg->flags & PV_FLAG_STREAM_PINNED_INPUT);
+        if (h->bar_input) {
+            // Host stores through the BAR pass the device's HDP block; the runtime maps its flush register for exactly this use (the attribute call
+            // stores a POINTER through its int* argument).  One more posted write per quantum, behind the data in PCIe order.
+            unsigned *reg = nullptr;
+            if (hipDeviceGetAttribute(reinterpret_cast<int *>(&reg), hipDeviceAttributeHdpMemFlushCntl, h->device) == hipSuccess) h->hdp_flush = reg;
+            (void)hipGetLastError();
+        }
     }
     if (h->d_pin_mapped && !(cfg->flags & PV_FLAG_STREAM_EVENT_WAIT)) {
         // completion words of the streaming quantum, one per channel slot, in pinned host memory the kernels store to
@@ -581,6 +589,7 @@ int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t 
 #if defined(__x86_64__)
     if (bar) _mm_sfence();                                                       // write-combining buffers drained before the doorbell
 #endif
+    if (bar && h->hdp_flush) *h->hdp_flush = 1u;                                 // ... and the device's host data path flushed behind them
     auto launch = [&]() -> int {
         if (h->d_pin_mapped && h->h_ctl) {
             // resident kernel: no launch -- start the waves if none are there (first quantum, or they left after their idle time-out), then publish the
@@ -605,6 +614,7 @@ int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t 
 #if defined(__x86_64__)
             _mm_sfence();                                                    // (through the BAR: out of the write-combining buffer now, not when it fills)
 #endif
+            if (h->resident_bar && h->hdp_flush) *h->hdp_flush = 1u;
             h->cur ^= 1;                                                     // what run_chain() commits for a launched quantum
             h->time_cursor += hop;
             return PV_OK;
