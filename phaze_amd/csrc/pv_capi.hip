@@ -49,7 +49,10 @@ struct pv_handle {
     unsigned quantum_seq;                        // sequence number the chains of the pending quantum store (never 0)
     volatile unsigned *h_ctl;                    // pinned control block of the resident streaming kernel {seq, nch, t0 mod N, cur, stop, slots in use}; null = not used
     unsigned *d_ctl;
-    bool resident_bar;                           // the resident kernel's control block and input live in DEVICE memory, written by the host through the BAR
+    bool resident_bar;                           // the resident kernel's control block lives in DEVICE memory, written by the host through the BAR
+    bool resident_in_bar;                        // ... and so does its input (largest quantum <= 16 KB; otherwise the waves read it from pinned host memory)
+    bool resident_wg;                            // the resident kernel is pv_wg_kernel: one control word per channel slot (ctl[16 + c]), channels handed over one by one
+    bool copied[64];                             // pv_process_end: channels whose output has been copied out already
     bool resident_on;                            // a resident kernel has been launched on the stream and not been stopped since
     std::chrono::steady_clock::time_point last_quantum;   // ... and when it was last given work (its waves leave after ~50 ms without)
     double *d_dbgX; float *d_dbgMag; int *d_dbgFlags; float *d_dbgY;
@@ -210,7 +213,7 @@ int resident_start(pv_handle *h, unsigned last_seq)
     PvKernelParams p;
     memset(&p, 0, sizeof p);
     const int hop = h->hop;
-    float *stage = h->resident_bar ? h->d_quantum : h->d_pin_mapped;         // where the host puts pitchFactor + input (see pv_process_begin)
+    float *stage = h->resident_in_bar ? h->d_quantum : h->d_pin_mapped;      // where the host puts pitchFactor + input (see pv_process_begin)
     p.in = stage + kHdrFloats; p.out = h->d_pin_mapped + kHdrFloats + (size_t)h->max_channels * hop; p.ch_stride = hop;
     p.nhops = 1; p.hop = hop; p.frames_per_chunk = 1;
     p.pitch = stage; p.pitch_stride = 0; p.ch_per_stream = 1;
@@ -220,8 +223,10 @@ int resident_start(pv_handle *h, unsigned last_seq)
     p.dbg_ch = -1; p.dbg_frame = -1;
     p.done = h->d_done; p.done_seq = last_seq;
     p.ctl = h->d_ctl;
+    p.in_cached = h->resident_in_bar ? 1 : 0;
     h->h_ctl[4] = 0u;
-    const hipError_t e = h->use_wave2k ? pv_launch_wave2k_resident(p, h->max_channels, h->stream) : pv_launch_wave_resident(p, h->max_channels, h->stream);
+    const hipError_t e = h->resident_wg ? pv_launch_wg_resident(h->log2n, p, h->max_channels, h->stream)
+                       : h->use_wave2k ? pv_launch_wave2k_resident(p, h->max_channels, h->stream) : pv_launch_wave_resident(p, h->max_channels, h->stream);
     if (e != hipSuccess) return fail_hip(h, e, "resident kernel launch");
     h->resident_on = true;
     h->last_frames_per_chunk = 1;
@@ -388,22 +393,26 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         h->h_done = hd;
         if (hipHostGetDevicePointer(&dd, hd, 0) == hipSuccess) h->d_done = (unsigned *)dd;
         (void)hipGetLastError();
-        if (h->d_done && (cfg->flags & PV_FLAG_PERSISTENT_STREAM) && (h->use_wave || h->use_wave2k) && maxch <= 64) {
+        if (h->d_done && (cfg->flags & PV_FLAG_PERSISTENT_STREAM) && maxch <= 64 &&
+            (h->use_wave || h->use_wave2k || (h->use_wg && !h->use_pair && pv_wg_resident_supported(log2n, hop)))) {
             // Control block: in DEVICE memory when the host can write it through the BAR and the largest quantum is small enough to travel the same
             // way -- the waves then poll their own HBM and find the input there too, the only PCIe traffic of a quantum being posted writes in both
             // directions (tools/bar_probe.hip: 1 KB handed over and acknowledged in 3.5 us, 7.2 us with the block and the input in pinned host memory)
-            h->resident_bar = h->bar_input && sizeof(float) * (size_t)maxch * hop <= 16384;
+            h->resident_wg = !(h->use_wave || h->use_wave2k);
+            h->resident_bar = h->bar_input;
+            h->resident_in_bar = h->bar_input && sizeof(float) * (size_t)maxch * hop <= 16384;
+            constexpr size_t kCtlBytes = sizeof(unsigned) * (16 + 64);       // {seq word, -, -, -, stop, slots in use, ...} + one word per channel slot (resident_wg)
             if (h->resident_bar) {
                 void *dc = nullptr;
-                CHK(hipMalloc(&dc, 64));
-                CHK(hipMemset(dc, 0, 64));
+                CHK(hipMalloc(&dc, kCtlBytes));
+                CHK(hipMemset(dc, 0, kCtlBytes));
                 h->d_ctl = (unsigned *)dc;
                 h->h_ctl = (volatile unsigned *)dc;                          // (written, never read, by the host)
             } else {
                 unsigned *hc = nullptr;
                 void *dc = nullptr;
-                CHK(hipHostMalloc((void **)&hc, 64, hipHostMallocMapped));
-                memset(hc, 0, 64);
+                CHK(hipHostMalloc((void **)&hc, kCtlBytes, hipHostMallocMapped));
+                memset(hc, 0, kCtlBytes);
                 h->h_ctl = hc;
                 if (hipHostGetDevicePointer(&dc, hc, 0) == hipSuccess) h->d_ctl = (unsigned *)dc; else h->h_ctl = nullptr;
                 (void)hipGetLastError();
@@ -578,14 +587,16 @@ int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t 
     // Above kBarInputMax the BAR write itself (~1.4 GB/s from one core) costs more than the waves' parallel reads.  The previous quantum's kernel
     // has finished (pv_process_end) before this buffer is written again.
     constexpr size_t kBarInputMax = 16384;
-    const bool bar = h->h_ctl ? h->resident_bar : (h->bar_input && sizeof(float) * (size_t)nch * hop <= kBarInputMax);   // (a resident kernel's pointers are fixed)
+    const bool bar = h->h_ctl ? h->resident_in_bar : (h->bar_input && sizeof(float) * (size_t)nch * hop <= kBarInputMax);   // (a resident kernel's pointers are fixed)
     float *stage = bar ? h->d_quantum : h->h_pin;
     float *pin_in = stage + kHdrFloats;
     stage[0] = pitch_factor;
-    for (int c = 0; c < nch; c++) {
+    auto stage_channel = [&](int c) {
         if (paused || !in[c]) memset(pin_in + (size_t)c * hop, 0, sizeof(float) * hop);
         else memcpy(pin_in + (size_t)c * hop, in[c], sizeof(float) * hop);       // host block is only valid during the call (ola:64)
-    }
+    };
+    const bool piecewise = h->h_ctl && h->resident_wg && h->d_pin_mapped;       // resident workgroup kernel: every channel is handed over as soon as it is staged
+    if (!piecewise) for (int c = 0; c < nch; c++) stage_channel(c);
 #if defined(__x86_64__)
     if (bar) _mm_sfence();                                                       // write-combining buffers drained before the doorbell
 #endif
@@ -605,16 +616,27 @@ int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t 
             if (seq == 0) seq = 1;
             h->quantum_seq = seq;
             if (nch > h->used_channels) h->used_channels = nch;
-            h->h_ctl[5] = (unsigned)h->used_channels;
-            std::atomic_thread_fence(std::memory_order_seq_cst);            // inputs, pitch and parameters are in memory before the waves see the word
+            const unsigned common = seq | ((unsigned)h->cur << 23) | ((unsigned)((h->time_cursor / hop) % h->R) << 24);
+            auto publish = [&](volatile unsigned *word, unsigned value) {
+                std::atomic_thread_fence(std::memory_order_seq_cst);        // inputs, pitch and parameters are in memory before the waves see the word
 #if defined(__x86_64__)
-            _mm_sfence();
+                _mm_sfence();
 #endif
-            h->h_ctl[0] = seq | ((unsigned)nch << 16) | ((unsigned)h->cur << 23) | ((unsigned)((h->time_cursor / hop) % h->R) << 24);
+                *word = value;
 #if defined(__x86_64__)
-            _mm_sfence();                                                    // (through the BAR: out of the write-combining buffer now, not when it fills)
+                _mm_sfence();                                                // (through the BAR: out of the write-combining buffer now, not when it fills)
 #endif
-            if (h->resident_bar && h->hdp_flush) *h->hdp_flush = 1u;
+                if (h->resident_bar && h->hdp_flush) *h->hdp_flush = 1u;
+            };
+            if (piecewise) {
+                // one word per channel slot: the workgroup of channel 0 is on its frame while the host still copies channel 1's input, and so on
+                // (pv_process_end collects the outputs in the same order).  Slots that hold state but are not in this quantum carry it (count 0).
+                for (int c = 0; c < nch; c++) { stage_channel(c); publish(h->h_ctl + 16 + c, common | (1u << 16)); h->copied[c] = false; }
+                for (int c = nch; c < h->used_channels; c++) publish(h->h_ctl + 16 + c, common);
+            } else {
+                h->h_ctl[5] = (unsigned)h->used_channels;
+                publish(h->h_ctl, common | ((unsigned)nch << 16));
+            }
             h->cur ^= 1;                                                     // what run_chain() commits for a launched quantum
             h->time_cursor += hop;
             return PV_OK;
@@ -658,9 +680,17 @@ int pv_process_end(pv_handle *h, float *const *out)
         // Bounded: after 200 ms without completion the stream wait below reports whatever went wrong.
         const unsigned seq = h->quantum_seq;
         const auto t0 = std::chrono::steady_clock::now();
+        int c = 0;                                                                // channels are collected in order, each copied out as soon as it is complete
+        for (int k = 0; k < nch && k < 64; k++) h->copied[k] = false;
         for (unsigned spins = 0;; spins++) {
-            int c = 0;
-            while (c < nch && h->h_done[c] == seq) c++;
+            while (c < nch && h->h_done[c] == seq) {
+                if (c < 64) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    if (out[c]) memcpy(out[c], pin_out + (size_t)c * hop, sizeof(float) * hop);
+                    h->copied[c] = true;
+                }
+                c++;
+            }
             if (c == nch) { done = true; break; }
 #if defined(__x86_64__)
             _mm_pause();
@@ -689,7 +719,7 @@ int pv_process_end(pv_handle *h, float *const *out)
         return fail_hip(h, e, "pv_process_end: stream synchronize");
     }
     for (int c = 0; c < nch; c++)
-        if (out[c]) memcpy(out[c], pin_out + (size_t)c * hop, sizeof(float) * hop);
+        if (out[c] && !(done && c < 64 && h->copied[c])) memcpy(out[c], pin_out + (size_t)c * hop, sizeof(float) * hop);
     return PV_OK;                                                                // ola-processor.js:170: return true
 }
 

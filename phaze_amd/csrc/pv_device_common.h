@@ -84,7 +84,7 @@ struct WaveSrc {
     const float *in;
     const float *hist;
     int hist_len;
-    bool sys = false;      // resident streaming kernel: `in` is pinned host memory the host rewrites between quanta WITHIN one launch -> system-scope loads
+    bool sys = false;      // resident streaming kernel with its input in DEVICE memory (cached in L2) that the host rewrites through the BAR between quanta WITHIN one launch -> system-scope loads
     __device__ __forceinline__ float at(long s) const
     {
         if (s < 0) return hist[s + hist_len];

@@ -38,6 +38,8 @@ struct PvKernelParams {
     // next sequence number.  ctl = {seq, nch, t0_mod_n, cur, stop}; state2[] = both halves of the state ping-pong (cur selects hist_in / acc_in).
     const unsigned *ctl;
     float *hist2[2], *acc2[2];
+    int in_cached;            // resident form: `in` / `pitch` are DEVICE memory the host rewrites through the BAR (cached in L2: system-scope loads);
+                              // 0 = pinned host memory (uncached on the device: plain, coalesced loads behind the acquire fence of the poll)
     unsigned *stamps;         // measurement builds only (-DPV_STAMPS, tools/exp_headline.sh): [chain][16] accumulated s_memtime deltas per phase
 };
 
@@ -66,6 +68,8 @@ hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStre
 // resident form of the same kernel for streaming quanta (p.ctl != null): one wave per channel slot, nslots of them, polling p.ctl until ctl[4] (stop) or ~50 ms idle
 hipError_t pv_launch_wave_resident(const PvKernelParams &p, int nslots, hipStream_t st);
 hipError_t pv_launch_wave2k_resident(const PvKernelParams &p, int nslots, hipStream_t st);
+bool pv_wg_resident_supported(int log2n, int hop);
+hipError_t pv_launch_wg_resident(int log2n, const PvKernelParams &p, int nslots, hipStream_t st);
 
 // one wavefront per 2048-point frame (pv_wave2k_kernel.hip): N = 2048, hop in {128, 256, 512, 1024, 2048}, every pitchFactor
 bool pv_wave2k_supported(int log2n, int hop);

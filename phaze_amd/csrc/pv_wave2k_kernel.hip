@@ -330,7 +330,7 @@ resident_top:
     if (from_state) first_frame = 0;
 
     const long cbase = (long)ch * p.ch_stride;
-    const WaveSrc src{p.in + cbase, hist_in + (long)ch * L, L, RESIDENT};
+    const WaveSrc src{p.in + cbase, hist_in + (long)ch * L, L, RESIDENT && p.in_cached != 0};
     float *outp = p.out + cbase;
     const bool vec_out = (reinterpret_cast<uintptr_t>(outp) & 15u) == 0;
     const bool vec_in = ((reinterpret_cast<uintptr_t>(src.in) | reinterpret_cast<uintptr_t>(src.hist)) & 15u) == 0;
@@ -368,7 +368,7 @@ resident_top:
     };
     auto load_rows = [&](v4f *w, int frame) {
         const long s0u = (long)(frame + 1) * HOP - N;                       // wave-uniform
-        if (!RESIDENT && HALF && s0u >= 0 && vec_in) {                                   // (hop 128 only: -3 % there; at hop 512 the f < 1 path lost 3 % to the changed register allocation)
+        if (!(RESIDENT && src.sys) && HALF && s0u >= 0 && vec_in) {                                   // (hop 128 only: -3 % there; at hop 512 the f < 1 path lost 3 % to the changed register allocation)
             const unsigned ob = 16u * (unsigned)lane;
 #pragma unroll
             for (int r = 0; r < 8; r++) w[r] = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(src.in + s0u + 256 * r) + ob);
@@ -378,7 +378,7 @@ resident_top:
             for (int r = 0; r < 8; r++) {
                 const long sx = s0 + 256 * r;                               // a multiple of 4: the four samples never straddle history / input
                 const float *q = sx < 0 ? src.hist + sx + src.hist_len : src.in + sx;
-                if (RESIDENT && sx >= 0) w[r] = vec_in ? ld_sys4(q) : v4f{src.at(sx), src.at(sx + 1), src.at(sx + 2), src.at(sx + 3)};
+                if (RESIDENT && src.sys && sx >= 0) w[r] = vec_in ? ld_sys4(q) : v4f{src.at(sx), src.at(sx + 1), src.at(sx + 2), src.at(sx + 3)};
                 else if (vec_in) w[r] = *reinterpret_cast<const v4f *>(q);
                 else w[r] = v4f{q[0], q[1], q[2], q[3]};
             }
@@ -386,7 +386,7 @@ resident_top:
     };
     v4f raw[8];
     load_rows(raw, first_frame);
-    float pf_next = RESIDENT ? __hip_atomic_load(pitch_row + first_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : pitch_row[first_frame];
+    float pf_next = (RESIDENT && src.sys) ? __hip_atomic_load(pitch_row + first_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : pitch_row[first_frame];
     int emit_v = first_out;
     asm volatile("" : "+v"(emit_v));
     v4f hw[8];

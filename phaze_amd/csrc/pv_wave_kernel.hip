@@ -545,7 +545,7 @@ resident_top:
     if (from_state) first_frame = 0;
 
     const long cbase = (long)ch * p.ch_stride;
-    const WaveSrc src{p.in + cbase, hist_in + (long)ch * (N - HOP), N - HOP, RESIDENT};
+    const WaveSrc src{p.in + cbase, hist_in + (long)ch * (N - HOP), N - HOP, RESIDENT && p.in_cached != 0};
     float *outp = p.out + cbase;
     const bool vec_out = (reinterpret_cast<uintptr_t>(outp) & 7u) == 0;           // 8-byte aligned channel base: float2 stores
     const bool vec_in = ((reinterpret_cast<uintptr_t>(src.in) | reinterpret_cast<uintptr_t>(src.hist)) & 7u) == 0;
@@ -577,7 +577,7 @@ resident_top:
 #pragma unroll
         for (int r = 0; r < nrows; r++) {
             const long sx = s0 + 128 * (first_row + r);
-            if (RESIDENT && vec_in && sx >= 0) {                           // the host's hop of this quantum: never from a cache
+            if (RESIDENT && src.sys && vec_in && sx >= 0) {                // the host's hop of this quantum: never from a cache
                 const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src.in + sx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 w[r] = float2{__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32))};
             } else if (vec_in) w[r] = *reinterpret_cast<const float2 *>(sx < 0 ? src.hist + sx + src.hist_len : src.in + sx);
@@ -591,7 +591,7 @@ resident_top:
     // s_waitcnt vmcnt(#stores) at the top of the next frame.  A load in mid-frame (the pitch row used to be read where it was needed) or a
     // wave-uniform branch around the stores makes the compiler wait with vmcnt(0) -- for the prefetch it has just issued and for the
     // acknowledgement of the stores -- and every frame of every wave then sits out two exposed HBM round trips.
-    float pf_next = RESIDENT ? __hip_atomic_load(pitch_row + first_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : pitch_row[first_frame];
+    float pf_next = (RESIDENT && src.sys) ? __hip_atomic_load(pitch_row + first_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : pitch_row[first_frame];
     int emit_v = first_out;
     asm volatile("" : "+v"(emit_v));                                     // opaque VGPR copy of first_out: keeps the store predicate divergent
     // 0.5 * Hann rows of this lane: read at the END of a frame (4 ds_read_b128) for the synthesis window and kept across the loop edge for
@@ -1016,9 +1016,15 @@ resident_top:
         for (int r = 0; r < LROWS; r++) {
             float *a = acc_out + (long)ch * (N - HOP) + 2 * l + 128 * r;
             a[0] = acc[r].x; a[1] = acc[r].y;
+            // the history of the next call = the last N - hop samples of the stream = rows S_ROWS..7 of the last frame's window, which the slide has
+            // left in raw[0 .. 8 - S_ROWS): stored from registers (re-reading them costs a streaming quantum an exposed memory -- or PCIe -- round trip)
             float *hs = hist_out + (long)ch * (N - HOP) + 2 * l + 128 * r;
+#ifdef PV_RELOAD_ROWS
             const long s = (long)p.nhops * HOP - (N - HOP) + 2 * l + 128 * r;
             hs[0] = src.at(s); hs[1] = src.at(s + 1);
+#else
+            hs[0] = raw[r].x; hs[1] = raw[r].y;
+#endif
         }
     }
     pv_signal_done<false>(p.done, done_seq, chain);

@@ -23,6 +23,11 @@
 #include "pv_kernels.h"
 #include "pv_device_common.h"
 #include "pv_pk_math.h"
+#ifdef PV_WG_STAMPS   // measurement build (make variant ... EXTRA=-DPV_WG_STAMPS CAPI_EXTRA=-DPV_STAMPS=1): s_memtime at the stations of a 1-hop launch, workgroup (0, ch)
+#define WG_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && p.stamps) p.stamps[16 * blockIdx.y + (i)] = (unsigned)t_; } while (0)
+#else
+#define WG_STAMP(i)
+#endif
 #ifndef PV_PAIRWISE
 #define PV_PAIRWISE 1                               // 0: every f < 1 frame goes through the claim rounds (A/B)
 #endif
@@ -290,7 +295,7 @@ __device__ __forceinline__ int digitrev4_(int v, int nd)
 // Rare path: above-Nyquist residue of fft.js's in-place real DIT, one quarter of the buffer at a time, then its sources
 // are added into Y.  Same structure as residue_scatter_1024, any LOG2N (radix-2 base stage when log2 N is odd: bundle:447-463).
 template <int LOG2N, int R_>
-__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(const float *in, const float *hist, int hist_len, bool sys, long s0, const float *__restrict__ hann,
                                                              const float2 *__restrict__ tw32, int t, int upper_end, int up_delta, unsigned up_ridx,
                                                              double *dbg_X, bool plain)
 {
@@ -304,7 +309,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(cons
     float2 *Y = reinterpret_cast<float2 *>(smem + C::OFF_Y);
     unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);             // aliases ROUTE once the routes are in registers (f < 1)
     float2 *Q = reinterpret_cast<float2 *>(smem + C::OFF_RESQ);
-    const WaveSrc src{in, hist, hist_len};
+    const WaveSrc src{in, hist, hist_len, sys};
     for (int base = N / 2; base < N && base < upper_end; base += QN) {
         if (BASE4) {
             constexpr int nd = (LOG2N - 2) / 2;
@@ -376,7 +381,10 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(cons
     }
 }
 
-template <int LOG2N, int S_ROWS, bool AUX>
+// RESIDENT = true (register-resident overlap-add only, S_ROWS >= 1): streaming instance that stays on the GPU (PV_FLAG_PERSISTENT_STREAM).  One workgroup per channel
+// slot; each polls ITS OWN control word ctl[16 + ch] (same packing as the one-wave kernels' ctl[0]; channel count 0 = "carry your state, you are not in this quantum"),
+// so that the host can hand the channels over one by one while it is still copying the next one's input (pv_capi.hip).
+template <int LOG2N, int S_ROWS, bool AUX, bool RESIDENT = false>
 __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_kernel(const PvKernelParams p)
 {
     constexpr int G = 1 << (LOG2N - 10);
@@ -409,6 +417,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     double2 *TWB = reinterpret_cast<double2 *>(smem + C::OFF_TWB);
     double2 *TWC = reinterpret_cast<double2 *>(smem + C::OFF_TWC);
 
+    WG_STAMP(0);
     // ---- tables: W_M^{t k} = tw[2 t k], W_T^{q k} = tw[16 q k], W_{8G}^{q k} = tw[128 q k]  (tw[i] = exp(-2 pi j i / N)) ----
 #pragma unroll
     for (int k = 1; k < 8; k++) {
@@ -418,6 +427,43 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     for (int i = t; i < 7 * 8 * G; i += T) TWB[i] = p.tw64[(16 * (i % (8 * G)) * (i / (8 * G) + 1)) & (N - 1)];
     for (int i = t; i < 7 * G; i += T) TWC[i] = p.tw64[(128 * (i % G) * (i / G + 1)) & (N - 1)];
 
+    WG_STAMP(1);
+    unsigned psh_key = 0u;                                 // bit pattern of the f the shift table was built for, valid once psh_valid
+    bool psh_valid = false;
+    // what changes from quantum to quantum in the resident form (constants of the launch otherwise)
+    const float *hist_in = p.hist_in, *acc_in = p.acc_in;
+    float *hist_out = p.hist_out, *acc_out = p.acc_out;
+    int t0_mod_n = p.t0_mod_n;
+    unsigned done_seq = p.done_seq;
+    unsigned last_seq = p.done_seq;
+resident_top:
+    if (RESIDENT) {
+        unsigned *BC = reinterpret_cast<unsigned *>(smem + C::OFF_OCC);  // broadcast slot (the peak search's wave masks: not live here)
+        if (t == 0) {
+            unsigned word, idle = 0;
+            for (;;) {
+                word = __hip_atomic_load(p.ctl + 16 + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((word & 0xFFFFu) != (last_seq & 0xFFFFu)) break;
+                if (__hip_atomic_load(p.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || ++idle > 60000u) { word = 0u; break; }   // asked to leave / ~50 ms idle
+                __builtin_amdgcn_s_sleep(2);
+            }
+            BC[0] = word;
+        }
+        __syncthreads();
+        const unsigned word = BC[0];
+        __syncthreads();
+        if (word == 0u) return;                                          // (a sequence number is never 0)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        const unsigned seq = word & 0xFFFFu, nch_now = (word >> 16) & 0x7Fu, cur = (word >> 23) & 1u;
+        t0_mod_n = (int)(((word >> 24) & 0xFFu) * HOP) & (N - 1);
+        hist_in = p.hist2[cur]; hist_out = p.hist2[cur ^ 1u];
+        acc_in = p.acc2[cur]; acc_out = p.acc2[cur ^ 1u];
+        done_seq = last_seq = seq;
+        if (nch_now == 0u) {                                             // not part of this quantum: carry the state across the ping-pong flip
+            for (int j = t; j < N - HOP; j += T) { hist_out[(long)ch * (N - HOP) + j] = hist_in[(long)ch * (N - HOP) + j]; acc_out[(long)ch * (N - HOP) + j] = acc_in[(long)ch * (N - HOP) + j]; }
+            goto resident_top;
+        }
+    }
     const int first_out = chunk * p.frames_per_chunk;
     int last_out = first_out + p.frames_per_chunk;
     if (last_out > p.nhops) last_out = p.nhops;
@@ -426,7 +472,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     if (from_state) first_frame = 0;
 
     const long cbase = (long)ch * p.ch_stride;
-    const WaveSrc src{p.in + cbase, p.hist_in + (long)ch * (N - HOP), N - HOP};
+    const WaveSrc src{p.in + cbase, hist_in + (long)ch * (N - HOP), N - HOP, RESIDENT && p.in_cached != 0};
     float *outp = p.out + cbase;
     const bool vec_out = (reinterpret_cast<uintptr_t>(outp) & 7u) == 0;
     const bool vec_in = ((reinterpret_cast<uintptr_t>(src.in) | reinterpret_cast<uintptr_t>(src.hist)) & 7u) == 0;
@@ -435,8 +481,6 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     float *ACC = reinterpret_cast<float *>(smem + C::OFF_ACC);          // RING only
     const int Lr = N - HOP;
     int ring = 0;
-    unsigned psh_key = 0u;                                 // bit pattern of the f the shift table was built for, valid once psh_valid
-    bool psh_valid = false;
 
     const double2 wl = p.tw64[t];                          // split pass: W_N^{t + T r} = wl * W_16^r  (N = 16 T)
     const float2 wlf = cconj(p.tw32[t]);
@@ -449,11 +493,11 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
 #pragma unroll
     for (int r = 0; r < 8; r++) acc[r] = float2{0.f, 0.f};
     if (RING) {
-        for (int j = t; j < Lr; j += T) ACC[j] = from_state ? p.acc_in[(long)ch * Lr + j] : 0.f;
+        for (int j = t; j < Lr; j += T) ACC[j] = from_state ? acc_in[(long)ch * Lr + j] : 0.f;
     } else if (from_state) {
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
-            const float *a = p.acc_in + (long)ch * (N - HOP) + 2 * t + 2 * T * r;
+            const float *a = acc_in + (long)ch * (N - HOP) + 2 * t + 2 * T * r;
             acc[r] = float2{a[0], a[1]};
         }
     }
@@ -462,7 +506,10 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
 #pragma unroll
         for (int r = 0; r < nrows; r++) {
             const long sx = s0 + 2 * T * (first_row + r);
-            if (vec_in) w[r] = *reinterpret_cast<const float2 *>(sx < 0 ? src.hist + sx + src.hist_len : src.in + sx);
+            if (RESIDENT && src.sys && vec_in && sx >= 0) {                // the host's hop of this quantum: never from a cache
+                const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src.in + sx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w[r] = float2{__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32))};
+            } else if (vec_in) w[r] = *reinterpret_cast<const float2 *>(sx < 0 ? src.hist + sx + src.hist_len : src.in + sx);
             else w[r] = float2{src.at(sx), src.at(sx + 1)};
         }
     };
@@ -470,10 +517,15 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     load_rows(raw, 8, 0, first_frame);
     // all global accesses of a frame are issued one frame ahead in one place, and the stores are exec-masked straight-line code (emit_v is a
     // per-lane value on purpose): no s_waitcnt vmcnt(0) behind a just-issued load or store (see pv_wave_kernel.hip)
-    float pf_next = pitch_row[first_frame];
+    float pf_next = (RESIDENT && src.sys) ? __hip_atomic_load(pitch_row + first_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : pitch_row[first_frame];
     int emit_v = first_out;
     asm volatile("" : "+v"(emit_v));
     __syncthreads();
+    WG_STAMP(2);
+#ifdef PV_WG_STAMPS
+    { float sink = 0.f; for (int r = 0; r < 8; r++) sink += raw[r].x; asm volatile("" :: "v"(sink)); }   // the input rows have arrived
+    WG_STAMP(3);
+#endif
 
     for (int m = first_frame; m < last_out; ++m) {
         // the thread id is made opaque once per frame: LDS addresses are recomputed from it instead of being hoisted into registers that
@@ -483,7 +535,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         const int l = tq & 63, wv = __builtin_amdgcn_readfirstlane(tq >> 6);
         const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));   // k-rate pitchFactor (pv:47), uniform
         const double pf = (double)pfm;
-        const int tmod = (int)(((long)p.t0_mod_n + (long)m * HOP) & (N - 1));
+        const int tmod = (int)(((long)t0_mod_n + (long)m * HOP) & (N - 1));
         const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
 
         // ---- Hann (pv:55), pack, forward FFT in fp64 (the split pass's 1/2 is folded into the window, exact) ----
@@ -543,14 +595,18 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         // slide the raw window; the rows the next frame adds are issued here
         {
             const int mn = (m + 1 < last_out) ? m + 1 : m;                 // the last frame re-reads its own rows (unused): no branch
-            if (RING) {
+            if (RESIDENT) {
+                // one frame per quantum: nothing to prefetch; the slide leaves the next call's history in raw[0 .. 8 - S_ROWS)
+#pragma unroll
+                for (int r = 0; r < 8 - (RING ? 8 : S_ROWS); r++) raw[r] = raw[r + S_ROWS];
+            } else if (RING) {
                 load_rows(raw, 8, 0, mn);
             } else {
 #pragma unroll
                 for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
                 load_rows(&raw[8 - (RING ? 8 : S_ROWS)], S_ROWS, 8 - S_ROWS, mn);
             }
-            pf_next = pitch_row[mn];
+            if (!RESIDENT) pf_next = pitch_row[mn];
         }
         // ---- shift table Math.round(peak * f) - peak (pv:125,147), rebuilt only when f changes ----
         {
@@ -805,7 +861,7 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
                 if (need_res && upper_end > H + N / 8) {                    // (one call site for both forms of the scatter: a second one spills the main loop)
                     __syncthreads();
                     const int up_delta = (int)DSH[last_peak];
-                    residue_scatter_wg<LOG2N, R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw32, tq, upper_end, up_delta,
+                    residue_scatter_wg<LOG2N, R>(src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw32, tq, upper_end, up_delta,
                                                  (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1), dbg ? p.dbg_X : nullptr, pairwise);
                 }
             }
@@ -901,24 +957,29 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
         __syncthreads();
     }
 
+    WG_STAMP(4);
     if (RING && chunk == (int)gridDim.x - 1) {
         for (int j = t; j < Lr; j += T) {
             int slot = ring + j; if (slot >= Lr) slot -= Lr;
-            p.acc_out[(long)ch * Lr + j] = ACC[slot];
-            p.hist_out[(long)ch * Lr + j] = src.at((long)p.nhops * HOP - Lr + j);
+            acc_out[(long)ch * Lr + j] = ACC[slot];
+            hist_out[(long)ch * Lr + j] = src.at((long)p.nhops * HOP - Lr + j);
         }
     }
     if (!RING && chunk == (int)gridDim.x - 1) {
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
-            float *a = p.acc_out + (long)ch * (N - HOP) + 2 * t + 2 * T * r;
+            float *a = acc_out + (long)ch * (N - HOP) + 2 * t + 2 * T * r;
             a[0] = acc[r].x; a[1] = acc[r].y;
-            float *hs = p.hist_out + (long)ch * (N - HOP) + 2 * t + 2 * T * r;
-            const long s = (long)p.nhops * HOP - (N - HOP) + 2 * t + 2 * T * r;
-            hs[0] = src.at(s); hs[1] = src.at(s + 1);
+            // the next call's history = rows S_ROWS..7 of the last frame's window = raw[0 .. 8 - S_ROWS) after the slide: from registers
+            // (re-reading it costs a streaming quantum an exposed memory -- for 8-channel quanta PCIe -- round trip)
+            float *hs = hist_out + (long)ch * (N - HOP) + 2 * t + 2 * T * r;
+            hs[0] = raw[r].x; hs[1] = raw[r].y;
         }
     }
-    pv_signal_done<true>(p.done, p.done_seq, (long)ch * gridDim.x + chunk);
+    WG_STAMP(5);
+    pv_signal_done<true>(p.done, done_seq, (long)ch * gridDim.x + chunk);
+    WG_STAMP(6);
+    if (RESIDENT) goto resident_top;
 }
 
 template <int LOG2N, int S_ROWS, bool AUX>
@@ -934,6 +995,23 @@ hipError_t launch_wg(const PvKernelParams &p, int nch, int nchunks, hipStream_t 
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3(nchunks, nch, 1), dim3(64 * G, 1, 1), lds_bytes, st, p);
+    return hipGetLastError();
+}
+
+template <int LOG2N, int S_ROWS>
+hipError_t launch_wg_resident(const PvKernelParams &p, int nslots, hipStream_t st)
+{
+    constexpr int G = 1 << (LOG2N - 10);
+    static std::atomic<bool> attr_done[16];
+    auto k = pv_wg_kernel<LOG2N, S_ROWS, false, true>;
+    constexpr int lds_bytes = WgCfg<G>::LDS_BYTES;
+    {
+        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    PvKernelParams q = p;
+    q.nchunks = 1; q.nch = nslots; q.nhops = 1; q.frames_per_chunk = 1;
+    hipLaunchKernelGGL(k, dim3(1, nslots, 1), dim3(64 * G, 1, 1), lds_bytes, st, q);
     return hipGetLastError();
 }
 
@@ -976,6 +1054,21 @@ size_t pv_wg_lds_bytes(int log2n, int hop)
 }
 
 int pv_wg_threads(int log2n) { return 64 << (log2n - 10); }
+
+// resident streaming form: N = 8192 with the register-resident overlap-add (hop = N/8 .. N)
+bool pv_wg_resident_supported(int log2n, int hop) { const int N = 1 << log2n; return log2n == 13 && (hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N); }
+
+hipError_t pv_launch_wg_resident(int log2n, const PvKernelParams &p, int nslots, hipStream_t st)
+{
+    if (log2n != 13) return hipErrorInvalidValue;
+    switch (8 * p.hop / (1 << log2n)) {
+    case 1: return launch_wg_resident<13, 1>(p, nslots, st);
+    case 2: return launch_wg_resident<13, 2>(p, nslots, st);
+    case 4: return launch_wg_resident<13, 4>(p, nslots, st);
+    case 8: return launch_wg_resident<13, 8>(p, nslots, st);
+    default: return hipErrorInvalidValue;
+    }
+}
 
 hipError_t pv_launch_wg(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
