@@ -73,5 +73,6 @@ for (const cfg of [
   { fft: 1024, hop: 256, nch: 1, fs: 48000, sweep: false, label: "BASELINE configs[1] shape, streaming: mono 48 kHz FFT=1024 hop=256, pitchFactor 1.5" },
 ].concat(resident ? [{ fft: 1024, hop: 256, nch: 1, fs: 48000, sweep: false, flags: 32, label: "BASELINE configs[1] shape, streaming on the RESIDENT kernel (PV_FLAG_PERSISTENT_STREAM): mono 48 kHz FFT=1024 hop=256, pitchFactor 1.5" },
   { fft: 1024, hop: 256, nch: 2, fs: 48000, sweep: true, flags: 32, label: "stereo 48 kHz FFT=1024 hop=256 on the resident kernel, pitchFactor swept 0.5->2.0" },
-  { fft: 2048, hop: 128, nch: 2, fs: 48000, sweep: false, flags: 32, label: "reference native shape on the RESIDENT kernel: stereo 48 kHz FFT=2048 hop=128, pitchFactor 1.5" }] : []).concat(extraInputs > 1 ? [{ fft: 2048, hop: 128, nch: 2, fs: 48000, sweep: false, inputs: extraInputs,
+  { fft: 2048, hop: 128, nch: 2, fs: 48000, sweep: false, flags: 32, label: "reference native shape on the RESIDENT kernel: stereo 48 kHz FFT=2048 hop=128, pitchFactor 1.5" },
+  { fft: 8192, hop: 2048, nch: 8, fs: 96000, sweep: true, flags: 32, label: "BASELINE configs[4] on the RESIDENT kernel: 8-ch 96 kHz FFT=8192 hop=2048, pitchFactor swept 0.5->2.0 per hop" }] : []).concat(extraInputs > 1 ? [{ fft: 2048, hop: 128, nch: 2, fs: 48000, sweep: false, inputs: extraInputs,
     label: `reference native shape with numberOfInputs = ${extraInputs}: ${extraInputs} x stereo 48 kHz FFT=2048 hop=128, pitchFactor 1.5` }] : [])) console.log(JSON.stringify(run(cfg)));
