@@ -18,6 +18,7 @@ const Cls = getProcessor("phase-vocoder-processor");
 if (Cls !== PhaseVocoderProcessor) throw new Error("registration broken");
 const opts = { numberOfInputs: 1, numberOfOutputs: 1 };
 if (!(N === 2048 && h === 128 && spec.use_defaults)) opts.processorOptions = { fftSize: N, hopSize: h };
+if (spec.flags) opts.processorOptions = Object.assign(opts.processorOptions || {}, { flags: spec.flags });   // PV_FLAG_* (32: resident streaming kernel)
 const proc = new Cls(opts);
 const out = new Float32Array(maxCh * T * h);
 let nch = spec.nch;

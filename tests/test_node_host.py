@@ -70,8 +70,11 @@ NODE_CASES = ["c2_1024_256_mono_pf1.5_tonal", "c3_2048_512_stereo_pf0.8_noise", 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 32], ids=["launch", "resident"])
 @pytest.mark.parametrize("name", NODE_CASES)
-def test_node_process_matches_reference_golden(name, tmp_path):
+def test_node_process_matches_reference_golden(name, flags, tmp_path):
+    """PhaseVocoderProcessor.process() quantum by quantum against the reference's golden output -- launch per quantum, and with
+    `processorOptions.flags = 32` (PV_FLAG_PERSISTENT_STREAM: the resident kernel where the shape has one, the launch form elsewhere)."""
     _build()
     case = CASES[name]
     h, T = case["hop"], case["store_hops"]
@@ -81,7 +84,7 @@ def test_node_process_matches_reference_golden(name, tmp_path):
     sig.astype("<f4").tofile(tmp_path / "in.f32")
     pitch.astype("<f4").tofile(tmp_path / "pitch.f32")
     spec = {"fft": case["fft"], "hop": h, "nhops": T, "nch": case["nch"], "max_ch": nmax, "events": case.get("events", []),
-            "arate": bool(case.get("arate")), "use_defaults": name.startswith("native"),
+            "arate": bool(case.get("arate")), "use_defaults": name.startswith("native") and not flags, "flags": flags,
             "in_file": str(tmp_path / "in.f32"), "pitch_file": str(tmp_path / "pitch.f32"), "out_file": str(tmp_path / "out.f32")}
     (tmp_path / "spec.json").write_text(json.dumps(spec))
     r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node", "run_case.js"), str(tmp_path / "spec.json")], capture_output=True, text=True, timeout=300)
