@@ -926,13 +926,21 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
     }
 
     if (chunk == p.nchunks - 1) {
+        // the next call's history is read in one batch before anything is stored (interleaved, every load is waited for on its own: pv_wave2k_kernel.hip)
+        v4f hrow[LROWS > 0 ? LROWS : 1];
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) {
+            const long s = (long)p.nhops * HOP - L + so + 512 * r;
+            hrow[r] = v4f{src.at(s), src.at(s + 1), src.at(s + 4), src.at(s + 5)};
+        }
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) asm volatile("" : "+v"(hrow[r]));
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
             float *a = p.acc_out + (long)ch * L + so + 512 * r;
             a[0] = acc[r].x; a[1] = acc[r].y; a[4] = acc[r].z; a[5] = acc[r].w;
             float *hs = p.hist_out + (long)ch * L + so + 512 * r;
-            const long s = (long)p.nhops * HOP - L + so + 512 * r;
-            hs[0] = src.at(s); hs[1] = src.at(s + 1); hs[4] = src.at(s + 4); hs[5] = src.at(s + 5);
+            hs[0] = hrow[r].x; hs[1] = hrow[r].y; hs[4] = hrow[r].z; hs[5] = hrow[r].w;
         }
     }
     pv_signal_done<true>(p.done, p.done_seq, chain);

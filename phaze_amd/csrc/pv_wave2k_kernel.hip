@@ -31,6 +31,11 @@
 #define PV_PT 1, 0, 1, 2, 2, 2, 2, 2, 0, 0, 0, 2     // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C3 3.76 -> 3.31 ms)
 #endif
 #include "pv_wave_fft.h"
+#ifdef PV_W2K_STAMPS  // measurement build (make variant ... EXTRA=-DPV_W2K_STAMPS CAPI_EXTRA=-DPV_STAMPS=1): s_memtime at the stations of a 1-hop launch, per chain
+#define W2K_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0 && p.stamps) p.stamps[16 * chain + (i)] = (unsigned)t_; } while (0)
+#else
+#define W2K_STAMP(i)
+#endif
 #ifndef PV_PAIRWISE
 #define PV_PAIRWISE 1                               // 0: every f < 1 frame goes through the claim rounds (A/B)
 #endif
@@ -252,6 +257,7 @@ __global__ __launch_bounds__(RESIDENT ? 128 : 64 * WAVES2, RESIDENT ? 1 : 2) PV_
     const long chain = (long)blockIdx.x * (blockDim.x >> 6) + wv;        // a small launch runs fewer waves per workgroup (launch2k)
     const int ch = (int)(chain / p.nchunks), chunk = (int)(chain - (long)ch * p.nchunks);
 
+    W2K_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const double2 *TW1 = reinterpret_cast<const double2 *>(smem_all + T2_TW1);
     const double2 *TW2 = reinterpret_cast<const double2 *>(smem_all + T2_TW2);
@@ -282,6 +288,7 @@ __global__ __launch_bounds__(RESIDENT ? 128 : 64 * WAVES2, RESIDENT ? 1 : 2) PV_
     }
     __syncthreads();                                                     // the only workgroup-wide barrier
     if (ch >= p.nch) return;
+    W2K_STAMP(1);
     // what changes from quantum to quantum in the resident form (constants of the launch otherwise)
     const float *hist_in = p.hist_in, *acc_in = p.acc_in;
     float *hist_out = p.hist_out, *acc_out = p.acc_out;
@@ -392,6 +399,11 @@ resident_top:
     v4f hw[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) hw[r] = HW4[r * 64 + lane];
+    W2K_STAMP(2);
+#ifdef PV_W2K_STAMPS
+    { float sink = 0.f; for (int r = 0; r < 8; r++) sink += raw[r].x + acc[r].x; asm volatile("" :: "v"(sink)); }
+    W2K_STAMP(3);
+#endif
 
     for (int m = first_frame; m < last_out; ++m) {
         const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
@@ -806,8 +818,19 @@ resident_top:
         }
     }
 
+    W2K_STAMP(4);
     if (chunk == p.nchunks - 1) {
         const int lend = HALF ? (lane ^ (((last_out - first_frame) & 1) << 5)) : lane;     // layout the last frame left the accumulator in
+        // The history of the next call, read in ONE batch before anything is stored: written as `hs[i] = src.at(..)` the loads and stores alias as far
+        // as the compiler can tell, every load is waited for on its own, and a streaming quantum spends 5.5 us here (station clock, -DPV_W2K_STAMPS).
+        v4f hrow[LROWS > 0 ? LROWS : 1];
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) {
+            const long s = (long)p.nhops * HOP - L + 4 * lane + 256 * r;
+            hrow[r] = (4 * lane + 256 * r < L) ? v4f{src.at(s), src.at(s + 1), src.at(s + 2), src.at(s + 3)} : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) asm volatile("" : "+v"(hrow[r]));              // (all loads issued and landed before the first store)
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
             if (4 * lend + 256 * r < L) {
@@ -816,13 +839,13 @@ resident_top:
             }
             if (4 * lane + 256 * r < L) {
                 float *hs = hist_out + (long)ch * L + 4 * lane + 256 * r;
-                const long s = (long)p.nhops * HOP - L + 4 * lane + 256 * r;
-#pragma unroll
-                for (int i = 0; i < 4; i++) hs[i] = src.at(s + i);
+                hs[0] = hrow[r].x; hs[1] = hrow[r].y; hs[2] = hrow[r].z; hs[3] = hrow[r].w;
             }
         }
     }
+    W2K_STAMP(5);
     pv_signal_done<false>(p.done, done_seq, chain);
+    W2K_STAMP(6);
     if (RESIDENT) goto resident_top;
 }
 

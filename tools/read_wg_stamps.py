@@ -1,8 +1,9 @@
-"""Stations of ONE streaming quantum inside pv_wg_kernel (measurement build -DPV_WG_STAMPS, `make variant`): usage PHAZE_LIB=build/exp/libphaze_wgst.so python tools/read_wg_stamps.py"""
+"""Stations of ONE streaming quantum inside pv_wg_kernel / pv_wave2k_kernel (measurement builds -DPV_WG_STAMPS / -DPV_W2K_STAMPS, `make variant`):
+usage PHAZE_LIB=build/exp/libphaze_wgst.so python tools/read_wg_stamps.py [fft hop nch]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np, phaze_amd, signals as S
-fft, hop, nch = 8192, 2048, 8
+fft, hop, nch = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (8192, 2048, 8)
 pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1)
 L = pv._L
 x = np.stack([S.make_signal("tonal", c, 64 * hop) for c in range(nch)])
