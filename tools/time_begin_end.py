@@ -4,7 +4,7 @@ import ctypes as C, sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np, phaze_amd, signals as S
 fft, hop, nch = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (8192, 2048, 8)
-for flags, label in ((0, "launch"), (32, "resident"), (16, "launch, pinned input"), (48, "resident, pinned")):
+for flags, label in ((0, "launch"), (32, "resident"), (16, "launch, pinned input"), (48, "resident, pinned"), (4, "launch, workgroup kernel")):
     pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, flags=flags)
     L = pv._L
     x = np.stack([S.make_signal("tonal", c, 64 * hop) for c in range(nch)])
