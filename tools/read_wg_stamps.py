@@ -19,6 +19,6 @@ for m in range(200):
 pv.close()
 a = np.array(acc).mean(axis=(0, 1))
 names = ["tables built", "per-quantum setup + loads issued + barrier", "input rows arrived", "frame", "state written", "signal (fence + flag)"]
-print("s_memtime ticks (100 MHz constant clock on gfx9: 10 ns each) per station, mean over channels and quanta")
+print("s_memtime ticks (shader clock: ~2.0 GHz while one frame is all the GPU has to do) per station, mean over channels and quanta")
 for n, v in zip(names, a): print(f"  {v:8.0f}  {n}")
 print("  total", a.sum())
