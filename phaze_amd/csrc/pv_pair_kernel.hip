@@ -395,6 +395,11 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
     float pf_next = pitch_row[first_frame];
     int emit_v = first_out;
     asm volatile("" : "+v"(emit_v));
+    // conj(W^{2 kk}) of the fast residue's four bins of this lane, kk = 1 + (64 g + lane) + 128 j: loop-invariant (as a load inside the frame it sat, exposed,
+    // on the critical path of every f < 1 frame)
+    float2 s2w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) s2w[j] = cconj(p.tw32[2 * (1 + 64 * g + lane + 128 * j)]);
 
     for (int m = first_frame; m < last_out; ++m) {
         const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
                     const int kk = 1 + LL + 128 * j;                         // kk in [1, 512]
                     const float2 x0 = XS[kk], x1 = XS[kk + 1024], x2 = XS[2048 - kk], x3 = XS[1024 - kk];
                     const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
-                    s2v[j] = cmul(tsum, cconj(p.tw32[2 * kk]));
+                    s2v[j] = cmul(tsum, s2w[j]);
                 }
                 __syncthreads();                                           // (f < 1 only, uniform in the workgroup) the stash is dead: Y may be zeroed
             }

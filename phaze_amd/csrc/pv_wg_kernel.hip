@@ -63,7 +63,8 @@ struct WgCfg {
     static constexpr int TWA_ROWS = CT ? 3 : 7;
     static constexpr int OFF_TWB = OFF_TWA + 16 * TWA_ROWS * T;                  // double2[7][8G]
     static constexpr int OFF_TWC = OFF_TWB + 16 * 7 * 8 * G;                     // double2[7][G]
-    static constexpr int LDS_BYTES = OFF_TWC + 16 * 7 * G;
+    static constexpr int OFF_S2W = OFF_TWC + 16 * 7 * G;                         // float2[2][T] conj(W^{2k}) of the fast residue's bins k = 1 + t + T j
+    static constexpr int LDS_BYTES = OFF_S2W + 8 * 2 * T;
     static constexpr int OFF_ACC = LDS_BYTES;                                    // f32[N - hop] overlap-add ring, only for hops below N/8 (S_ROWS = 0)
     static constexpr int LDS_BYTES_RING = OFF_ACC + 4 * N;
 };
@@ -426,6 +427,11 @@ __global__ __launch_bounds__(64 << (LOG2N - 10), 2) PV_NO_DS_MERGE void pv_wg_ke
     }
     for (int i = t; i < 7 * 8 * G; i += T) TWB[i] = p.tw64[(16 * (i % (8 * G)) * (i / (8 * G) + 1)) & (N - 1)];
     for (int i = t; i < 7 * G; i += T) TWC[i] = p.tw64[(128 * (i % G) * (i / G + 1)) & (N - 1)];
+    // conj(W^{2k}) of the fast residue's two bins of a thread, k = 1 + t + T j: in LDS with the other tables (as a global load inside the frame it sat,
+    // exposed, on the critical path of every f < 1 frame -- one workgroup per CU has nothing to cover a global round trip with)
+    float2 *S2W = reinterpret_cast<float2 *>(smem + C::OFF_S2W);
+    S2W[t] = cconj(p.tw32[2 * (1 + t)]);
+    S2W[T + t] = cconj(p.tw32[2 * (1 + t + T)]);
 
     WG_STAMP(1);
     unsigned psh_key = 0u;                                 // bit pattern of the f the shift table was built for, valid once psh_valid
@@ -635,7 +641,7 @@ resident_top:
                 const int k = 1 + tq + T * j;                                // k in [1, N/8]
                 const float2 x0 = Y[k], x1 = Y[k + M / 2], x2 = Y[M - k], x3 = Y[M / 2 - k];
                 const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
-                s2v[j] = cmul(tsum, cconj(p.tw32[2 * k]));
+                s2v[j] = cmul(tsum, S2W[j * T + tq]);
             }
         }
         bool nonfinite = false;
