@@ -14,7 +14,7 @@ const rd = (f) => { const b = fs.readFileSync(f); return new Float32Array(b.buff
 const pitch = rd(spec.pitch_file);
 const x = spec.inputs.map((inp) => rd(inp.in_file));                       // [max_ch][T*h] per input
 const Cls = getProcessor("phase-vocoder-processor");
-const proc = new Cls({ numberOfInputs: nin, numberOfOutputs: nin, processorOptions: { fftSize: N, hopSize: h } });
+const proc = new Cls({ numberOfInputs: nin, numberOfOutputs: nin, processorOptions: { fftSize: N, hopSize: h, flags: spec.flags | 0 } });   // flags 32: one resident kernel per input
 const out = spec.inputs.map((inp) => new Float32Array(inp.max_ch * T * h));
 const nch = spec.inputs.map((inp) => inp.nch);
 for (let m = 0; m < T; m++) {

@@ -98,8 +98,9 @@ def test_node_process_matches_reference_golden(name, flags, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 32], ids=["launch", "resident"])
 @pytest.mark.parametrize("case", MAN["multi_cases"], ids=lambda c: c["name"])
-def test_node_two_inputs_match_reference_golden(case, tmp_path):
+def test_node_two_inputs_match_reference_golden(case, flags, tmp_path):
     """numberOfInputs: 2 -- two inputs with different channel counts, one changing mid-stream (ola-processor.js:24-33,38-52): the host keeps
     one native handle per input; the reference's outputs for BOTH inputs are the golden."""
     _build()
@@ -111,7 +112,7 @@ def test_node_two_inputs_match_reference_golden(case, tmp_path):
     for i, inp in enumerate(case["inputs"]):
         np.stack([s[:T * h] for s in sig[i]]).astype("<f4").tofile(tmp_path / f"in{i}.f32")
         inputs.append({"nch": inp["nch"], "events": inp.get("events", []), "max_ch": case["max_channels_per_input"][i], "in_file": str(tmp_path / f"in{i}.f32")})
-    spec = {"fft": case["fft"], "hop": h, "nhops": T, "inputs": inputs, "pitch_file": str(tmp_path / "pitch.f32"), "out_file": str(tmp_path / "out.f32")}
+    spec = {"fft": case["fft"], "hop": h, "nhops": T, "inputs": inputs, "pitch_file": str(tmp_path / "pitch.f32"), "out_file": str(tmp_path / "out.f32"), "flags": flags}
     (tmp_path / "spec.json").write_text(json.dumps(spec))
     r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node", "run_multi.js"), str(tmp_path / "spec.json")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr + r.stdout
