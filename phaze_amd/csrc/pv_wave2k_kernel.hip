@@ -347,6 +347,7 @@ resident_top:
     const double2 w2048 = p.tw64[lane];                                   // W_2048^l: split-pass twiddle W_2048^{l + 64 r} = w2048 * W_32^r
     constexpr float SC = 2.0f / ((float)N * (float)R);                    // 1/N of the inverse, 1/R of the overlap-add, 2 for the shared 0.5 * Hann table (exact)
     const float2 c2048 = cconj(p.tw32[lane]), c1024 = cconj(p.tw32[2 * lane]);
+    const float2 s2w0 = cconj(p.tw32[2 * (1 + lane)]);                    // fast residue (f < 1): conj(W^{2k}) of this lane's first bin k = 1 + lane
     const pk::c32 wl2048s{c2048.x * SC, c2048.y * SC};                    // c2r twiddle e^{+2 pi j l / 2048}, scale folded in
     const pk::c32 wl1024f{c1024.x, c1024.y};                              // DIF twiddle e^{+2 pi j l / 1024}
     pk::c32 wl2048s_x = wl2048s, wl1024f_x = wl1024f;                     // the same for the lane id l ^ 32 (odd frames of the half-row hop)
@@ -491,7 +492,11 @@ resident_top:
                 const int k = 1 + l + 64 * j;                                // k in [1, 256]
                 const float2 x0 = XS[k], x1 = XS[k + 512], x2 = XS[1024 - k], x3 = XS[512 - k];
                 const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
-                s2v[j] = cmul(tsum, cconj(p.tw32[2 * k]));
+                // conj(W^{2k}) = conj(W_1024^{1 + l}) * conj(W_16^j): one loop-invariant register pair and three constant rotations instead of four loads
+                // from the global table in every f < 1 frame
+                const float c8 = 0.92387953251128675613f, s8 = 0.38268343236508977173f, h8 = 0.70710678118654752440f;
+                const float2 wj = (j == 0) ? s2w0 : (j == 1) ? cmul(s2w0, float2{c8, s8}) : (j == 2) ? cmul(s2w0, float2{h8, h8}) : cmul(s2w0, float2{s8, c8});
+                s2v[j] = cmul(tsum, wj);
             }
             wave_sync();
         }
