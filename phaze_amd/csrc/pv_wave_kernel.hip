@@ -680,6 +680,13 @@ resident_top:
                 if (dbg) { p.dbg_X[2 * 256] = x256.x; p.dbg_X[2 * 256 + 1] = x256.y; }
             }
         }
+        // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change.  BEFORE the prefetch is issued: the
+        //      table build is a call, a function entry waits for vmcnt(0), and with the next frame's rows in flight that is an exposed HBM round trip in
+        //      every frame whose f differs from the last one (a pitch sweep: -3 % per launch) ----
+        {
+            const unsigned pfb = __float_as_uint(pfm);
+            if (!psh_valid || pfb != psh_key) { psh_key = pfb; psh_valid = true; build_shift_table_1024(pfm, wave_off, l); }
+        }
 #ifndef PV_RELOAD_ROWS
         // slide the window: the rows the next frame adds are issued here and land behind the shift + inverse FFT
 #pragma unroll
@@ -690,11 +697,6 @@ resident_top:
             pf_next = pitch_row[mn];
         }
 #endif
-        // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change ----
-        {
-            const unsigned pfb = __float_as_uint(pfm);
-            if (!psh_valid || pfb != psh_key) { psh_key = pfb; psh_valid = true; build_shift_table_1024(pfm, wave_off, l); }
-        }
         wave_sync();
         PV_STAMP(4);
         pv_prio(PH_PEAKS);
