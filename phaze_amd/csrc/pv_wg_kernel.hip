@@ -310,6 +310,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(cons
     float2 *Y = reinterpret_cast<float2 *>(smem + C::OFF_Y);
     unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);             // aliases ROUTE once the routes are in registers (f < 1)
     float2 *Q = reinterpret_cast<float2 *>(smem + C::OFF_RESQ);
+    const double2 *TWA1 = reinterpret_cast<const double2 *>(smem + C::OFF_TWA);     // row 1 of the forward FFT's twiddle table: W_N^{2t}, t < T (same offset in both layouts)
     const WaveSrc src{in, hist, hist_len, sys};
     for (int base = N / 2; base < N && base < upper_end; base += QN) {
         if (BASE4) {
@@ -345,9 +346,16 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(cons
                 if (t < nblocks * hq) { blk = t / hq; i = t - blk * hq; } else { blk = t - nblocks * hq; i = hq; }
                 const int o = blk << log2m;
                 const float2 A = Q[o + i];
-                const float2 Bv = cmul(Q[o + q + i], tw32[i << tws]);
-                const float2 Cc = cmul(Q[o + 2 * q + i], tw32[(2 * i) << tws]);
-                const float2 D = cmul(Q[o + 3 * q + i], tw32[(3 * i) << tws]);
+                // W^{e}, W^{2e}, W^{3e}, e = i << tws (even, <= N/8): W^e from the forward FFT's fp64 table in LDS (row 1 = W_N^{2t}), its square and
+                // cube formed here.  Three loads from the global table per butterfly were three exposed round trips in each of the five stages (one
+                // workgroup per CU has nothing to cover them with): 2500 of the 19 400 cycles of a call each (station clock, tools/read_wg_phases.py).
+                float2 w1;
+                if (i == hq) w1 = float2{0.70710678118654752440f, -0.70710678118654752440f};   // e = N/8: W_8 (one past the table row)
+                else { const double2 wd = TWA1[i << (tws - 1)]; w1 = float2{(float)wd.x, (float)wd.y}; }
+                const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                const float2 Bv = cmul(Q[o + q + i], w1);
+                const float2 Cc = cmul(Q[o + 2 * q + i], w2);
+                const float2 D = cmul(Q[o + 3 * q + i], w3);
                 const float2 T0 = cadd(A, Cc), T1 = csub(A, Cc), T2 = cadd(Bv, D), T3 = csub(Bv, D);
                 Q[o + i] = cadd(T0, T2);
                 Q[o + q + i] = float2{T1.x + T3.y, T1.y - T3.x};
