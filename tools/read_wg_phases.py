@@ -1,4 +1,4 @@
-"""Phase clock of pv_wg_kernel in a THROUGHPUT launch (measurement build -DPV_WG_STAMPS=2, `make variant ... CAPI_EXTRA=-DPV_STAMPS=1`):
+"""Phase clock of pv_wg_kernel in a THROUGHPUT launch (a measurement build with s_memtime accumulators at the phase boundaries of the frame loop -- the hooks are not kept in the product source; the numbers are in profiles/r03_wg_phase_clock.md):
 usage PHAZE_LIB=build/exp/libphaze_wgph.so python tools/read_wg_phases.py [pitch | sweep]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -13,8 +13,6 @@ x = (0.25 * torch.sin(n * (0.0288 + 0.002 * c)) + 0.125 * torch.sin(n * 0.18) + 
 y = torch.empty_like(x)
 p = ((0.5 + 1.5 * (torch.arange(T, device=dev) % 64).float() / 63.0) if arg == "sweep" else torch.full((T,), float(arg), device=dev)).float().contiguous()
 pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1)
-pv._L.pv_exp_res_acc.argtypes = [C.c_void_p, C.c_int]
-pv._L.pv_exp_res_acc(None, 1)
 for _ in range(3): pv.process_batch_device(x.data_ptr(), y.data_ptr(), nch, T, T * hop, p.data_ptr(), 0, 1)
 pv.synchronize()
 info = pv.info(); nchunks = (T + info["frames_per_chunk"] - 1) // info["frames_per_chunk"]
@@ -29,11 +27,3 @@ names = ["Hann + forward FFT (fp64, 3 transposes)", "split pass + |X|^2 (+ stash
 print(f"pv_wg_kernel<13,2> C5 shape, pitch {arg}: {int(ok.sum())} workgroups x {int(fr.max())} frames; shader-clock ticks per frame: {a.sum():.0f}")
 for nme, v in zip(names, a): print(f"  {v:8.0f}  {100 * v / a.sum():5.1f} %  {nme}")
 
-racc = np.zeros(16, np.uint64)
-pv2 = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=1, max_hops=1)
-pv2._L.pv_exp_res_acc(racc.ctypes.data_as(C.c_void_p), 0); pv2.close()
-if racc[15]:
-    calls = float(racc[15])
-    print(f"  general residue: {int(calls)} calls (3 launches); ticks per call:")
-    for i, nme in ((0, "base stage (global input + Hann, first butterflies, barrier)"), (1, "stage 1"), (2, "stage 2"), (3, "stage 3"), (4, "stage 4"), (5, "stage 5"), (8, "sources + rotations"), (9, "stores / claim rounds + barrier")):
-        print(f"    {racc[i] / calls:8.0f}  {nme}")
