@@ -187,6 +187,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(cons
     float2 *Y = reinterpret_cast<float2 *>(smem_all + wave_off + O2_S);
     unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + O2_ROUTE);
     float2 *Q = reinterpret_cast<float2 *>(smem_all + wave_off + O2_RESQ);
+    const double2 *TW1R = reinterpret_cast<const double2 *>(smem_all + T2_TW1);   // shared table of the workgroup: entry 64 k + l = W_512^{l k}
     const WaveSrc src{in, hist, hist_len, sys};
     for (int base = N / 2; base < N && base < upper_end; base += QN) {
 #pragma unroll
@@ -207,9 +208,15 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(cons
                 if (t < nblocks * hq) { blk = t / hq; i = t - blk * hq; } else { blk = t - nblocks * hq; i = hq; }
                 const int o = blk << log2m;
                 const float2 A = Q[o + i];
-                const float2 Bv = cmul(Q[o + q + i], tw32[i << tws]);
-                const float2 Cc = cmul(Q[o + 2 * q + i], tw32[(2 * i) << tws]);
-                const float2 D = cmul(Q[o + 3 * q + i], tw32[(3 * i) << tws]);
+                // W^e, W^{2e}, W^{3e}, e = i << tws (a multiple of 4, <= N/8): W^e from row 1 of the forward FFT's fp64 table in LDS (W_512^l = W_N^{4l}), its
+                // square and cube formed here, instead of three loads from the global table per butterfly (see pv_wg_kernel.hip)
+                float2 w1;
+                if (i == hq) w1 = float2{0.70710678118654752440f, -0.70710678118654752440f};   // e = N/8: W_8 (one past the table row)
+                else { const double2 wd = TW1R[64 + (i << (tws - 2))]; w1 = float2{(float)wd.x, (float)wd.y}; }
+                const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                const float2 Bv = cmul(Q[o + q + i], w1);
+                const float2 Cc = cmul(Q[o + 2 * q + i], w2);
+                const float2 D = cmul(Q[o + 3 * q + i], w3);
                 const float2 T0 = cadd(A, Cc), T1 = csub(A, Cc), T2 = cadd(Bv, D), T3 = csub(Bv, D);
                 Q[o + i] = cadd(T0, T2);
                 Q[o + q + i] = float2{T1.x + T3.y, T1.y - T3.x};
