@@ -82,12 +82,15 @@ enum {
                                   * is written by the HOST into device memory through the BAR (posted writes, ordered before the launch doorbell),
                                   * so the kernel starts on local HBM instead of a PCIe read round trip; larger quanta and other devices keep the
                                   * pinned-memory read.  The output always goes to pinned host memory (posted device writes) */
-    PV_FLAG_PERSISTENT_STREAM = 32, /* streaming quanta on a RESIDENT kernel (N = 1024 with hop 128..1024, at most 64 channel slots; ignored
-                                  * elsewhere): the kernel of the first pv_process stays on the GPU, one wave per channel slot polling a word in
-                                  * pinned host memory; a quantum then costs no launch.  The waves leave by themselves after ~50 ms without
-                                  * work (and are relaunched on demand) and before any other use of the handle's stream (batch calls, state
-                                  * export / import, reset).  Same kernel code, same bits as the launch-per-quantum form.  Off by default:
-                                  * while resident, a device-wide synchronize of another user of the GPU waits for that idle time-out */
+    PV_FLAG_PERSISTENT_STREAM = 32, /* streaming quanta on a RESIDENT kernel (N = 1024 and 2048 with the hops their one-wave kernels cover, N = 8192 with
+                                  * hop >= N/8; at most 64 channel slots; ignored elsewhere): the kernel of the first pv_process stays on the GPU, one wave
+                                  * (N = 8192: one workgroup) per channel slot polling a control word -- in device memory, written by the host through the
+                                  * large BAR together with quanta of up to 16 KB of input; in pinned host memory on other devices / with
+                                  * PV_FLAG_STREAM_PINNED_INPUT.  A quantum then costs no launch.  The waves leave by themselves after ~50 ms without work
+                                  * (and are relaunched on demand) and before any other use of the handle's stream (batch calls, state export / import,
+                                  * reset, pv_synchronize).  Same kernel code, same bits as the launch-per-quantum form.  Off by default: while resident, a
+                                  * device-wide synchronize of another user of the GPU waits for that idle time-out, and the handle should keep its own
+                                  * stream (pv_set_stream to a stream shared with other work would queue that work behind the resident kernel) */
     PV_FLAG_ALL = 63             /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
 };
 
