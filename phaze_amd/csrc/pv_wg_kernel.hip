@@ -64,7 +64,8 @@ struct WgCfg {
     static constexpr int OFF_TWB = OFF_TWA + 16 * TWA_ROWS * T;                  // double2[7][8G]
     static constexpr int OFF_TWC = OFF_TWB + 16 * 7 * 8 * G;                     // double2[7][G]
     static constexpr int OFF_S2W = OFF_TWC + 16 * 7 * G;                         // float2[2][T] conj(W^{2k}) of the fast residue's bins k = 1 + t + T j
-    static constexpr int LDS_BYTES = OFF_S2W + 8 * 2 * T;
+    static constexpr int OFF_XQ = OFF_S2W + 8 * 2 * T;                           // f32[N/4] windowed input samples xw[4n + 2] of the current frame (f < 0.75 only): base stage of the general residue
+    static constexpr int LDS_BYTES = OFF_XQ + N;
     static constexpr int OFF_ACC = LDS_BYTES;                                    // f32[N - hop] overlap-add ring, only for hops below N/8 (S_ROWS = 0)
     static constexpr int LDS_BYTES_RING = OFF_ACC + 4 * N;
 };
@@ -295,7 +296,7 @@ __device__ __forceinline__ int digitrev4_(int v, int nd)
 
 // Rare path: above-Nyquist residue of fft.js's in-place real DIT, one quarter of the buffer at a time, then its sources
 // are added into Y.  Same structure as residue_scatter_1024, any LOG2N (radix-2 base stage when log2 N is odd: bundle:447-463).
-template <int LOG2N, int R_>
+template <int LOG2N, int R_, bool CT>
 __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(const float *in, const float *hist, int hist_len, bool sys, long s0, const float *__restrict__ hann,
                                                              const float2 *__restrict__ tw32, int t, int upper_end, int up_delta, unsigned up_ridx,
                                                              double *dbg_X, bool plain)
@@ -303,7 +304,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(cons
     // plain: the frame passed the pairwise test (see the peak search), so nothing but the residue itself lands on the residue's targets -- the
     // continuation of the last region, all distinct: plain stores instead of claim rounds (two barriers and an atomic per source and round)
     constexpr int G = 1 << (LOG2N - 10);
-    using C = WgCfg<G>;
+    using C = WgCfg<G, CT>;
     constexpr int N = C::N, H = C::H, T = C::T, QN = N / 4;
     constexpr bool BASE4 = (LOG2N % 2) == 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -312,8 +313,27 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(cons
     float2 *Q = reinterpret_cast<float2 *>(smem + C::OFF_RESQ);
     const double2 *TWA1 = reinterpret_cast<const double2 *>(smem + C::OFF_TWA);     // row 1 of the forward FFT's twiddle table: W_N^{2t}, t < T (same offset in both layouts)
     const WaveSrc src{in, hist, hist_len, sys};
+    const float *XQ = reinterpret_cast<const float *>(smem + C::OFF_XQ);   // the frame's windowed samples xw[4n + 2] (stashed by the kernel): base stage of the first quarter
     for (int base = N / 2; base < N && base < upper_end; base += QN) {
-        if (BASE4) {
+        if (base == N / 2) {
+            if (BASE4) {
+                const int off = digitrev4_(N / 8 + t, (LOG2N - 2) / 2);      // = 2 (mod 4): sample off + q N/4 is XQ[(off - 2) / 4 + q N/16]
+                const float a = XQ[(off - 2) >> 2], b = XQ[((off - 2) >> 2) + N / 16], c = XQ[((off - 2) >> 2) + N / 8], d = XQ[((off - 2) >> 2) + 3 * N / 16];
+                const float t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+                Q[4 * t] = float2{t0 + t2, 0.f};
+                Q[4 * t + 1] = float2{t1, -t3};
+                Q[4 * t + 2] = float2{t0 - t2, 0.f};
+                Q[4 * t + 3] = float2{t1, t3};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int lb = t + T * i, off = digitrev4_(N / 4 + lb, (LOG2N - 1) / 2);
+                    const float a = XQ[(off - 2) >> 2], b = XQ[((off - 2) >> 2) + N / 8];
+                    Q[2 * lb] = float2{a + b, 0.f};
+                    Q[2 * lb + 1] = float2{a - b, 0.f};
+                }
+            }
+        } else if (BASE4) {
             constexpr int nd = (LOG2N - 2) / 2;
             const int blk = base / 4 + t;                                  // QN/4 = T blocks per quarter
             const int off = digitrev4_(blk, nd);
@@ -595,6 +615,14 @@ resident_top:
 #pragma unroll
                 for (int r = 0; r < 4; r++) { Y[tq + T * r] = XA[r]; Y[M - tq - T * r] = XB[r]; }
                 if (tq == 0) Y[M / 2] = xHf;
+                if (pf < 0.75 && (tq & 1)) {
+                    // A frame that reads beyond position N/2 + N/8 above Nyquist (possible only for f < 0.75) rebuilds quarter 2 of fft.js's buffer from the
+                    // windowed samples xw[4n + 2] (residue_scatter_wg).  They are still in registers here -- sample 2 (t + T r) of the odd threads -- and a
+                    // digit-reversed gather from global memory later costs 5500-7500 cycles (profiles/r03_wg_phase_clock.md): stashed in natural order, 8 KB.
+                    float *XQ = reinterpret_cast<float *>(smem + C::OFF_XQ);
+#pragma unroll
+                    for (int r = 0; r < 8; r++) XQ[(tq + T * r - 1) >> 1] = raw[r].x * hw[r].x;
+                }
             }
             if (dbg) {
 #pragma unroll
@@ -875,7 +903,7 @@ resident_top:
                 if (need_res && upper_end > H + N / 8) {                    // (one call site for both forms of the scatter: a second one spills the main loop)
                     __syncthreads();
                     const int up_delta = (int)DSH[last_peak];
-                    residue_scatter_wg<LOG2N, R>(src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw32, tq, upper_end, up_delta,
+                    residue_scatter_wg<LOG2N, R, RING>(src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw32, tq, upper_end, up_delta,
                                                  (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1), dbg ? p.dbg_X : nullptr, pairwise);
                 }
             }
