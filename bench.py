@@ -75,27 +75,28 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(fft, hop, pitch, target_seconds=12.0):
-    """Times the CPU oracle (oracle/pv_oracle.c -- the checker, used here only as the reported baseline) on one core."""
+def cpu_baseline(fft, hop, pitch, x_prefix, what, target_seconds=12.0):
+    """Times the CPU oracle (oracle/pv_oracle.c -- the checker, used here only as the reported baseline) on one core, on a prefix of the SAME
+    signal the GPU leg processed (x_prefix: channel 0 of the headline input, downloaded from HBM)."""
     import numpy as np
     import oracle_lib
-    import signals as S
-    probe = 1024
-    x = S.make_signal("tonal", 0, probe * hop)[None, :]
+    avail = x_prefix.shape[-1] // hop
+    probe = min(1024, avail)
+    x = np.ascontiguousarray(x_prefix[:1, :probe * hop])
     p = np.full(probe, pitch, np.float32)
     o = oracle_lib.Oracle(fft, hop, 1)
     t0 = time.perf_counter()
     o.process_planar(x, p)
     dt = time.perf_counter() - t0
-    n = int(max(probe, min(2000000, target_seconds / (dt / probe))))
-    x = S.make_signal("tonal", 0, n * hop)[None, :]
+    n = int(max(probe, min(avail, target_seconds / (dt / probe))))
+    x = np.ascontiguousarray(x_prefix[:1, :n * hop])
     p = np.full(n, pitch, np.float32)
     o = oracle_lib.Oracle(fft, hop, 1)
     t0 = time.perf_counter()
     o.process_planar(x, p)
     dt = time.perf_counter() - t0
     out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": f"{n} frames of mono {fft}/{hop} pf={pitch} tonal+noise input, single thread, {dt:.1f} s",
+           "sample": f"the first {n} hops of channel 0 of {what} (downloaded from HBM), mono {fft}/{hop} pf={pitch}, single thread, {dt:.1f} s",
            "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
     # the reference itself (unmodified JS bundle under Node, one thread) cannot travel to the GPU box; tools/time_reference.js timed it
     # next to this port on the same core of the build container -> port/reference ratio -> estimate for this host
@@ -116,7 +117,7 @@ def cpu_baseline(fft, hop, pitch, target_seconds=12.0):
 
 
 def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmup, label, local_rank, frames_per_chunk=0,
-            pitch_stride=0, ch_per_stream=1, parity_hops=0, seed=0, repeats=1):
+            pitch_stride=0, ch_per_stream=1, parity_hops=0, seed=0, repeats=1, keep_prefix_hops=0):
     """One workload: resident input, `warmup` + `steps` launches bracketed by HIP events on the launch stream.  Returns a dict."""
     import numpy as np
     from phaze_amd import shard
@@ -173,7 +174,7 @@ def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmu
             el = time.perf_counter() - t0
             km = ev0.elapsed_time(ev1) / steps                # HIP events on the launch stream: average launch duration
             regions.append(tuple(shard.reduce_max([el, km], dist, dev)))      # MAX over ranks
-    # the line reports the MEDIAN region (box noise is 1-2 % between regions, 3-4 % between boxes), all regions are listed next to it
+    # the line reports the MEDIAN region (box noise is 1-2 % between regions, 3-4 % between boxes); all regions, their min and max are listed next to it
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     elapsed, kernel_ms = regions[order[len(order) // 2]]
     info = pv.info()
@@ -181,10 +182,86 @@ def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmu
     frames = nch * T
     alg_bytes = frames * 2 * hop * 4                          # 2*hop*4 B per channel-frame
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    prefix = x[:1, :min(keep_prefix_hops, T) * hop].cpu().numpy() if keep_prefix_hops else None
     del x, y
     return {"label": label, "frames_per_step_rank": frames, "elapsed": elapsed, "kernel_ms": kernel_ms, "info": info,
-            "alg_bytes": alg_bytes, "achieved_gbs": achieved, "parity": parity,
+            "alg_bytes": alg_bytes, "achieved_gbs": achieved, "parity": parity, "x_prefix": prefix,
             "regions_ms_per_step": [r[0] / steps * 1e3 for r in regions], "regions_kernel_ms": [r[1] for r in regions]}
+
+
+def pcie_bandwidth(torch, dev, nbytes=256 << 20, reps=4):
+    """Pinned hipMemcpy bandwidth of this box, GB/s: host->device and device->host alone, and each way with BOTH directions in flight (what a
+    pipelined host-buffer batch can reach at best).  Measured in the same run as the host-buffer lines that are priced against it."""
+    n = nbytes // 4
+    ha, hb = torch.empty(n, dtype=torch.float32).pin_memory(), torch.empty(n, dtype=torch.float32).pin_memory()
+    da, db = torch.empty(n, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.float32, device=dev)
+    ha.fill_(1.0)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+    def run(up, down):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            if up:
+                with torch.cuda.stream(s1):
+                    da.copy_(ha, non_blocking=True)
+            if down:
+                with torch.cuda.stream(s2):
+                    hb.copy_(db, non_blocking=True)
+        torch.cuda.synchronize()
+        return reps * nbytes / (time.perf_counter() - t0) / 1e9
+    run(True, True)
+    return {"h2d_alone": run(True, False), "d2h_alone": run(False, True), "each_way_concurrent": run(True, True), "bytes": nbytes}
+
+
+def host_batch(torch, phaze_amd, dev, fft, hop, nch, T, cps, pitch_rows, steps, local_rank, bw, workload):
+    """The PRODUCT boundary with host pointers (what a Node / C host calls): pv_process_batch on buffers in page-locked memory (pv_host_alloc),
+    wall clock around `steps` synchronous calls, PCIe both ways included.  Checked bit for bit against the HBM-resident form of the same batch."""
+    import numpy as np
+    n = T * hop
+    xd = synth_input(torch, nch, n, dev, seed=3)
+    x, y = phaze_amd.pinned_empty((nch, n)), phaze_amd.pinned_empty((nch, n))
+    x[:] = xd.cpu().numpy()
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T, device_id=local_rank)
+    pv.process_batch(x, pitch_rows, channels_per_stream=cps, out=y)              # warm-up: streams, events, first launches
+    pv.reset()
+    pv.process_batch(x, pitch_rows, channels_per_stream=cps, out=y)
+    first = y.copy()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pv.process_batch(x, pitch_rows, channels_per_stream=cps, out=y)
+    dt = time.perf_counter() - t0
+    pv.close()
+    # the same batch, resident: one launch on device buffers from a fresh handle
+    ref = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, device_id=local_rank)
+    yd = torch.empty_like(xd)
+    pd = torch.from_numpy(np.ascontiguousarray(pitch_rows)).to(dev)
+    ref.process_batch_device(xd.data_ptr(), yd.data_ptr(), nch, T, n, pd.data_ptr(), pitch_rows.shape[1] if pitch_rows.ndim == 2 else 0, cps)
+    ref.synchronize()
+    ref.close()
+    same = bool(np.array_equal(first.view(np.uint32), yd.cpu().numpy().view(np.uint32)))
+    gbs = steps * nch * n * 4 / dt / 1e9
+    return {"workload": workload, "value": steps * nch * T / dt, "unit": "frames/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "form": "pv_process_batch on host pointers in page-locked memory (pv_host_alloc), synchronous calls, wall clock: PCIe both ways + kernels, pipelined inside the call",
+            "gbytes_per_s_each_way": gbs, "pcie_frac": gbs / bw["each_way_concurrent"], "pcie_pinned_memcpy_gbs": bw,
+            "bit_equal_to_resident_form": same}
+
+
+def node_sharded_line(bw, streams, cps, fft, hop, T, steps):
+    """The same share through the Node.js boundary: tools/bench_node_sharded.js (ShardedPhaseVocoder.processInPlace -> N-API -> pv_process_batch)."""
+    import shutil
+    node = shutil.which("node")
+    if not node or not os.path.exists(os.path.join(ROOT, "phaze_amd", "node", "phaze_napi.node")):
+        return None
+    r = subprocess.run([node, os.path.join(ROOT, "tools", "bench_node_sharded.js"), "--gpus", "1", "--streams", str(streams), "--channels", str(cps), "--fft", str(fft),
+                        "--hop", str(hop), "--hops", str(T), "--steps", str(steps)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    if r.returncode != 0:
+        return {"workload": "C4 share through sharded.js", "error": (r.stderr or r.stdout)[-400:]}
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"workload": f"BASELINE configs[3], one GPU's share through the Node.js boundary (phaze_amd/node/sharded.js): {j['config']['workload']}",
+            "value": j["value"], "unit": "frames/s", "steps": j["steps"], "ms_per_step": j["ms_per_step"], "form": j["form"],
+            "gbytes_per_s_each_way": j["gbytes_per_s_each_way"], "pcie_frac": j["gbytes_per_s_each_way"] / bw["each_way_concurrent"], "node": j["node"],
+            "shards_in_flight_together": j["shards_in_flight_together"]}
 
 
 def synth_stream(torch, nch, n0, n1, device):
@@ -326,7 +403,10 @@ def main():
     ap.add_argument("--pitch", type=float, default=1.5)
     ap.add_argument("--pitch-sweep", action="store_true", help="pitchFactor swept 0.5->2.0 per hop, period 64 hops (BASELINE configs[4]'s schedule) instead of --pitch")
     ap.add_argument("--frames-per-chunk", type=int, default=0)
-    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps launches each; the line reports the median region and lists all")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps launches each; the line reports the median region and lists all (min / median / max)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend under torch.distributed.run.  nccl (= RCCL) is what the driver runs; gloo exists for ONE test that puts two ranks on one "
+                         "GPU (RCCL refuses that) to execute the multi-rank code paths end to end (tests/test_gpu_multirank.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-config lines and the latency histogram (profiling runs)")
     ap.add_argument("--allow-lib-override", action="store_true", help="accept PHAZE_LIB (A/B builds of the same ABI); recorded in the line")
@@ -334,6 +414,8 @@ def main():
     ap.add_argument("--time-shard", action="store_true",
                     help="ONE stream of --hops hops split along the time axis over the ranks (strong scaling; single-stream configs C2 / C3 on N GPUs)")
     ap.add_argument("--simulate-shard", default="", help="with --time-shard on ONE GPU: measure the span of rank r of w ('r/w') without a process group")
+    ap.add_argument("--sg-streams", type=int, default=0, help="with --scatter-gather: number of streams rank 0 scatters (default: one per rank; a count the ranks "
+                                                              "do not divide takes the ragged send / recv branch)")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="N > 1: all streams start on rank 0, are scattered over RCCL, and the results gathered back (reported separately, never in value)")
     args = ap.parse_args()
@@ -369,7 +451,10 @@ def main():
     if world > 1 or "RANK" in os.environ:          # under torch.distributed.run (also at world size 1: exercises RCCL)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     fft, hop, nch, T = args.fft, args.hop, args.channels, args.hops
     from phaze_amd import shard
@@ -407,18 +492,25 @@ def main():
     else:
         args.pitch_num = args.pitch
     head = measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch, args.steps, args.warmup, "headline", local_rank,
-                   frames_per_chunk=args.frames_per_chunk, parity_hops=96 if rank == 0 else 0, seed=rank, repeats=args.repeats)
+                   frames_per_chunk=args.frames_per_chunk, parity_hops=96 if rank == 0 else 0, seed=rank, repeats=args.repeats,
+                   keep_prefix_hops=(1 << 19) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else 0)
 
     sg_ms = None
     if args.scatter_gather and dist is not None:             # also at world size 1 under torchrun: the collectives still run through RCCL
         # the only exchange a multi-GPU job can have: whole streams out from rank 0 and results back (outside the timed region)
-        x_all = (torch.stack([synth_input(torch, nch, T * hop, dev, seed=r) for r in range(world)]) if rank == 0
+        nsg = args.sg_streams if args.sg_streams > 0 else world
+        x_all = (torch.stack([synth_input(torch, nch, T * hop, dev, seed=r) for r in range(nsg)]) if rank == 0
                  else torch.empty((0, nch, T * hop), device=dev, dtype=torch.float32))
         torch.cuda.synchronize(); dist.barrier(); t_sg = time.perf_counter()
-        xs = shard.scatter_streams(x_all, world, dist)
-        ys = shard.gather_streams(xs, world, dist)
+        xs = shard.scatter_streams(x_all, nsg, dist)
+        ys = shard.gather_streams(xs, nsg, dist)
         torch.cuda.synchronize(); dist.barrier()
         sg_ms = shard.reduce_max([(time.perf_counter() - t_sg) * 1e3], dist, dev)[0]
+        sg_ok = None
+        if rank == 0:                                                     # the round trip returns every stream to its place, untouched
+            sg_ok = bool(ys.shape == x_all.shape and torch.equal(ys, x_all))
+        sg_mine = len(shard.stream_partition(nsg, world, rank))
+        assert xs.shape[0] == sg_mine
         del x_all, xs, ys
 
     info = head["info"]
@@ -461,17 +553,25 @@ def main():
             "parity_rms_vs_oracle": head["parity"],
             "timed_regions": {"count": len(head["regions_kernel_ms"]), "steps_each": args.steps, "reported": "median region",
                               "ms_per_step": head["regions_ms_per_step"], "kernel_ms": head["regions_kernel_ms"],
-                              "kernel_ms_min": min(head["regions_kernel_ms"]), "kernel_ms_max": max(head["regions_kernel_ms"])},
+                              "kernel_ms_min": min(head["regions_kernel_ms"]), "kernel_ms_median": sorted(head["regions_kernel_ms"])[len(head["regions_kernel_ms"]) // 2],
+                              "kernel_ms_max": max(head["regions_kernel_ms"]),
+                              "ms_per_step_min": min(head["regions_ms_per_step"]), "ms_per_step_max": max(head["regions_ms_per_step"])},
         }
-        if requested != world:
-            out["requested_gpus"] = requested
-            out["replicas_measured"] = world
-            out["note_gpus"] = (f"{requested} GPUs requested, {ndev} visible: {world} replica(s) measured; streams are independent shards with no "
-                                "inter-GPU dependency (SURVEY 8e), nothing is extrapolated")
+        distinct = min(world, ndev)                                      # LOCAL_RANK % ndev: more ranks than visible devices share them
+        if requested != world or distinct != world:
+            out["n_gpus"] = distinct
+            out["requested_gpus"] = max(requested, world)
+            out["replicas_measured"] = distinct
+            out["ranks"] = world
+            out["note_gpus"] = (f"{max(requested, world)} GPUs requested, {ndev} visible: {distinct} replica(s) measured"
+                                + (f" ({world} ranks share them: `value` is what those devices delivered together, NOT a {world}-GPU rate)" if distinct != world else "")
+                                + "; streams are independent shards with no inter-GPU dependency (SURVEY 8e), nothing is extrapolated; no scaling curve was measured")
         if os.environ.get("PHAZE_LIB"):
             out["lib_override"] = os.environ["PHAZE_LIB"]
         if sg_ms is not None:
             out["scatter_gather_ms"] = sg_ms        # one step's input out + back over RCCL, outside the timed region
+            out["scatter_gather"] = {"streams": nsg, "branch": "scatter / gather (equal shares)" if nsg % world == 0 else "send / recv (ragged shares)",
+                                     "round_trip_intact": sg_ok, "rank0_streams": sg_mine}
         if dist is not None:
             out["dist_backend"] = dist.get_backend()          # "nccl" = RCCL on ROCm: barrier, all_reduce(MAX) of the timing, scatter / gather
 
@@ -507,6 +607,19 @@ def main():
         add("sweep", f"headline shape with pitchFactor swept 0.5->2.0 per hop (period 64 hops): mono 48 kHz FFT=1024 hop=256, 1 ch x {T2} hops resident",
             1024, 256, 1, T2, sw, steps=12, warm=4)
         out["configs"] = extras
+        # ---- the product boundary with HOST pointers (round-3 verdict, Weak 4): what a Node / C caller that owns host memory gets, PCIe included.
+        #      Never `value`; each line carries the fraction of this box's pinned hipMemcpy bandwidth (both directions busy) it reaches. ----
+        bw = pcie_bandwidth(torch, dev)
+        hb = []
+        rows4 = np.stack([np.full(64, 1.25, np.float32) for _ in range(128)])
+        hb.append(host_batch(torch, phaze_amd, dev, 4096, 1024, 1024, 64, 8, rows4, 5, local_rank, bw,
+                             "BASELINE configs[3], one GPU's share through pv_process_batch (host pointers): 128 streams x 8 ch, FFT=4096 hop=1024, 64 hops per call, pitchFactor 1.25"))
+        hb.append(host_batch(torch, phaze_amd, dev, 1024, 256, 8, 1 << 15, 8, np.full((1, 1 << 15), 1.5, np.float32), 5, local_rank, bw,
+                             f"headline shape through pv_process_batch (host pointers): 8-ch 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 8 ch x {1 << 15} hops per call"))
+        nl = node_sharded_line(bw, 128, 8, 4096, 1024, 64, 5)
+        if nl:
+            hb.append(nl)
+        out["host_buffer_configs"] = hb
         out["latency_us"] = latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True)
         # the headline shape as a stream: launch per quantum, and on the resident kernel (opt-in flag of the C ABI / `processorOptions.flags` in Node)
         out["latency_us_headline_shape"] = {"launch": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, fs=48000.0),
@@ -514,7 +627,8 @@ def main():
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(fft, hop, args.pitch_num)
+            out["cpu_baseline"] = cpu_baseline(fft, hop, args.pitch_num, head["x_prefix"],
+                                               f"the bench input (synth_input seed 0: three partials + a -36 dB noise floor, {nch} ch x {T} hops)")
         if args.pcie:
             import signals as S
             Tp = min(T, 1 << 14)

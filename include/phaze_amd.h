@@ -44,8 +44,9 @@ enum {
 typedef struct pv_handle pv_handle;
 
 /* Version of this header's binary interface (struct layouts + semantics).  pv_abi_version() returns the value the LIBRARY was built with;
- * 2 = round 3: pv_config carries its own size, unknown pv_config.flags bits are rejected, PV_FLAG_PERSISTENT_STREAM. */
-#define PV_ABI_VERSION 2
+ * 2 = round 3: pv_config carries its own size, unknown pv_config.flags bits are rejected, PV_FLAG_PERSISTENT_STREAM;
+ * 3 = round 4: pv_host_alloc / pv_host_free (page-locked host buffers: pv_process_batch pipelines them), PV_FLAG_TEST_NO_HDP_FLUSH. */
+#define PV_ABI_VERSION 3
 
 /* Construction options.  Replaces `new PhaseVocoderProcessor(options)` (phase-vocoder.js:24-43,
  * ola-processor.js:7-34).  The reference hard-codes fft_size 2048 (phase-vocoder.js:6) and hop 128
@@ -91,7 +92,11 @@ enum {
                                   * reset, pv_synchronize).  Same kernel code, same bits as the launch-per-quantum form.  Off by default: while resident, a
                                   * device-wide synchronize of another user of the GPU waits for that idle time-out, and the handle should keep its own
                                   * stream (pv_set_stream to a stream shared with other work would queue that work behind the resident kernel) */
-    PV_FLAG_ALL = 63             /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
+    PV_FLAG_TEST_NO_HDP_FLUSH = 64, /* TEST HOOK, never needed in production: behave as if the device did not expose its HDP flush register
+                                  * (hipDeviceAttributeHdpMemFlushCntl).  The library then must not hand quanta over through the BAR -- a host store
+                                  * could still sit in the device's host data path when the kernel reads -- and falls back to the pinned-memory
+                                  * form on its own; tests/test_gpu_stream_forms.py runs every hand-over form under this bit */
+    PV_FLAG_ALL = 127            /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
 };
 
 typedef struct pv_info {
@@ -170,10 +175,21 @@ PV_API int pv_process_end(pv_handle *h, float *const *out);
  * pitchFactor of hop m; with pitch_stride != 0 channel c uses the row of its stream,
  * pitch[(c / channels_per_stream) * pitch_stride + m] (independent processors batched together).
  * State (history, accumulator tail, timeCursor) carries across calls exactly as if process() had been
- * called hop by hop.  Host-pointer variant: synchronous, stages through device memory. */
+ * called hop by hop.  Host-pointer variant: synchronous, stages through device memory.  When `in` and `out` are page-locked memory
+ * (pv_host_alloc below, or anything hipHostMalloc / hipHostRegister produced) a batch of 4 MB or more is PIPELINED: cut into up to 16 pieces
+ * -- groups of whole streams when there are enough, else spans of hops -- with piece k+1 on its way to the device while piece k is in the
+ * kernel and piece k-1 on its way back (DMA both ways at once; the results are bit-identical to the unpipelined call).  Pageable buffers
+ * work as before (the runtime stages them synchronously: several times slower). */
 PV_API int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int32_t nhops,
                             int64_t ch_stride, const float *pitch, int32_t pitch_stride,
                             int32_t channels_per_stream);
+
+/* Page-locked host memory for the batch call above (hipHostMalloc, visible to every device of the process): what a host that owns its audio
+ * buffers should put them in -- the N-API addon hands it out as external ArrayBuffers (native.allocPinned), so that a Node host writes its
+ * streams in place.  Replaces the `new Float32Array(...)` a caller of OLAProcessor.process owns (ola-processor.js:159-171 receives host
+ * arrays).  No handle needed; pv_host_free(NULL) is a no-op. */
+PV_API int pv_host_alloc(size_t bytes, void **out);
+PV_API int pv_host_free(void *p);
 
 /* Device-pointer variant: in/out/pitch are DEVICE pointers (HBM-resident), the launch is asynchronous on
  * the handle's stream (pv_set_stream / pv_synchronize).  This is the form bench.py times. */

@@ -21,7 +21,7 @@ EXPORTS = [
     "pv_create", "pv_destroy", "pv_last_error", "pv_status_string", "pv_get_info", "pv_reset", "pv_reset_channels",
     "pv_get_time_cursor", "pv_set_time_cursor", "pv_process", "pv_process_batch", "pv_process_batch_device",
     "pv_set_stream", "pv_synchronize", "pv_debug_frame", "pv_export_state", "pv_import_state", "pv_abi_version",
-    "pv_process_begin", "pv_process_end", "pv_device_count",
+    "pv_process_begin", "pv_process_end", "pv_device_count", "pv_host_alloc", "pv_host_free",
 ]
 
 
@@ -40,11 +40,12 @@ def make_config(fft_size, hop_size, max_channels=1, max_hops=1, device_id=0, fra
     return _Config(C.sizeof(_Config), fft_size, hop_size, max_channels, max_hops, device_id, frames_per_chunk, flags)
 
 
-ABI_VERSION = 2          # PV_ABI_VERSION of include/phaze_amd.h this binding was written against (checked at load time)
+ABI_VERSION = 3          # PV_ABI_VERSION of include/phaze_amd.h this binding was written against (checked at load time)
 
 
 # pv_config.flags (include/phaze_amd.h): explicit A/B switches; the library reads no environment variables
 FLAG_GENERIC_KERNEL, FLAG_STREAM_COPY, FLAG_WORKGROUP_KERNEL, FLAG_STREAM_EVENT_WAIT, FLAG_STREAM_PINNED_INPUT, FLAG_PERSISTENT_STREAM = 1, 2, 4, 8, 16, 32
+FLAG_TEST_NO_HDP_FLUSH = 64      # test hook (tests/test_gpu_stream_forms.py)
 
 
 class _Info(C.Structure):
@@ -110,6 +111,8 @@ def load_library():
     L.pv_process_begin.argtypes = [vp, C.POINTER(fp), C.c_int32, C.c_int32, C.c_float]
     L.pv_process_end.argtypes = [vp, C.POINTER(fp)]
     L.pv_device_count.argtypes = [C.POINTER(C.c_int32)]
+    L.pv_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.pv_host_free.argtypes = [vp]
     L.pv_abi_version.argtypes = []
     if L.pv_abi_version() != ABI_VERSION:
         raise PvError(PV_ERR_ARGUMENT, f"{_LIB_PATH} has PV_ABI_VERSION {L.pv_abi_version()}, this binding expects {ABI_VERSION}: rebuild the library")
@@ -119,6 +122,38 @@ def load_library():
 
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class _PinnedBlock:
+    """Owner of one pv_host_alloc block: frees it when the last numpy view is gone."""
+
+    def __init__(self, nbytes):
+        self._L = load_library()
+        self.ptr = C.c_void_p()
+        rc = self._L.pv_host_alloc(max(int(nbytes), 1), C.byref(self.ptr))
+        if rc != PV_OK:
+            raise PvError(rc, self._L.pv_last_error(None).decode())
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ptr.value:
+                self._L.pv_host_free(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """numpy array in page-locked host memory (pv_host_alloc): process_batch() pipelines batches that live in such arrays (DMA both ways at
+    once).  The memory is released when the array and every view of it are gone."""
+    shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if shape else 1
+    blk = _PinnedBlock(n * dt.itemsize)
+    buf = (C.c_char * max(n * dt.itemsize, 1)).from_address(blk.ptr.value)
+    buf._pv_owner = blk                              # the ctypes object keeps the block alive; numpy keeps the ctypes object alive (base)
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
 
 
 class PhaseVocoder:
@@ -222,8 +257,9 @@ class PhaseVocoder:
         return True
 
     # -- the hot call, batch forms --
-    def process_batch(self, x, pitch, channels_per_stream=0):
-        """x: float32[nch, nhops*hop] (host); pitch: float32[nhops] or [nstreams, nhops]. Returns y like x."""
+    def process_batch(self, x, pitch, channels_per_stream=0, out=None):
+        """x: float32[nch, nhops*hop] (host); pitch: float32[nhops] or [nstreams, nhops]. Returns y like x (written into `out` when given:
+        with x and out in page-locked memory -- pinned_empty() -- the call is pipelined, see pv_process_batch)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         nch, n = x.shape
         nhops = n // self.hop_size
@@ -232,7 +268,11 @@ class PhaseVocoder:
         stride = 0
         if pitch.ndim == 2:
             stride = pitch.shape[1]
-        y = np.empty_like(x)
+        if out is not None:
+            assert out.shape == x.shape and out.dtype == np.float32 and out.flags.c_contiguous
+            y = out
+        else:
+            y = np.empty_like(x)
         self._check(self._L.pv_process_batch(self._h, _fp(x), _fp(y), nch, nhops, n, _fp(pitch), stride, channels_per_stream or 1))
         return y
 

@@ -23,6 +23,7 @@
 namespace {
 constexpr uint32_t kMagic = 0x50564d49u;   // 'PVMI'
 constexpr int kHdrFloats = 16;             // pinned staging header: [0] = pitchFactor
+constexpr int kMaxPieces = 16;             // pieces a pipelined host-buffer batch is cut into at most
 thread_local char g_create_err[256] = "";
 }  // namespace
 
@@ -39,6 +40,9 @@ struct pv_handle {
     float *d_hist[2], *d_acc[2];
     int cur;
     float *d_stage_in, *d_stage_out, *d_pitch;   // host-buffer batch staging
+    hipStream_t s_in, s_out;                     // pipelined host-buffer batch: H2D of piece k+1 || kernel of piece k || D2H of piece k-1 (created on first use)
+    hipEvent_t ev_in[kMaxPieces], ev_k[kMaxPieces];
+    bool pipe_ready;
     float *h_pin;                                // pinned: [hdr | max_channels*hop in | max_channels*hop out]
     float *d_quantum;                            // device twin of h_pin
     float *d_pin_mapped;                         // device view of h_pin (zero-copy streaming quantum); null = stage through d_quantum
@@ -142,18 +146,20 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
     return best < 1 ? 1 : best;
 }
 
-// One launch over [nch] channel slots x [nhops] hops; flips the state ping-pong and advances timeCursor.
-int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops, long ch_stride, const float *d_pitch,
-              int pitch_stride, int ch_per_stream, bool commit, int dbg_ch, unsigned done_seq = 0)
+// One launch over the channel slots [ch0, ch0 + nch) x [nhops] hops, reading the current half of the state ping-pong and writing the other one.
+// d_in / d_out / d_pitch are the pointers of slot ch0 (the caller has applied the offsets); ch0 only places the state.  Nothing is committed.
+int launch_chain(pv_handle *h, const float *d_in, float *d_out, int ch0, int nch, int nhops, long ch_stride, const float *d_pitch,
+                 int pitch_stride, int ch_per_stream, bool chunked, int dbg_ch, unsigned done_seq)
 {
     PvKernelParams p;
     memset(&p, 0, sizeof p);
     p.in = d_in; p.out = d_out; p.ch_stride = ch_stride;
     p.nhops = nhops; p.hop = h->hop;
-    p.frames_per_chunk = commit ? pick_frames_per_chunk(h, nch, nhops) : nhops;
+    p.frames_per_chunk = chunked ? pick_frames_per_chunk(h, nch, nhops) : nhops;
     p.pitch = d_pitch; p.pitch_stride = pitch_stride; p.ch_per_stream = ch_per_stream > 0 ? ch_per_stream : 1;
-    p.hist_in = h->d_hist[h->cur]; p.hist_out = h->d_hist[h->cur ^ 1];
-    p.acc_in = h->d_acc[h->cur];   p.acc_out = h->d_acc[h->cur ^ 1];
+    const size_t soff = (size_t)ch0 * h->L;
+    p.hist_in = h->d_hist[h->cur] + soff; p.hist_out = h->d_hist[h->cur ^ 1] + soff;
+    p.acc_in = h->d_acc[h->cur] + soff;   p.acc_out = h->d_acc[h->cur ^ 1] + soff;
     p.t0_mod_n = (int)(h->time_cursor & (int64_t)(h->N - 1));
     p.tw64 = h->d_tw64; p.tw32 = h->d_tw32; p.hann = h->d_hann;
     p.dbg_ch = -1; p.dbg_frame = -1;
@@ -176,33 +182,68 @@ int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops,
                       : pv_launch_chain(h->log2n, p, nch, nchunks, h->stream);
     }
     if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
-    if (commit) {
-        // channels outside [0, nch) keep their state: copy them across the ping-pong flip
-        if (nch > h->used_channels) h->used_channels = nch;
-        if (nch < h->used_channels && h->L > 0) {
-            const size_t off = (size_t)nch * h->L, cnt = (size_t)(h->used_channels - nch) * h->L * sizeof(float);
-            HIPCHK(h, hipMemcpyAsync(h->d_hist[h->cur ^ 1] + off, h->d_hist[h->cur] + off, cnt, hipMemcpyDeviceToDevice, h->stream));
-            HIPCHK(h, hipMemcpyAsync(h->d_acc[h->cur ^ 1] + off, h->d_acc[h->cur] + off, cnt, hipMemcpyDeviceToDevice, h->stream));
-        }
-        h->cur ^= 1;
-        h->time_cursor += (int64_t)nhops * h->hop;
-    }
     return PV_OK;
 }
 
-// ---- resident streaming kernel (PV_FLAG_PERSISTENT_STREAM) ----
-// Asks the resident waves to leave and waits for them: required before anything else is put on the handle's stream (it would queue behind them).
-int resident_stop(pv_handle *h)
+// What a completed pass over the slots [0, nch) x [nhops] hops commits: the ping-pong flip (slots outside the pass keep their state: copied
+// across), timeCursor.
+int commit_chain(pv_handle *h, int nch, int nhops)
 {
-    if (!h->resident_on) return PV_OK;
-    h->h_ctl[4] = 1u;
+    if (nch > h->used_channels) h->used_channels = nch;
+    if (nch < h->used_channels && h->L > 0) {
+        const size_t off = (size_t)nch * h->L, cnt = (size_t)(h->used_channels - nch) * h->L * sizeof(float);
+        HIPCHK(h, hipMemcpyAsync(h->d_hist[h->cur ^ 1] + off, h->d_hist[h->cur] + off, cnt, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_acc[h->cur ^ 1] + off, h->d_acc[h->cur] + off, cnt, hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->cur ^= 1;
+    h->time_cursor += (int64_t)nhops * h->hop;
+    return PV_OK;
+}
+
+// One launch over [nch] channel slots x [nhops] hops; flips the state ping-pong and advances timeCursor.
+int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops, long ch_stride, const float *d_pitch,
+              int pitch_stride, int ch_per_stream, bool commit, int dbg_ch, unsigned done_seq = 0)
+{
+    const int rc = launch_chain(h, d_in, d_out, 0, nch, nhops, ch_stride, d_pitch, pitch_stride, ch_per_stream, commit, dbg_ch, done_seq);
+    if (rc != PV_OK || !commit) return rc;
+    return commit_chain(h, nch, nhops);
+}
+
+// Is this host pointer page-locked memory the HIP runtime knows (pv_host_alloc, hipHostMalloc, hipHostRegister)?  Only such memory can be the
+// end point of an asynchronous copy; pageable memory is staged by the runtime synchronously.
+bool host_pinned(const void *ptr)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// ---- resident streaming kernel (PV_FLAG_PERSISTENT_STREAM) ----
+// One word handed to the resident waves: everything written before it (input, pitchFactor, parameters) is in memory first, and the word itself leaves
+// the write-combining buffer and the device's host data path now, not when something else happens to drain them (the control block may live in
+// DEVICE memory behind the BAR).  Used for the sequence words of a quantum AND for the stop word.
+void resident_publish(pv_handle *h, volatile unsigned *word, unsigned value)
+{
     std::atomic_thread_fence(std::memory_order_seq_cst);
 #if defined(__x86_64__)
     _mm_sfence();
 #endif
+    *word = value;
+#if defined(__x86_64__)
+    _mm_sfence();
+#endif
+    if (h->resident_bar && h->hdp_flush) *h->hdp_flush = 1u;
+}
+
+// Asks the resident waves to leave and waits for them: required before anything else is put on the handle's stream (it would queue behind them).
+int resident_stop(pv_handle *h)
+{
+    if (!h->resident_on) return PV_OK;
+    resident_publish(h, h->h_ctl + 4, 1u);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->h_ctl[4] = 0u;
+    resident_publish(h, h->h_ctl + 4, 0u);
     h->resident_on = false;
     return PV_OK;
 }
@@ -224,7 +265,9 @@ int resident_start(pv_handle *h, unsigned last_seq)
     p.done = h->d_done; p.done_seq = last_seq;
     p.ctl = h->d_ctl;
     p.in_cached = h->resident_in_bar ? 1 : 0;
-    h->h_ctl[4] = 0u;
+    resident_publish(h, h->h_ctl + 4, 0u);
+    // stale completion words must not match a future 16-bit sequence number (a slot unused for exactly 65535 quanta)
+    for (int c = 0; c < h->max_channels; c++) h->h_done[c] = 0u;
     const hipError_t e = h->resident_wg ? pv_launch_wg_resident(h->log2n, p, h->max_channels, h->stream)
                        : h->use_wave2k ? pv_launch_wave2k_resident(p, h->max_channels, h->stream) : pv_launch_wave_resident(p, h->max_channels, h->stream);
     if (e != hipSuccess) return fail_hip(h, e, "resident kernel launch");
@@ -377,11 +420,16 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) != hipSuccess) { large_bar = 0; (void)hipGetLastError(); }
         h->bar_input = large_bar == 1 && h->d_pin_mapped != nullptr && !(cfg->flags & PV_FLAG_STREAM_PINNED_INPUT);
         if (h->bar_input) {
-            // Host stores through the BAR pass the device's HDP block; the runtime maps its flush register for exactly this use (the attribute call
-            // stores a POINTER through its int* argument).  One more posted write per quantum, behind the data in PCIe order.
+            // Host stores through the BAR pass the device's HDP block; the runtime maps its flush register for exactly this use.  The attribute
+            // call stores a POINTER (8 bytes) through its int* argument -- that is how ROCm defines hipDeviceAttributeHdpMemFlushCntl; `reg` is a
+            // full pointer-sized object, so nothing is written out of bounds.  One more posted write per quantum, behind the data in PCIe order.
             unsigned *reg = nullptr;
-            if (hipDeviceGetAttribute(reinterpret_cast<int *>(&reg), hipDeviceAttributeHdpMemFlushCntl, h->device) == hipSuccess) h->hdp_flush = reg;
+            const bool have = !(cfg->flags & PV_FLAG_TEST_NO_HDP_FLUSH) &&
+                              hipDeviceGetAttribute(reinterpret_cast<int *>(&reg), hipDeviceAttributeHdpMemFlushCntl, h->device) == hipSuccess && reg != nullptr;
             (void)hipGetLastError();
+            // Without the flush register a host store through the BAR may still sit in the HDP when the kernel reads: no BAR hand-over then, the quantum
+            // is read from pinned host memory (the PV_FLAG_STREAM_PINNED_INPUT form) and the resident kernel keeps its control block there as well.
+            if (have) h->hdp_flush = reg; else h->bar_input = false;
         }
     }
     if (h->d_pin_mapped && !(cfg->flags & PV_FLAG_STREAM_EVENT_WAIT)) {
@@ -439,6 +487,11 @@ int pv_destroy(pv_handle *h)
     (void)hipSetDevice(h->device);
     (void)resident_stop(h);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    if (h->pipe_ready) {
+        (void)hipStreamSynchronize(h->s_in); (void)hipStreamSynchronize(h->s_out);
+        for (int i = 0; i < kMaxPieces; i++) { (void)hipEventDestroy(h->ev_in[i]); (void)hipEventDestroy(h->ev_k[i]); }
+        (void)hipStreamDestroy(h->s_in); (void)hipStreamDestroy(h->s_out);
+    }
     (void)hipFree(h->d_tw64); (void)hipFree(h->d_tw32); (void)hipFree(h->d_hann);
     for (int i = 0; i < 2; i++) { (void)hipFree(h->d_hist[i]); (void)hipFree(h->d_acc[i]); }
     (void)hipFree(h->d_stage_in); (void)hipFree(h->d_stage_out); (void)hipFree(h->d_pitch);
@@ -605,10 +658,13 @@ int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t 
         if (h->d_pin_mapped && h->h_ctl) {
             // resident kernel: no launch -- start the waves if none are there (first quantum, or they left after their idle time-out), then publish the
             // quantum: its parameters first, the sequence number last
+            // Long pause: the waves count their idle polls one by one and leave after ~50 ms, NOT at the same instant -- a quantum published while some
+            // have left and others still poll would be picked up by the survivors only (they reset their count, the kernel never ends, the departed
+            // channels never complete).  So after any pause that comes near the time-out the waves are told to leave, waited for, and started afresh.
             const auto now = std::chrono::steady_clock::now();
-            if (h->resident_on && now - h->last_quantum > std::chrono::milliseconds(20)) {   // long pause: the waves may have left
-                if (hipStreamQuery(h->stream) == hipSuccess) h->resident_on = false;
-                (void)hipGetLastError();
+            if (h->resident_on && now - h->last_quantum > std::chrono::milliseconds(20)) {
+                const int rc = resident_stop(h);
+                if (rc != PV_OK) return rc;
             }
             h->last_quantum = now;
             if (!h->resident_on) { const int rc = resident_start(h, h->quantum_seq); if (rc != PV_OK) return rc; }
@@ -617,17 +673,7 @@ int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t 
             h->quantum_seq = seq;
             if (nch > h->used_channels) h->used_channels = nch;
             const unsigned common = seq | ((unsigned)h->cur << 23) | ((unsigned)((h->time_cursor / hop) % h->R) << 24);
-            auto publish = [&](volatile unsigned *word, unsigned value) {
-                std::atomic_thread_fence(std::memory_order_seq_cst);        // inputs, pitch and parameters are in memory before the waves see the word
-#if defined(__x86_64__)
-                _mm_sfence();
-#endif
-                *word = value;
-#if defined(__x86_64__)
-                _mm_sfence();                                                // (through the BAR: out of the write-combining buffer now, not when it fills)
-#endif
-                if (h->resident_bar && h->hdp_flush) *h->hdp_flush = 1u;
-            };
+            auto publish = [&](volatile unsigned *word, unsigned value) { resident_publish(h, word, value); };
             if (piecewise) {
                 // one word per channel slot: the workgroup of channel 0 is on its frame while the host still copies channel 1's input, and so on
                 // (pv_process_end collects the outputs in the same order).  Slots that hold state but are not in this quantum carry it (count 0).
@@ -699,8 +745,10 @@ int pv_process_end(pv_handle *h, float *const *out)
                 const auto waited = std::chrono::steady_clock::now() - t0;
                 if (h->h_ctl && h->resident_on && waited > std::chrono::milliseconds(2) && hipStreamQuery(h->stream) == hipSuccess) {
                     // the resident waves left (idle time-out) just as this quantum was published: start new ones, they pick it up
+                    // (a PARTIAL leave cannot happen here: pv_process_begin restarts the waves after every pause of 20 ms or more)
                     h->resident_on = false;
                     if (resident_start(h, seq - 1u) != PV_OK) break;
+                    for (int k = 0; k < c && k < 64; k++) if (h->copied[k]) h->h_done[k] = seq;   // resident_start cleared the words of channels already collected
                 }
                 (void)hipGetLastError();
                 if (waited > std::chrono::milliseconds(200)) break;
@@ -709,10 +757,10 @@ int pv_process_end(pv_handle *h, float *const *out)
         std::atomic_thread_fence(std::memory_order_acquire);
     }
     if (!done) {
-        if (h->resident_on) { h->h_ctl[4] = 1u; std::atomic_thread_fence(std::memory_order_seq_cst); }   // ask the resident waves to leave: the wait below must end
+        if (h->resident_on) resident_publish(h, h->h_ctl + 4, 1u);             // ask the resident waves to leave: the wait below must end
         e = hipSetDevice(h->device);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (h->resident_on) { h->h_ctl[4] = 0u; h->resident_on = false; if (e == hipSuccess) e = hipErrorLaunchFailure; }   // the quantum did not complete
+        if (h->resident_on) { resident_publish(h, h->h_ctl + 4, 0u); h->resident_on = false; if (e == hipSuccess) e = hipErrorLaunchFailure; }   // the quantum did not complete
     }
     if (e != hipSuccess) {                                                       // the state is committed only when the whole quantum succeeded
         h->cur = h->pending_cur; h->time_cursor = h->pending_time_cursor; h->active_nch = h->pending_active_nch;
@@ -763,21 +811,103 @@ int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int
     const int nrows = pitch_stride ? (nch + cps - 1) / cps : 1;
     if (pitch_stride && pitch_stride < nhops) return fail(h, PV_ERR_ARGUMENT, "pv_process_batch: pitch_stride smaller than nhops");
     const Commit before{h->cur, h->time_cursor, h->active_nch};
+    // ---- plan: how the batch is cut into pieces (PINNED host buffers only: pageable memory is staged by the runtime, synchronously) ----
+    // With in / out in page-locked memory (pv_host_alloc) the copies are asynchronous DMA: the batch is cut into up to kMaxPieces pieces and piece k+1
+    // is on its way to the device while piece k is in the kernel and piece k-1 on its way back (three streams, two events per piece).  Pieces are
+    //   * groups of whole streams (contiguous channel rows: the largest DMA segments, no extra halo) when the batch has enough of them, else
+    //   * spans of hops: consecutive calls on the carried state, bit-identical to one call (tests: call-splitting invariance).
+    // The kernel rate is 10-30x the PCIe rate, so the pieces only have to be large enough for the DMA engines.
+    const bool pinned = host_pinned(in) && host_pinned(out);
+    const size_t row_bytes = row * sizeof(float), total = row_bytes * (size_t)nch;
+    int pieces = 1;
+    bool by_channel = false;
+    if (pinned && total >= ((size_t)4 << 20)) {
+        const int groups = nch / cps;                                           // whole streams
+        if (nch % cps == 0 && groups >= 4 && total / 4 >= ((size_t)1 << 20)) {
+            by_channel = true;
+            pieces = (int)(total / ((size_t)2 << 20));
+            if (pieces > groups) pieces = groups;
+        } else {
+            const int min_hops = (int)((65536 + (size_t)h->hop * 4 - 1) / ((size_t)h->hop * 4));      // >= 64 KB per row segment
+            pieces = (int)(total / ((size_t)2 << 20));
+            if (pieces > nhops / (min_hops > 0 ? min_hops : 1)) pieces = nhops / (min_hops > 0 ? min_hops : 1);
+        }
+        if (pieces > kMaxPieces) pieces = kMaxPieces;
+        if (pieces < 1) pieces = 1;
+    }
     auto batch = [&]() -> int {
-        HIPCHK(h, hipMemcpy2DAsync(h->d_stage_in, row * sizeof(float), in, (size_t)ch_stride * sizeof(float), row * sizeof(float), nch,
-                                   hipMemcpyHostToDevice, h->stream));
+        if (pieces > 1 && !h->pipe_ready) {
+            HIPCHK(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+            HIPCHK(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+            for (int i = 0; i < kMaxPieces; i++) {
+                HIPCHK(h, hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming));
+                HIPCHK(h, hipEventCreateWithFlags(&h->ev_k[i], hipEventDisableTiming));
+            }
+            h->pipe_ready = true;
+        }
         HIPCHK(h, hipMemcpy2DAsync(h->d_pitch, (size_t)nhops * sizeof(float), pitch, (size_t)(pitch_stride ? pitch_stride : nhops) * sizeof(float),
                                    (size_t)nhops * sizeof(float), nrows, hipMemcpyHostToDevice, h->stream));
-        const int rc = run_chain(h, h->d_stage_in, h->d_stage_out, nch, nhops, (long)row, h->d_pitch, pitch_stride ? nhops : 0, cps, true, -1);
-        if (rc != PV_OK) return rc;
-        HIPCHK(h, hipMemcpy2DAsync(out, (size_t)ch_stride * sizeof(float), h->d_stage_out, row * sizeof(float), row * sizeof(float), nch,
-                                   hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (pieces == 1) {
+            HIPCHK(h, hipMemcpy2DAsync(h->d_stage_in, row_bytes, in, (size_t)ch_stride * sizeof(float), row_bytes, nch, hipMemcpyHostToDevice, h->stream));
+            const int rc = run_chain(h, h->d_stage_in, h->d_stage_out, nch, nhops, (long)row, h->d_pitch, pitch_stride ? nhops : 0, cps, true, -1);
+            if (rc != PV_OK) return rc;
+            HIPCHK(h, hipMemcpy2DAsync(out, (size_t)ch_stride * sizeof(float), h->d_stage_out, row_bytes, row_bytes, nch, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            return PV_OK;
+        }
+        // the device staging buffers hold the WHOLE batch (planar, row = nhops * hop floats per channel): pieces never share bytes, no buffer is
+        // reused inside a call, so the only ordering is H2D(k) -> kernel(k) -> D2H(k)
+        const int groups = nch / cps;
+        for (int k = 0; k < pieces; k++) {
+            int c0 = 0, cn = nch, m0 = 0, mn = nhops;
+            if (by_channel) { c0 = (int)((long)groups * k / pieces) * cps; cn = (int)((long)groups * (k + 1) / pieces) * cps - c0; }
+            else { m0 = (int)((long)nhops * k / pieces); mn = (int)((long)nhops * (k + 1) / pieces) - m0; }
+            const size_t doff = (size_t)c0 * row + (size_t)m0 * h->hop, hoff = (size_t)c0 * (size_t)ch_stride + (size_t)m0 * h->hop;
+            const size_t w = (size_t)mn * h->hop * sizeof(float);
+            HIPCHK(h, hipMemcpy2DAsync(h->d_stage_in + doff, row_bytes, in + hoff, (size_t)ch_stride * sizeof(float), w, cn, hipMemcpyHostToDevice, h->s_in));
+            HIPCHK(h, hipEventRecord(h->ev_in[k], h->s_in));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in[k], 0));
+            const float *pp = h->d_pitch + (pitch_stride ? (size_t)(c0 / cps) * nhops : 0) + m0;
+            const int rc = by_channel ? launch_chain(h, h->d_stage_in + doff, h->d_stage_out + doff, c0, cn, mn, (long)row, pp, pitch_stride ? nhops : 0, cps, true, -1, 0)
+                                      : run_chain(h, h->d_stage_in + doff, h->d_stage_out + doff, nch, mn, (long)row, pp, pitch_stride ? nhops : 0, cps, true, -1);
+            if (rc != PV_OK) return rc;
+            HIPCHK(h, hipEventRecord(h->ev_k[k], h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->s_out, h->ev_k[k], 0));
+            HIPCHK(h, hipMemcpy2DAsync(out + hoff, (size_t)ch_stride * sizeof(float), h->d_stage_out + doff, row_bytes, w, cn, hipMemcpyDeviceToHost, h->s_out));
+        }
+        if (by_channel) { const int rc = commit_chain(h, nch, nhops); if (rc != PV_OK) return rc; }
+        HIPCHK(h, hipStreamSynchronize(h->s_out));
+        HIPCHK(h, hipStreamSynchronize(h->stream));                          // (the state copies of the commit)
         return PV_OK;
     };
     const int rc = batch();
-    if (rc != PV_OK) { h->cur = before.cur; h->time_cursor = before.time_cursor; h->active_nch = before.active_nch; }   // a failed call leaves the handle as it was
+    if (rc != PV_OK) {                                                       // a failed call leaves the handle as it was (and nothing in flight)
+        if (h->pipe_ready) { (void)hipStreamSynchronize(h->s_in); (void)hipStreamSynchronize(h->s_out); }
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipGetLastError();
+        h->cur = before.cur; h->time_cursor = before.time_cursor; h->active_nch = before.active_nch;
+    }
     return rc;
+}
+
+int pv_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return PV_ERR_ARGUMENT;
+    *out = nullptr;
+    if (bytes == 0) return PV_ERR_ARGUMENT;
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);        // visible to every device of the process
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail_hip(nullptr, e, "pv_host_alloc: hipHostMalloc"); }
+    *out = p;
+    return PV_OK;
+}
+
+int pv_host_free(void *p)
+{
+    if (!p) return PV_OK;
+    const hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail_hip(nullptr, e, "pv_host_free: hipHostFree"); }
+    return PV_OK;
 }
 
 int pv_debug_frame(pv_handle *h, int32_t ch, const float *block, float pitch_factor, double *X, float *mag, int32_t *peak_flags, float *Y)
@@ -797,6 +927,14 @@ int pv_debug_frame(pv_handle *h, int32_t ch, const float *block, float pitch_fac
     HIPCHK(h, hipMemsetAsync(h->d_dbgX, 0, sizeof(double) * 2 * N, h->stream));
     const int rc = run_chain(h, dq_in, dq_out, ch + 1, 1, hop, h->d_quantum, 0, 1, false, ch);   // commit=false: state untouched
     if (rc != PV_OK) return rc;
+    // ... except that the kernel has written the frame's history / accumulator of slots [0, ch] into the OTHER ping-pong half.  Slots below
+    // used_channels are rewritten there by the next committed launch (by the kernel or by run_chain's copy); slots [used_channels, ch] are
+    // covered by neither -- they count as "zero in both halves" -- so they are zeroed again here.
+    if (ch + 1 > h->used_channels && h->L > 0) {
+        const size_t off = (size_t)h->used_channels * h->L, bytes = sizeof(float) * (size_t)(ch + 1 - h->used_channels) * h->L;
+        HIPCHK(h, hipMemsetAsync(h->d_hist[h->cur ^ 1] + off, 0, bytes, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_acc[h->cur ^ 1] + off, 0, bytes, h->stream));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (X) HIPCHK(h, hipMemcpy(X, h->d_dbgX, sizeof(double) * 2 * N, hipMemcpyDeviceToHost));
     if (mag) HIPCHK(h, hipMemcpy(mag, h->d_dbgMag, sizeof(float) * H, hipMemcpyDeviceToHost));

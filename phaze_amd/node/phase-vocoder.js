@@ -95,9 +95,17 @@ class PhaseVocoderProcessor extends Base {
         // several inputs = several independent processors (phase-vocoder.js:49-50): launch them all, then collect them all -- every
         // kernel is in flight before the first wait, a quantum costs one exposed launch + wait instead of one per input
         const counts = new Array(this._handles.length);
-        for (let i = 0; i < this._handles.length; i++) {
-            const ins = paused ? inputs[i].map(() => PhaseVocoderProcessor._EMPTY) : inputs[i];
-            counts[i] = native.processBegin(this._handles[i], ins, pitchFactor);
+        let begun = 0;
+        try {
+            for (; begun < this._handles.length; begun++) {
+                const ins = paused ? inputs[begun].map(() => PhaseVocoderProcessor._EMPTY) : inputs[begun];
+                counts[begun] = native.processBegin(this._handles[begun], ins, pitchFactor);
+            }
+        } catch (e) {
+            // a later input failed to launch (bad block length, device error): collect the quanta already in flight so that their handles
+            // do not stay "pending" for ever, then report the failure
+            for (let i = 0; i < begun; i++) { try { native.processEnd(this._handles[i], outputs[i] || [], counts[i]); } catch (_) { /* the first error wins */ } }
+            throw e;
         }
         for (let i = 0; i < this._handles.length; i++) native.processEnd(this._handles[i], outputs[i] || [], counts[i]);
         return true;                                            // ola-processor.js:170

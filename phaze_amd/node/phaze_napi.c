@@ -1,3 +1,4 @@
+#define _POSIX_C_SOURCE 200809L
 /*
  * phaze_napi.c -- thin N-API (C) addon over the C ABI of include/phaze_amd.h.
  *
@@ -14,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/phaze_amd.h"
 
@@ -27,6 +29,8 @@ typedef struct pv_slot {
     int busy;          /* an asynchronous batch runs on a worker thread: the handle accepts no other call until its promise settles */
     int doomed;        /* destroy() arrived while busy: the completion callback destroys the handle */
     int orphan;        /* the JS handle object was collected while busy: the completion callback also frees this slot */
+    double t_begin_ms, t_end_ms;   /* CLOCK_MONOTONIC window of the last asynchronous batch on its worker thread (batchWindow(): are the shards really side by side?) */
+    int begun;         /* channel count of the quantum pv_process_begin launched (pv_process_end indexes exactly that many output pointers) */
 } pv_slot;
 
 #define NAPI_OK_OR_THROW(env, call, msg)                         \
@@ -108,7 +112,8 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     pv_handle *h = NULL;
     const int rc = pv_create(&cfg, &h);
     if (rc != PV_OK) return throw_status(env, NULL, rc);
-    pv_slot *slot = (pv_slot *)malloc(sizeof(pv_slot));
+    pv_slot *slot = (pv_slot *)calloc(1, sizeof(pv_slot));
+    if (!slot) { pv_destroy(h); napi_throw_error(env, NULL, "out of memory"); return NULL; }
     slot->h = h;
     slot->hop = cfg.hop_size;
     slot->fft = cfg.fft_size;
@@ -192,8 +197,8 @@ static napi_value js_process(napi_env env, napi_callback_info info)
 /* processBatch(handle, in: Float32Array [nch*nhops*hop], out: Float32Array, nch, nhops, pitch: Float32Array, pitchStride, channelsPerStream) */
 static napi_value js_process_batch(napi_env env, napi_callback_info info)
 {
-    size_t argc = 8;
-    napi_value argv[8];
+    size_t argc = 9;
+    napi_value argv[9];
     NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
     if (argc < 6) { napi_throw_type_error(env, NULL, "processBatch(handle, in, out, nch, nhops, pitch[, pitchStride, channelsPerStream])"); return NULL; }
     pv_slot *slot = unwrap(env, argv[0]);
@@ -209,17 +214,21 @@ static napi_value js_process_batch(napi_env env, napi_callback_info info)
         return NULL;
     }
     int32_t nch = 0, nhops = 0, pstride = 0, cps = 1;
+    int64_t chs = 0;
     napi_get_value_int32(env, argv[3], &nch);
     napi_get_value_int32(env, argv[4], &nhops);
     if (argc > 6) napi_get_value_int32(env, argv[6], &pstride);
     if (argc > 7) napi_get_value_int32(env, argv[7], &cps);
-    const size_t need = (size_t)nch * (size_t)nhops * (size_t)slot->hop;
+    if (argc > 8) napi_get_value_int64(env, argv[8], &chs);                  /* channel stride in floats; 0 / omitted: nhops * hopSize (packed rows) */
+    if (chs <= 0) chs = (int64_t)nhops * slot->hop;
+    if (nch <= 0 || nhops <= 0 || chs < (int64_t)nhops * slot->hop) { napi_throw_range_error(env, NULL, "buffer sizes do not match nch*nhops*hopSize"); return NULL; }
+    const size_t need = (size_t)(nch - 1) * (size_t)chs + (size_t)nhops * (size_t)slot->hop;
     const size_t rows = pstride ? (size_t)((nch + (cps > 0 ? cps : 1) - 1) / (cps > 0 ? cps : 1)) : 1;
     if (nch <= 0 || nhops <= 0 || nin < need || nout < need || npitch < (pstride ? (rows - 1) * (size_t)pstride + (size_t)nhops : (size_t)nhops)) {
         napi_throw_range_error(env, NULL, "buffer sizes do not match nch*nhops*hopSize");
         return NULL;
     }
-    const int rc = pv_process_batch(slot->h, (const float *)din, (float *)dout, nch, nhops, (int64_t)nhops * slot->hop, (const float *)dp, pstride, cps);
+    const int rc = pv_process_batch(slot->h, (const float *)din, (float *)dout, nch, nhops, chs, (const float *)dp, pstride, cps);
     if (rc != PV_OK) return throw_status(env, slot->h, rc);
     napi_value t;
     napi_get_boolean(env, true, &t);
@@ -250,6 +259,7 @@ static napi_value js_process_begin(napi_env env, napi_callback_info info)
         if (nsamples && inlen[c] != (size_t)slot->hop) { napi_throw_range_error(env, NULL, "input block length must equal hopSize"); return NULL; }
     const int rc = pv_process_begin(slot->h, (const float *const *)in, nin, nsamples, (float)pf);
     if (rc != PV_OK) return throw_status(env, slot->h, rc);
+    slot->begun = nin;
     napi_value n;
     napi_create_int32(env, nin, &n);
     return n;
@@ -267,10 +277,11 @@ static napi_value js_process_end(napi_env env, napi_callback_info info)
     size_t outlen[MAX_CH];
     const int nout = gather_channels(env, argv[1], out, outlen, MAX_CH);
     if (nout < 0) { napi_throw_type_error(env, NULL, "outputs must be an array of Float32Array (<= 64 channels)"); return NULL; }
-    int32_t nin = nout;
-    if (argc > 2) napi_get_value_int32(env, argv[2], &nin);
-    if (nin > MAX_CH) nin = MAX_CH;
-    for (int c = 0; c < nin; c++) outp[c] = (c < nout && outlen[c] >= (size_t)slot->hop) ? out[c] : NULL;   /* phase-vocoder.js:51 */
+    /* pv_process_end reads one pointer per channel of the quantum that was BEGUN, whatever the caller passes here: missing or short outputs are
+     * NULL (skipped), as the reference skips outputs that do not mirror the inputs (phase-vocoder.js:51).  The optional third argument is accepted
+     * for compatibility and ignored. */
+    for (int c = 0; c < MAX_CH; c++) outp[c] = (c < slot->begun && c < nout && outlen[c] >= (size_t)slot->hop) ? out[c] : NULL;
+    slot->begun = 0;
     const int rc = pv_process_end(slot->h, outp);
     if (rc != PV_OK) return throw_status(env, slot->h, rc);
     napi_value t;
@@ -289,6 +300,7 @@ typedef struct batch_job {
     const float *in, *pitch;
     float *out;
     int32_t nch, nhops, pstride, cps;
+    int64_t chs;
     int rc;
     char err[256];
 } batch_job;
@@ -297,11 +309,16 @@ static void batch_execute(napi_env env, void *data)
 {
     (void)env;
     batch_job *j = (batch_job *)data;
-    j->rc = pv_process_batch(j->slot->h, j->in, j->out, j->nch, j->nhops, (int64_t)j->nhops * j->slot->hop, j->pitch, j->pstride, j->cps);
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    j->slot->t_begin_ms = (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+    j->rc = pv_process_batch(j->slot->h, j->in, j->out, j->nch, j->nhops, j->chs, j->pitch, j->pstride, j->cps);
     if (j->rc != PV_OK) {
         const char *m = pv_last_error(j->slot->h);
         snprintf(j->err, sizeof j->err, "%s", (m && m[0]) ? m : pv_status_string(j->rc));
     }
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    j->slot->t_end_ms = (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
 }
 
 static void batch_complete(napi_env env, napi_status status, void *data)
@@ -328,8 +345,8 @@ static void batch_complete(napi_env env, napi_status status, void *data)
 
 static napi_value js_process_batch_async(napi_env env, napi_callback_info info)
 {
-    size_t argc = 8;
-    napi_value argv[8];
+    size_t argc = 9;
+    napi_value argv[9];
     NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
     if (argc < 6) { napi_throw_type_error(env, NULL, "processBatchAsync(handle, in, out, nch, nhops, pitch[, pitchStride, channelsPerStream])"); return NULL; }
     pv_slot *slot = unwrap(env, argv[0]);
@@ -345,11 +362,15 @@ static napi_value js_process_batch_async(napi_env env, napi_callback_info info)
         return NULL;
     }
     int32_t nch = 0, nhops = 0, pstride = 0, cps = 1;
+    int64_t chs = 0;
     napi_get_value_int32(env, argv[3], &nch);
     napi_get_value_int32(env, argv[4], &nhops);
     if (argc > 6) napi_get_value_int32(env, argv[6], &pstride);
     if (argc > 7) napi_get_value_int32(env, argv[7], &cps);
-    const size_t need = (size_t)nch * (size_t)nhops * (size_t)slot->hop;
+    if (argc > 8) napi_get_value_int64(env, argv[8], &chs);                  /* channel stride in floats; 0 / omitted: nhops * hopSize */
+    if (chs <= 0) chs = (int64_t)nhops * slot->hop;
+    if (nch <= 0 || nhops <= 0 || chs < (int64_t)nhops * slot->hop) { napi_throw_range_error(env, NULL, "buffer sizes do not match nch*nhops*hopSize"); return NULL; }
+    const size_t need = (size_t)(nch - 1) * (size_t)chs + (size_t)nhops * (size_t)slot->hop;
     const size_t rows = pstride ? (size_t)((nch + (cps > 0 ? cps : 1) - 1) / (cps > 0 ? cps : 1)) : 1;
     if (nch <= 0 || nhops <= 0 || nin < need || nout < need || npitch < (pstride ? (rows - 1) * (size_t)pstride + (size_t)nhops : (size_t)nhops)) {
         napi_throw_range_error(env, NULL, "buffer sizes do not match nch*nhops*hopSize");
@@ -358,7 +379,7 @@ static napi_value js_process_batch_async(napi_env env, napi_callback_info info)
     batch_job *j = (batch_job *)calloc(1, sizeof(batch_job));
     if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
     j->slot = slot; j->in = (const float *)din; j->out = (float *)dout; j->pitch = (const float *)dp;
-    j->nch = nch; j->nhops = nhops; j->pstride = pstride; j->cps = cps;
+    j->nch = nch; j->nhops = nhops; j->pstride = pstride; j->cps = cps; j->chs = chs;
     napi_value promise, name;
     if (napi_create_promise(env, &j->deferred, &promise) != napi_ok) { free(j); napi_throw_error(env, NULL, "napi_create_promise failed"); return NULL; }
     napi_create_reference(env, argv[1], 1, &j->refs[0]);
@@ -373,6 +394,52 @@ static napi_value js_process_batch_async(napi_env env, napi_callback_info info)
     }
     slot->busy = 1;
     return promise;
+}
+
+/* batchWindow(handle) -> [beginMs, endMs]: when the last processBatchAsync of this handle ran on its libuv worker thread (CLOCK_MONOTONIC).  A host
+ * that drives G shards checks with it that G batches were in flight together (UV_THREADPOOL_SIZE >= G took effect), tools/bench_node_sharded.js. */
+static napi_value js_batch_window(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
+    if (argc < 1) { napi_throw_type_error(env, NULL, "batchWindow(handle)"); return NULL; }
+    pv_slot *slot = unwrap(env, argv[0]);
+    if (!slot) return NULL;
+    napi_value arr, a, b;
+    napi_create_array_with_length(env, 2, &arr);
+    napi_create_double(env, slot->t_begin_ms, &a);
+    napi_create_double(env, slot->t_end_ms, &b);
+    napi_set_element(env, arr, 0, a);
+    napi_set_element(env, arr, 1, b);
+    return arr;
+}
+
+/* allocPinned(nFloats) -> Float32Array in page-locked host memory (pv_host_alloc; freed when the ArrayBuffer is collected).  processBatch /
+ * processBatchAsync on such arrays are pipelined (DMA to and from the device at the same time, include/phaze_amd.h); a host that owns its audio
+ * buffers (what a caller of OLAProcessor.process does, ola-processor.js:159-171) allocates them here and writes its streams in place. */
+static void finalize_pinned(napi_env env, void *data, void *hint)
+{
+    (void)env; (void)hint;
+    pv_host_free(data);
+}
+
+static napi_value js_alloc_pinned(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
+    double nf = 0;
+    if (argc < 1 || napi_get_value_double(env, argv[0], &nf) != napi_ok || !(nf >= 1) || nf > 4e12) { napi_throw_range_error(env, NULL, "allocPinned(nFloats): nFloats >= 1"); return NULL; }
+    const size_t n = (size_t)nf;
+    void *p = NULL;
+    const int rc = pv_host_alloc(n * sizeof(float), &p);
+    if (rc != PV_OK) return throw_status(env, NULL, rc);
+    memset(p, 0, n * sizeof(float));
+    napi_value ab, ta;
+    if (napi_create_external_arraybuffer(env, p, n * sizeof(float), finalize_pinned, NULL, &ab) != napi_ok) { pv_host_free(p); napi_throw_error(env, NULL, "napi_create_external_arraybuffer failed"); return NULL; }
+    NAPI_OK_OR_THROW(env, napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta), "napi_create_typedarray failed");
+    return ta;
 }
 
 /* exportState(handle, channel) -> {hist: Float32Array(N - hop), acc: Float32Array(N - hop), timeCursor}
@@ -527,6 +594,8 @@ static napi_value init(napi_env env, napi_value exports)
         {"processBegin", NULL, js_process_begin, NULL, NULL, NULL, napi_enumerable, NULL},
         {"processEnd", NULL, js_process_end, NULL, NULL, NULL, napi_enumerable, NULL},
         {"processBatchAsync", NULL, js_process_batch_async, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"allocPinned", NULL, js_alloc_pinned, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"batchWindow", NULL, js_batch_window, NULL, NULL, NULL, napi_enumerable, NULL},
         {"exportState", NULL, js_export_state, NULL, NULL, NULL, napi_enumerable, NULL},
         {"importState", NULL, js_import_state, NULL, NULL, NULL, napi_enumerable, NULL},
         {"deviceCount", NULL, js_device_count, NULL, NULL, NULL, napi_enumerable, NULL},

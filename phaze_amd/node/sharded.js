@@ -7,10 +7,14 @@
  *
  *     stream s  ->  shard s mod G          (SURVEY 8e)      shard g = one native handle on device g mod deviceCount
  *
- * No data moves between GPUs.  processBatch() packs every shard's streams into one planar buffer, starts ALL shards through the
- * asynchronous entry of the addon (napi_async_work -> pv_process_batch on a libuv worker thread, one per shard) and only then awaits them:
- * every GPU has its batch in flight before the first wait.  With fewer devices than requested shards the shards share devices (each handle
- * has its own HIP stream) and the result says so (`replicasMeasured`), exactly as bench.py does.
+ * No data moves between GPUs.  Every shard owns ONE planar input and ONE planar output buffer in page-locked host memory (native.allocPinned ->
+ * pv_host_alloc): a host writes the samples of stream s, channel c straight into inputView(s, c), calls processInPlace(nhops) and reads
+ * outputView(s, c) -- no re-packing in JavaScript, and the native batch call pipelines pinned buffers (H2D of piece k+1, kernel of piece k and
+ * D2H of piece k-1 at the same time).  processInPlace starts ALL shards through the asynchronous entry of the addon (napi_async_work ->
+ * pv_process_batch on a libuv worker thread, one per shard) and only then awaits them: every GPU has its batch in flight before the first
+ * wait.  processBatch(inputs, outputs, ...) keeps the round-3 form for hosts whose samples live in their own arrays (one copy in, one copy out).
+ * With fewer devices than requested shards the shards share devices (each handle has its own HIP stream) and the result says so
+ * (`replicasMeasured`), exactly as bench.py does.
  *
  * libuv starts 4 worker threads by default: for more than 4 shards set UV_THREADPOOL_SIZE >= shards BEFORE Node starts any thread-pool
  * work (the constructor sets it when it still can and reports `threadPoolSize`).
@@ -48,10 +52,30 @@ class ShardedPhaseVocoder {
             const nch = mine.length * this.channelsPerStream;
             this._handles.push(native.create({ fftSize: this.fftSize, hopSize: this.hopSize, maxChannels: nch, maxHops: this.maxHops,
                                                deviceId: g % this.devicesPresent, flags: o.flags | 0 }));
-            this._in.push(new Float32Array(nch * this.maxHops * this.hopSize));
-            this._out.push(new Float32Array(nch * this.maxHops * this.hopSize));
-            this._pitch.push(new Float32Array(mine.length * this.maxHops));
+            // page-locked, planar: channel slot q of the shard at [q * stride, (q + 1) * stride), stride = maxHops * hopSize floats
+            this._in.push(native.allocPinned(nch * this.maxHops * this.hopSize));
+            this._out.push(native.allocPinned(nch * this.maxHops * this.hopSize));
+            this._pitch.push(new Float32Array(mine.length * this.maxHops).fill(1.0));
         }
+        this.stride = this.maxHops * this.hopSize;
+    }
+
+    /** The samples of stream s, channel c live HERE (maxHops * hopSize floats of the shard's pinned input / output buffer): write / read in place. */
+    inputView(s, c) { const w = this.shardOf(s), q = w.slot * this.channelsPerStream + c; return this._in[w.shard].subarray(q * this.stride, (q + 1) * this.stride); }
+    outputView(s, c) { const w = this.shardOf(s), q = w.slot * this.channelsPerStream + c; return this._out[w.shard].subarray(q * this.stride, (q + 1) * this.stride); }
+    /** k-rate pitchFactor of stream s per hop (phase-vocoder.js:47), maxHops floats, defaults to 1.0 */
+    pitchView(s) { const w = this.shardOf(s); return this._pitch[w.shard].subarray(w.slot * this.maxHops, (w.slot + 1) * this.maxHops); }
+
+    /** nhops consecutive process() calls for every stream, on the views above.  Resolves when every output view is complete. */
+    async processInPlace(nhops) {
+        if (nhops > this.maxHops) throw new Error("processInPlace: nhops exceeds maxHops");
+        const jobs = [];
+        for (let g = 0; g < this.shards; g++) {                              // launch every shard ...
+            const nch = this._streamsOf[g].length * this.channelsPerStream;
+            jobs.push(native.processBatchAsync(this._handles[g], this._in[g], this._out[g], nch, nhops, this._pitch[g], this.maxHops, this.channelsPerStream, this.stride));
+        }
+        await Promise.all(jobs);                                             // ... before the first wait
+        return true;
     }
 
     /** shard (= handle) that owns stream s, and its slot there */
@@ -66,23 +90,23 @@ class ShardedPhaseVocoder {
     async processBatch(inputs, outputs, pitch, nhops) {
         if (nhops > this.maxHops) throw new Error("processBatch: nhops exceeds maxHops");
         const n = nhops * this.hopSize, cps = this.channelsPerStream;
-        const jobs = [];
-        for (let g = 0; g < this.shards; g++) {                              // pack + launch every shard ...
-            const mine = this._streamsOf[g], nch = mine.length * cps;
-            const bin = this._in[g].subarray(0, nch * n), bout = this._out[g].subarray(0, nch * n), bp = this._pitch[g].subarray(0, mine.length * nhops);
-            for (let k = 0; k < mine.length; k++) {
-                for (let c = 0; c < cps; c++) bin.set(inputs[mine[k]][c].subarray(0, n), (k * cps + c) * n);
-                bp.set(pitch[mine[k]].subarray(0, nhops), k * nhops);
-            }
-            jobs.push(native.processBatchAsync(this._handles[g], bin, bout, nch, nhops, bp, nhops, cps));
+        for (let s = 0; s < this.streams; s++) {
+            for (let c = 0; c < cps; c++) this.inputView(s, c).set(inputs[s][c].subarray(0, n));
+            this.pitchView(s).set(pitch[s].subarray(0, nhops));
         }
-        await Promise.all(jobs);                                             // ... before the first wait
-        for (let g = 0; g < this.shards; g++) {
-            const mine = this._streamsOf[g];
-            for (let k = 0; k < mine.length; k++)
-                for (let c = 0; c < cps; c++) outputs[mine[k]][c].set(this._out[g].subarray((k * cps + c) * n, (k * cps + c + 1) * n));
-        }
+        await this.processInPlace(nhops);
+        for (let s = 0; s < this.streams; s++)
+            for (let c = 0; c < cps; c++) outputs[s][c].set(this.outputView(s, c).subarray(0, n));
         return true;
+    }
+
+    /** How many shards' last batches were in flight TOGETHER (largest set of pairwise overlapping worker-thread windows): equals `shards` when the
+     *  libuv pool has a thread for each (UV_THREADPOOL_SIZE >= shards took effect), at most the pool size otherwise. */
+    maxConcurrentShards() {
+        const w = this._handles.map((h) => native.batchWindow(h));
+        let best = 0;
+        for (const [b] of w) { let n = 0; for (const [b2, e2] of w) if (b2 <= b && b < e2) n++; if (n > best) best = n; }   // windows open at the instant a window opens
+        return best;
     }
 
     /** state of channel c of stream s: {hist, acc, timeCursor} (checkpoint / resume / moving a stream to another shard) */

@@ -16,13 +16,19 @@ def stream_partition(nstreams: int, world: int, rank: int) -> List[int]:
     return list(range(rank, nstreams, world))
 
 
+def _host_side(dist, t):
+    """gloo moves host tensors; RCCL moves device tensors.  With gloo (CPU tests, and the one GPU test that puts two ranks on one device) a device
+    tensor makes the round trip through host memory around the call."""
+    return dist.get_backend() == "gloo" and t.is_cuda
+
+
 def reduce_max(values: Sequence[float], dist=None, device=None) -> List[float]:
     """Element-wise MAX over ranks (identity without a process group; WITH one the collective runs even at world size 1, so that a one-rank
     torchrun exercises the backend -- RCCL on the GPU box)."""
     if dist is None or not dist.is_initialized():
         return [float(v) for v in values]
     import torch
-    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    t = torch.tensor(list(values), dtype=torch.float64, device=None if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(v) for v in t]
 
@@ -40,10 +46,12 @@ def scatter_streams(x_all, nstreams: int, dist, src: int = 0):
         return x_all[:nstreams].clone()
     world, rank = dist.get_world_size(), dist.get_rank()
     mine = stream_partition(nstreams, world, rank)
-    out = torch.empty((len(mine),) + tuple(x_all.shape[1:]), dtype=x_all.dtype, device=x_all.device)
+    host = _host_side(dist, x_all)
+    wire = torch.device("cpu") if host else x_all.device
+    out = torch.empty((len(mine),) + tuple(x_all.shape[1:]), dtype=x_all.dtype, device=wire)
     pieces = None
     if rank == src:
-        pieces = [x_all[r:nstreams:world].contiguous() for r in range(world)]
+        pieces = [x_all[r:nstreams:world].contiguous().to(wire) for r in range(world)]
     if nstreams % world == 0:
         dist.scatter(out, pieces, src=src)
     else:                                                    # unequal shares: point-to-point (scatter wants equal sizes)
@@ -55,7 +63,7 @@ def scatter_streams(x_all, nstreams: int, dist, src: int = 0):
                     dist.send(pieces[r], dst=r)
         elif out.numel():
             dist.recv(out, src=src)
-    return out
+    return out.to(x_all.device) if host else out
 
 
 def gather_streams(y_mine, nstreams: int, dist, dst: int = 0):
@@ -64,6 +72,9 @@ def gather_streams(y_mine, nstreams: int, dist, dst: int = 0):
     if dist is None or not dist.is_initialized():
         return y_mine
     world, rank = dist.get_world_size(), dist.get_rank()
+    home = y_mine.device
+    if _host_side(dist, y_mine):
+        y_mine = y_mine.cpu()
     pieces = None
     if nstreams % world == 0:
         pieces = [torch.empty_like(y_mine) for _ in range(world)] if rank == dst else None
@@ -86,4 +97,4 @@ def gather_streams(y_mine, nstreams: int, dist, dst: int = 0):
     out = torch.empty((nstreams,) + tuple(y_mine.shape[1:]), dtype=y_mine.dtype, device=y_mine.device)
     for r in range(world):
         out[r:nstreams:world] = pieces[r]
-    return out
+    return out.to(home)

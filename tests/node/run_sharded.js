@@ -56,6 +56,18 @@ const x = rd(spec.in_file), p = rd(spec.pitch_file), n = T * hop;
   await pv.processBatch(inputs, o2, pitch, T);
   let same = true; for (let c = 0; c < cps && same; c++) same = Buffer.compare(Buffer.from(o2[0][c].buffer), Buffer.from(cont.buffer, c * n * 4, n * 4)) === 0;
   res.migrated_stream_continues_bit_exact = same;
+  // (5) round 4: the in-place form -- streams written straight into the shards' pinned buffers (inputView / pitchView), processInPlace, results read
+  // from outputView -- gives the bits of the copying form; and every shard's batch was in flight at the same time (libuv pool >= shards)
+  const pv2 = new ShardedPhaseVocoder({ fftSize: fft, hopSize: hop, channelsPerStream: cps, streams: S, maxHops: T + 3, gpus: shards });   // maxHops > nhops: strided rows
+  for (let s = 0; s < S; s++) { for (let c = 0; c < cps; c++) pv2.inputView(s, c).set(inputs[s][c]); pv2.pitchView(s).set(pitch[s]); }
+  await pv2.processInPlace(T);
+  let inplace = true;
+  for (let s = 0; s < S && inplace; s++) for (let c = 0; c < cps && inplace; c++)
+    inplace = Buffer.compare(Buffer.from(pv2.outputView(s, c).buffer, pv2.outputView(s, c).byteOffset, n * 4), Buffer.from(one.buffer, (s * cps + c) * n * 4, n * 4)) === 0;
+  res.in_place_equals_one_handle = inplace;
+  res.shards_in_flight_together = pv2.maxConcurrentShards();
+  res.thread_pool = pv2.threadPoolSize;
+  pv2.close();
   native.destroy(h1); native.destroy(h2); pv.close();
   console.log(JSON.stringify(res));
 })().catch((e) => { console.error(e); process.exit(1); });

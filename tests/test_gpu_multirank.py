@@ -95,4 +95,25 @@ def test_rccl_branch_runs_on_hardware_at_world_size_one():
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["n_gpus"] == 1 and j["dist_backend"] == "nccl"
     assert np.isfinite(j["scatter_gather_ms"]) and j["scatter_gather_ms"] > 0
-    assert j["parity_rms_vs_oracle"] < 2e-6 and len(j["timed_regions"]["kernel_ms"]) == 3
+    assert j["parity_rms_vs_oracle"] < 2e-6 and len(j["timed_regions"]["kernel_ms"]) == 5
+
+
+def test_two_bench_ranks_on_one_gpu_run_the_multi_rank_line_end_to_end():
+    """What the driver launches on an 8-GPU node, with TWO ranks squeezed onto ONE device (HIP_VISIBLE_DEVICES=0, LOCAL_RANK % ndev) and the gloo backend
+    (RCCL refuses two ranks on one device; `--dist-backend gloo` exists for this test only): rank-local seeds, barrier + MAX-over-ranks timing,
+    aggregate_rate over both ranks, the RAGGED send / recv branch of scatter_streams / gather_streams (3 streams over 2 ranks), and the line's own
+    statement that the two ranks shared one device (`replicas_measured` 1, no scaling claimed)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HIP_VISIBLE_DEVICES="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29743",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--hops", "8192", "--repeats", "2", "--no-extras", "--no-cpu-baseline",
+                        "--dist-backend", "gloo", "--scatter-gather", "--sg-streams", "3"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                            # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["dist_backend"] == "gloo" and j["ranks"] == 2 and j["n_gpus"] == 1 and j["requested_gpus"] == 2 and j["replicas_measured"] == 1
+    assert "no scaling curve" in j["note_gpus"]
+    assert j["scatter_gather"]["branch"].startswith("send / recv") and j["scatter_gather"]["round_trip_intact"] is True and j["scatter_gather"]["rank0_streams"] == 2
+    # whole-job value = frames of BOTH ranks / slowest rank's time (shard.aggregate_rate)
+    assert abs(j["value"] - 2 * 8192 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-6
+    assert j["parity_rms_vs_oracle"] < 2e-6 and j["scaling"] == "weak"

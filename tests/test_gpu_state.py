@@ -151,3 +151,24 @@ def test_failed_call_leaves_the_handle_as_it_was():
     r1 = ref.process_batch(x[:, T * hop:], p)
     pv.close(); ref.close()
     assert np.array_equal(y1, r1)
+
+
+@pytest.mark.parametrize("fft,hop", [(1024, 256), (2048, 512), (4096, 1024), (8192, 2048), (512, 128)])
+def test_debug_frame_leaves_unused_slots_zero(fft, hop):
+    """pv_debug_frame runs a frame of slots [0, ch] without committing, but the kernels still store that frame's history / accumulator into the
+    other ping-pong half.  Slots that have never been processed count as "zero in both halves" (they are not copied across a flip): after a tap
+    on slot 1 of a fresh handle, a mono batch and then a stereo batch, channel 1 must start from silence -- as on a handle that was never tapped."""
+    T = 12
+    x = np.stack([S.make_signal("tonal", c, 2 * T * hop) for c in range(2)])
+    p = np.full(T, 0.9, np.float32)
+    outs = []
+    for tap in (False, True):
+        pv = _pv(fft_size=fft, hop_size=hop, max_channels=2, max_hops=T)
+        if tap:
+            pv.debug_frame(1, x[1, :hop] * 3.0 + 0.5, 1.3)
+        y1 = pv.process_batch(x[:1, :T * hop], p)
+        y2 = pv.process_batch(x[:, T * hop:], p)
+        pv.close()
+        outs.append((y1, y2))
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))

@@ -43,7 +43,7 @@ def test_addon_loads_and_exports_surface():
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout)
     assert d["native"] == sorted(["create", "destroy", "process", "processBatch", "reset", "timeCursor", "info", "processBegin", "processEnd",
-                                  "processBatchAsync", "exportState", "importState", "deviceCount"])
+                                  "processBatchAsync", "exportState", "importState", "deviceCount", "allocPinned", "batchWindow"])
     assert d["desc"] == [{"name": "pitchFactor", "defaultValue": 1}]          # phase-vocoder.js:17-22
     assert d["registered"] and d["hasProcess"]
 
@@ -175,6 +175,7 @@ def test_node_sharded_streams_in_flight_together(fft, hop, streams, cps, shards,
     assert res["equal_to_one_handle"] is True and res["async_equals_sync"] is True
     assert res["busy_guard"] == "PV_BUSY"
     assert res["state_cursor"] == T * hop and res["state_len"] == fft - hop and res["migrated_stream_continues_bit_exact"] is True
+    assert res["in_place_equals_one_handle"] is True and res["thread_pool"] >= shards
     import oracle_lib
     got = np.fromfile(tmp_path / "out.f32", dtype="<f4").reshape(streams * cps, T * hop)
     for s in (0, streams - 1):
@@ -192,6 +193,9 @@ def test_node_sharded_bench_reports_what_it_measured():
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["requested_gpus"] == 8 and j["replicas_measured"] == j["n_gpus"] == min(8, j["devices_present"]) and j["shards"] == 8
     assert j["frames_per_s"] > 1e4 and j["output_rms_stream0"] > 1e-3
+    # 8 shards on the devices present: the libuv pool was raised to 8 before it started, so all eight batches were in flight together
+    # (with the default pool of 4 at most four worker-thread windows overlap)
+    assert j["config"]["uv_threadpool_size"] >= 8 and j["shards_in_flight_together"] >= 6, j
 
 
 @pytest.mark.gpu

@@ -96,6 +96,18 @@ out.devices = m.deviceCount();
     m.processBegin(h, [x.subarray(0, 256), x.subarray(256, 512)], 1.5);
     m.processEnd(h, o, 2);
     out.quantum = o[0].some((v) => v !== 0);
+    // round 4: fewer output arrays than begun channels (ADVICE r3: the addon passes exactly the begun count, NULL for the missing ones)
+    m.processBegin(h, [x.subarray(0, 256), x.subarray(256, 512)], 1.5);
+    m.processEnd(h, [o[0]]);
+    // pinned buffers: pipelined batch through external ArrayBuffers, strided rows, window of the worker thread
+    const px = m.allocPinned(2 * 8 * 256 + 512), py = m.allocPinned(2 * 8 * 256 + 512);
+    px.set(x.subarray(0, 8 * 256), 0); px.set(x.subarray(8 * 256), 8 * 256 + 256);
+    m.reset(h);
+    await m.processBatchAsync(h, px, py, 2, 8, p, 0, 1, 8 * 256 + 256);
+    out.pinned_equal = Buffer.compare(Buffer.from(py.buffer, 0, 8 * 256 * 4), Buffer.from(y.buffer, 0, 8 * 256 * 4)) === 0
+                    && Buffer.compare(Buffer.from(py.buffer, (8 * 256 + 256) * 4, 8 * 256 * 4), Buffer.from(y.buffer, 8 * 256 * 4, 8 * 256 * 4)) === 0;
+    const w = m.batchWindow(h);
+    out.window_ok = w.length === 2 && w[1] >= w[0] && w[0] > 0;
     m.destroy(h);
     try { m.info(h); out.destroyed = 'no throw'; } catch (e) { out.destroyed = e.code; }
   } else {
@@ -128,7 +140,7 @@ def _run_addon(tmp_path):
 @pytest.mark.skipif(NODE is None, reason="node not installed")
 def test_napi_addon_error_paths_under_asan(tmp_path):
     out = _run_addon(tmp_path)
-    assert out["exports"] == 13 and out["bad"] == "FFT size must be a power of two and bigger than 1" and out["nohandle"] == "throws"
+    assert out["exports"] == 15 and out["bad"] == "FFT size must be a power of two and bigger than 1" and out["nohandle"] == "throws"
     if out["devices"] == 0:
         assert "no HIP device" in out["nodev"]
 
@@ -138,3 +150,4 @@ def test_napi_addon_error_paths_under_asan(tmp_path):
 def test_napi_addon_full_surface_under_asan(tmp_path):
     out = _run_addon(tmp_path)
     assert out["devices"] >= 1 and out["busy"] == "PV_BUSY" and out["async_equal"] is True and out["quantum"] is True and out["destroyed"] == "PV_6"
+    assert out["pinned_equal"] is True and out["window_ok"] is True
