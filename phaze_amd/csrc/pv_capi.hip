@@ -40,6 +40,8 @@ struct pv_handle {
     float *d_hist[2], *d_acc[2];
     int cur;
     float *d_stage_in, *d_stage_out, *d_pitch;   // host-buffer batch staging
+    unsigned *d_chain_list;                      // N = 1024 batch launches: chain classes (pv_launch_wave), 2 + 2 * chain_list_cap words
+    long chain_list_cap;
     hipStream_t s_in, s_out;                     // pipelined host-buffer batch: H2D of piece k+1 || kernel of piece k || D2H of piece k-1 (created on first use)
     hipEvent_t ev_in[kMaxPieces], ev_k[kMaxPieces];
     bool pipe_ready;
@@ -148,8 +150,9 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
 
 // One launch over the channel slots [ch0, ch0 + nch) x [nhops] hops, reading the current half of the state ping-pong and writing the other one.
 // d_in / d_out / d_pitch are the pointers of slot ch0 (the caller has applied the offsets); ch0 only places the state.  Nothing is committed.
+// spread: what the HOST knows about the pitchFactors of the launch (> 0: all >= 1, 0: not all, < 0: nothing -- they live in device memory)
 int launch_chain(pv_handle *h, const float *d_in, float *d_out, int ch0, int nch, int nhops, long ch_stride, const float *d_pitch,
-                 int pitch_stride, int ch_per_stream, bool chunked, int dbg_ch, unsigned done_seq)
+                 int pitch_stride, int ch_per_stream, bool chunked, int dbg_ch, unsigned done_seq, int spread = -1)
 {
     PvKernelParams p;
     memset(&p, 0, sizeof p);
@@ -177,7 +180,21 @@ int launch_chain(pv_handle *h, const float *d_in, float *d_out, int ch0, int nch
         e = pv_launch_pair(p, nch, nchunks, h->stream);
     } else {
         if (!h->use_wave && nch > 65535) return fail(h, PV_ERR_CAPACITY, "more than 65535 channel slots in one launch (grid.y limit): split the call");
-        e = h->use_wave ? pv_launch_wave(p, nch, nchunks, h->stream)
+        unsigned *list = nullptr;
+        if (h->use_wave && spread < 0 && dbg_ch < 0) {
+            // chain classes are sorted on the device: room for two lists of nch * nchunks chains (grown on demand; a launch in flight may still read the old one)
+            const long chains = (long)nch * nchunks;
+            if (chains > h->chain_list_cap) {
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                if (h->d_chain_list) (void)hipFree(h->d_chain_list);
+                h->d_chain_list = nullptr; h->chain_list_cap = 0;
+                const long cap = chains + chains / 2 + 64;
+                HIPCHK(h, hipMalloc(&h->d_chain_list, sizeof(unsigned) * (size_t)(2 + 2 * cap)));
+                h->chain_list_cap = cap;
+            }
+            list = h->d_chain_list;
+        }
+        e = h->use_wave ? pv_launch_wave(p, nch, nchunks, h->stream, spread, list)
           : h->use_wg ? pv_launch_wg(h->log2n, p, nch, nchunks, h->stream)
                       : pv_launch_chain(h->log2n, p, nch, nchunks, h->stream);
     }
@@ -202,9 +219,9 @@ int commit_chain(pv_handle *h, int nch, int nhops)
 
 // One launch over [nch] channel slots x [nhops] hops; flips the state ping-pong and advances timeCursor.
 int run_chain(pv_handle *h, const float *d_in, float *d_out, int nch, int nhops, long ch_stride, const float *d_pitch,
-              int pitch_stride, int ch_per_stream, bool commit, int dbg_ch, unsigned done_seq = 0)
+              int pitch_stride, int ch_per_stream, bool commit, int dbg_ch, unsigned done_seq = 0, int spread = -1)
 {
-    const int rc = launch_chain(h, d_in, d_out, 0, nch, nhops, ch_stride, d_pitch, pitch_stride, ch_per_stream, commit, dbg_ch, done_seq);
+    const int rc = launch_chain(h, d_in, d_out, 0, nch, nhops, ch_stride, d_pitch, pitch_stride, ch_per_stream, commit, dbg_ch, done_seq, spread);
     if (rc != PV_OK || !commit) return rc;
     return commit_chain(h, nch, nhops);
 }
@@ -495,6 +512,7 @@ int pv_destroy(pv_handle *h)
     (void)hipFree(h->d_tw64); (void)hipFree(h->d_tw32); (void)hipFree(h->d_hann);
     for (int i = 0; i < 2; i++) { (void)hipFree(h->d_hist[i]); (void)hipFree(h->d_acc[i]); }
     (void)hipFree(h->d_stage_in); (void)hipFree(h->d_stage_out); (void)hipFree(h->d_pitch);
+    if (h->d_chain_list) (void)hipFree(h->d_chain_list);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_done) (void)hipHostFree((void *)h->h_done);
     if (h->h_ctl) { if (h->resident_bar) (void)hipFree((void *)h->h_ctl); else (void)hipHostFree((void *)h->h_ctl); }
@@ -691,12 +709,12 @@ int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t 
             float *m_in = (bar ? h->d_quantum : h->d_pin_mapped) + kHdrFloats, *m_out = h->d_pin_mapped + kHdrFloats + (size_t)h->max_channels * hop;
             unsigned seq = 0;
             if (h->d_done) { seq = ++h->quantum_seq; if (seq == 0) seq = h->quantum_seq = 1; }
-            return run_chain(h, m_in, m_out, nch, 1, hop, bar ? h->d_quantum : h->d_pin_mapped, 0, 1, true, -1, seq);
+            return run_chain(h, m_in, m_out, nch, 1, hop, bar ? h->d_quantum : h->d_pin_mapped, 0, 1, true, -1, seq, pitch_factor >= 1.0f ? 1 : 0);
         }
         float *dq_in = h->d_quantum + kHdrFloats, *dq_out = dq_in + (size_t)h->max_channels * hop;
         float *pin_out = pin_in + (size_t)h->max_channels * hop;
         HIPCHK(h, hipMemcpyAsync(h->d_quantum, h->h_pin, sizeof(float) * (kHdrFloats + (size_t)nch * hop), hipMemcpyHostToDevice, h->stream));
-        const int rc = run_chain(h, dq_in, dq_out, nch, 1, hop, h->d_quantum, 0, 1, true, -1);
+        const int rc = run_chain(h, dq_in, dq_out, nch, 1, hop, h->d_quantum, 0, 1, true, -1, 0, pitch_factor >= 1.0f ? 1 : 0);
         if (rc != PV_OK) return rc;
         HIPCHK(h, hipMemcpyAsync(pin_out, dq_out, sizeof(float) * (size_t)nch * hop, hipMemcpyDeviceToHost, h->stream));
         return PV_OK;

@@ -106,7 +106,10 @@ __device__ __forceinline__ float2 rotate_route(unsigned route, float2 v, const f
         const float a = sw ? v.y : v.x, b = sw ? v.x : v.y;
         return float2{__uint_as_float(__float_as_uint(a) ^ ((((qd + 1u) >> 1) & 1u) << 31)), __uint_as_float(__float_as_uint(b) ^ ((qd >> 1) << 31))};
     }
-    return cmul(v, cconj(tw32[ridx & ((1u << LOG2N_) - 1u)]));   // masked: NOROUTE carries ridx = 0xFFFF
+    // v * conj(w), the order of the roundings spelled out: the instances of a kernel (streaming / batch, f >= 1 only / every f) must agree bit for bit,
+    // and a contraction left to the compiler comes out as fma(v.x, w.x, v.y * w.y) in one and fma(v.y, w.y, v.x * w.x) in another
+    const float2 w = tw32[ridx & ((1u << LOG2N_) - 1u)];                  // masked: NOROUTE carries ridx = 0xFFFF
+    return float2{__fmaf_rn(v.x, w.x, __fmul_rn(v.y, w.y)), __fmaf_rn(v.y, w.x, -__fmul_rn(v.x, w.y))};
 }
 
 

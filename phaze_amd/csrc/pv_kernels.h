@@ -40,6 +40,11 @@ struct PvKernelParams {
     float *hist2[2], *acc2[2];
     int in_cached;            // resident form: `in` / `pitch` are DEVICE memory the host rewrites through the BAR (cached in L2: system-scope loads);
                               // 0 = pinned host memory (uncached on the device: plain, coalesced loads behind the acquire fence of the poll)
+    // N = 1024 batch launches: the chains of the launch sorted into two classes by pv_classify_chains (pv_wave_kernel.hip) -- chain_list[0 .. nchains) holds the
+    // chains whose pitchFactor is >= 1 on every frame (count chain_count[0]), chain_list[nchains .. 2 nchains) the others (chain_count[1]); each class runs on
+    // its own instance of the kernel.  Null: chains are numbered directly (streaming quantum, test tap)
+    const unsigned *chain_list;
+    const unsigned *chain_count;
     unsigned *stamps;         // measurement builds only (-DPV_STAMPS, tools/exp_headline.sh): [chain][16] accumulated s_memtime deltas per phase
 };
 
@@ -64,7 +69,9 @@ hipError_t pv_launch_chain(int log2n, const PvKernelParams &p, int nch, int nchu
 size_t pv_wave_lds_bytes();
 int pv_wave_threads();
 bool pv_wave_supported(int log2n, int hop);
-hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
+// spread: > 0 every frame of the launch has pitchFactor >= 1 (the host knows: streaming quantum), 0 it does not, < 0 unknown: classify the chains on the device
+// (list = 2 * nch * nchunks + 2 words of device memory owned by the caller) and run each class on its instance
+hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st, int spread, unsigned *list);
 // resident form of the same kernel for streaming quanta (p.ctl != null): one wave per channel slot, nslots of them, polling p.ctl until ctl[4] (stop) or ~50 ms idle
 hipError_t pv_launch_wave_resident(const PvKernelParams &p, int nslots, hipStream_t st);
 hipError_t pv_launch_wave2k_resident(const PvKernelParams &p, int nslots, hipStream_t st);

@@ -51,13 +51,7 @@ constexpr int TAB_TW2F = TAB_TW1F + 4 * 64 * 16; // float4[4*8]    conj(W_64^{n0
 constexpr int TAB_HANN = TAB_TW2F + 4 * 8 * 16;  // float4[4*64]   0.5 * Hann at samples 2n, 2n+1 for n = l + 64 r: entry [j*64 + l] = (r = 2j, r = 2j+1).
                                                  //                ONE table serves both windows: the 1/2 of the split pass is folded in for the analysis
                                                  //                window, and the synthesis side folds 2/R into the scale of the c2r pass (all exact)
-#ifndef PV_INV_FP64
 constexpr int TAB_BYTES = TAB_HANN + 4 * 64 * 16;  // 17920
-#else
-constexpr int TAB_TW1C = TAB_HANN + 4 * 64 * 16;   // double2[8*64]  conj(W_512^{l k})   (measurement variant: fp64 inverse)
-constexpr int TAB_TW2C = TAB_TW1C + 8 * 64 * 16;   // double2[8*8]   conj(W_64^{n0 k})
-constexpr int TAB_BYTES = TAB_TW2C + 8 * 8 * 16;
-#endif
 
 // conj(W_512^{l k}) in fp32 from the pair-interleaved table (residue paths)
 __device__ __forceinline__ float2 tw1f_at(int k, int l)
@@ -110,34 +104,59 @@ struct Stamps {
 #endif
 
 
+// ---- per-wave LDS region (byte offsets) ----
+// The shifted spectrum Y and the fp32 spectrum stash XS are stored TRANSPOSED, eight rows of 68 slots:
+//     slot(t) = (t & 7) * 68 + (t >> 3),     byte address = 8 * slot(t) = t + (t & 7) * 543
+// because both are touched in two lane orders.  "Strided": lane l <-> bins l + 64 r (how the FFTs leave and take the spectrum): (l & 7) * 68 + (l >> 3)
+// + 8 r, the sixteen lanes of a ds_write_b64 group land on sixteen different bank pairs, r is an immediate offset.  "Natural": lane l <-> bins
+// 8 l + i (the peak search, and since round 4 the scatter): slot = 68 i + l, consecutive lanes on consecutive slots, i an immediate offset.  A
+// plain array is conflict-free in the first order and a 16-way bank conflict in the second (64 bytes between neighbouring lanes).
+constexpr int YROW = 68;
+constexpr int YSLOTS = 8 * YROW;    // 544 slots, 4352 bytes
+__device__ __forceinline__ unsigned yslot_bytes(unsigned t) { return __umul24(t & 7u, 543u) + t; }
+
+constexpr int OFF_Y = 0;            // float2[544]   shifted spectrum, transposed (aliases the fp64 transpose scratch: dead between the FFTs)
+constexpr int OFF_MAG = 4112;       // f32[520]      |X|^2: MAG[4 + k], k in [-4, 516) -- behind the four partner rows of the split pass, which are still being read
+                                    //               while the magnitudes are written.  Y's tail overlaps it: Y is zeroed after the magnitudes have been read
+constexpr int OFF_CLAIM = 4352;     // u16[544]      claim words of the fallback scatter (inside the dead magnitudes, behind Y)
+constexpr int OFF_ROUTE = 4352;     // u32[528]      f >= 1 frames: route of source bin b, from the lanes that compute it to the lanes that hold the bin (dead magnitudes +
+                                    //               the head of the stash, which only f < 1 frames use)
+constexpr int OFF_XS = 6224;        // float2[544]   fp32 spectrum stash, transposed: written by the split pass (strided), read by the scatter (natural) and the fast residue
+constexpr int OFF_RESQ = 6224;      // float2[256]   one quarter of the above-Nyquist residue at a time (general path) | c2r hand-over -- alias XS: never live together
+constexpr int OFF_PSH = OFF_XS + 8 * YSLOTS;   // i16[512]  shift table Math.round(p * f) - p
+constexpr int WAVE_LDS = OFF_PSH + 1024;       // 11600: 17920 + 12 * 11600 = 157120 B per workgroup (<= 160 KB)
+
 // f < 1: regions compress and `+=` collisions happen (pv:169-170).  LDS float atomics serialise per lane (measured: half of the frame
-// time), so collisions are resolved by CLAIM ROUNDS: every pending source writes its id to CLAIM[target], the id that sticks wins the
-// round and does a plain read-modify-write on Y; losers retry.  Rounds = max multiplicity of a target (2-3 for f >= 0.3).
+// time), so collisions that are not simple pairs (see "pairwise" in the kernel) are resolved by CLAIM ROUNDS: every pending source writes its id
+// to CLAIM[target], the id that sticks wins the round and does a plain read-modify-write on Y; losers retry.  Rounds = max multiplicity of a
+// target (2-3 for f >= 0.3).
 // YZERO: the caller guarantees that Y is still all zero (first scatter of a frame): the winners of round 1 then store their value instead
 // of a read-modify-write (0 + v == v bit for bit, also for v = -0: Y is +0 and +0 + -0 = +0 -- so a -0 component is stored as +0 explicitly).
 template <int NS, bool YZERO>
-__device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned short *CLAIM)
+__device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], unsigned char *Yb, unsigned short *CLAIM)
 {
     unsigned pend = 0;                                                     // (a bool per source would be carried through the loop as 0/1 VGPRs: slower)
-    unsigned tg[NS];
+    unsigned ta[NS];                                                       // byte address of the target's slot (both arrays are transposed: CLAIM[slot], Y[slot])
 #pragma unroll
     for (int r = 0; r < NS; r++) {
         const unsigned t = rt[r] & 0xFFFFu;
         const bool ok = t < 513u;                                          // valid route <=> target field < H
         pend |= ok ? (1u << r) : 0u;
-        tg[r] = ok ? t : 0u;                                               // in-range address for the unconditional reads below
+        ta[r] = yslot_bytes(ok ? t : 0u);                                  // in-range address for the unconditional reads below
     }
+    auto claim = [&](int r) -> unsigned short & { return CLAIM[ta[r] >> 3]; };
+    auto yat = [&](int r) -> float2 & { return *reinterpret_cast<float2 *>(Yb + ta[r]); };
     if (YZERO) {
 #pragma unroll
-        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[tg[r]] = (unsigned short)id[r];
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) claim(r) = (unsigned short)id[r];
         wave_sync();
         unsigned short c[NS];
 #pragma unroll
-        for (int r = 0; r < NS; r++) c[r] = CLAIM[tg[r]];
+        for (int r = 0; r < NS; r++) c[r] = claim(r);
 #pragma unroll
         for (int r = 0; r < NS; r++) {
             if ((pend & (1u << r)) && c[r] == (unsigned short)id[r]) {
-                Y[tg[r]] = float2{0.f + ys[r].x, 0.f + ys[r].y};           // what the reference's += leaves in a zeroed bin (pv:121,169-170)
+                yat(r) = float2{0.f + ys[r].x, 0.f + ys[r].y};             // what the reference's += leaves in a zeroed bin (pv:121,169-170)
                 pend &= ~(1u << r);
             }
         }
@@ -145,20 +164,20 @@ __device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const flo
     }
     while (__any(pend != 0u)) {
 #pragma unroll
-        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[tg[r]] = (unsigned short)id[r];
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) claim(r) = (unsigned short)id[r];
         wave_sync();
         // all claim words and all current Y values first (two batches of independent reads, one wait), then the winners' stores:
         // a per-source `if (CLAIM == id) { read Y; write Y }` costs two dependent LDS round trips per source instead
         unsigned short c[NS];
         float2 o[NS];
 #pragma unroll
-        for (int r = 0; r < NS; r++) c[r] = CLAIM[tg[r]];
+        for (int r = 0; r < NS; r++) c[r] = claim(r);
 #pragma unroll
-        for (int r = 0; r < NS; r++) o[r] = Y[tg[r]];
+        for (int r = 0; r < NS; r++) o[r] = yat(r);
 #pragma unroll
         for (int r = 0; r < NS; r++) {
             if ((pend & (1u << r)) && c[r] == (unsigned short)id[r]) {
-                Y[tg[r]] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
+                yat(r) = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
                 pend &= ~(1u << r);
             }
         }
@@ -166,43 +185,26 @@ __device__ __forceinline__ void claim_rounds(const unsigned (&rt)[NS], const flo
     }
 }
 
-// per-wave LDS region (byte offsets): see the carve in the kernel
-#ifndef PV_INV_FP64
-constexpr int OFF_Y = 0;            // float2[513]   shifted spectrum
-constexpr int OFF_ROUTE = 4112;     // u32[528] routes | f32 mags (alias) | u16 claim ids (alias, after the routes are in registers)
-constexpr int OFF_RESQ = 6224;      // float2[256]   one quarter of the above-Nyquist residue at a time (general path) | c2r hand-over
-constexpr int OFF_XS = 6224;        // float2[513]   fp32 spectrum stash of the fast residue path (aliases RESQ: never live together)
-constexpr int OFF_PSH = 10336;      // i16[512]      shift table Math.round(p * f) - p
-constexpr int WAVE_LDS = OFF_PSH + 1024;   // 11360: 22016 + 12 * 11360 = 158336 B per workgroup (<= 160 KB)
-#else
-// Measurement variant (never the product; DESIGN.md section 4, "all-fp64 data point"): shifted spectrum, c2r pass and inverse FFT in fp64 like
-// the reference (freqComplexBufferShifted / inverseTransform are plain JS doubles, bundle:102-114) -- f >= 1 frames only (a frame with f < 1
-// comes out silent).  Y is double2[513] and cannot alias the routes any more; 8 waves per workgroup (build with -DPV_WAVES=8 -DPV_WAVES_PER_SIMD=2).
-constexpr int OFF_Y = 0;            // double2[513]
-constexpr int OFF_ROUTE = 9216;
-constexpr int OFF_RESQ = 11328;     // double2[256] c2r hand-over
-constexpr int OFF_XS = 11328;
-constexpr int OFF_PSH = 15424;
-constexpr int WAVE_LDS = OFF_PSH + 1024;
-#endif
-
 // Above-Nyquist residue, fast path.  What fft.js's in-place real radix-4 DIT leaves at positions 512..640 is the clean first half
 // of the 256-point sub-DFT S2 of xw[4n+2] (its last stage never touches quarter 2, bundle:329-441), and the decimation identity
 //     W^{2k} S2[k] = (X[k] - X[k+256] + X[k+512] - X[k+768]) / 4,   W = exp(-2 pi j / 1024),   X[1024 - i] = conj(X[i])
-// gives it from the spectrum the frame already has: four LDS reads and a twiddle per bin instead of re-running a 256-point FFT.  Valid
-// while the last region ends at or below position 641 (f >= 0.75 always; lower f when the last peak sits low enough); the general path
-// below covers the rest.  Sources b = 513 + l + 64 j, j < 2, all owned by the last peak (pv:133): b -> b + up_delta.
+// gives it from the spectrum the frame already has -- the stash XS every frame writes --: four LDS reads and a twiddle per bin instead of re-running a
+// 256-point FFT.  Valid while the last region ends at or below position 641 (f >= 0.75 always; lower f when the last peak sits low enough); the
+// general path below covers the rest.  Sources b = 513 + l + 64 j, j < 2, all owned by the last peak (pv:133): b -> b + up_delta.
 template <int R_>
 __device__ __forceinline__ void residue_fast_1024(const float2 *__restrict__ tw32, unsigned wave_off, int l, int upper_end, int up_delta,
-                                                  unsigned up_ridx, double *dbg_X, unsigned (&rt)[2], float2 (&ys)[2], int (&id)[2])
+                                                  unsigned up_ridx, double *dbg_X, unsigned (&rt)[2], float2 (&ys)[2])
 {
     constexpr int H = 513;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    const float2 *XS = reinterpret_cast<const float2 *>(smem_all + wave_off + OFF_XS);
+    const unsigned char *XSb = smem_all + wave_off + OFF_XS;
+    // k = 1 + l + 64 j, k + 256, 512 - k, 256 - k: the two members of each pair sit 32 slots (256 bytes) apart, j moves every address by +-8 slots
+    const unsigned a0 = yslot_bytes((unsigned)(1 + l)), a2 = yslot_bytes((unsigned)(192 - 1 - l));        // slot(k) at j = 0; slot(256 - k) at j = 1
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int k = 1 + l + 64 * j, b = 512 + k, tgt = b + up_delta;        // k in [1, 128]
-        const float2 x0 = XS[k], x1 = XS[k + 256], x2 = XS[512 - k], x3 = XS[256 - k];
+        const float2 x0 = *reinterpret_cast<const float2 *>(XSb + a0 + 64 * j), x1 = *reinterpret_cast<const float2 *>(XSb + a0 + 64 * j + 256);
+        const float2 x3 = *reinterpret_cast<const float2 *>(XSb + a2 + 64 * (1 - j)), x2 = *reinterpret_cast<const float2 *>(XSb + a2 + 64 * (1 - j) + 256);
         const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
         // W^{-2k} = conj(W_512^k) = conj(W_512^{k & 63}) * conj(W_8^{k >> 6}) from the LDS table (a global table load would sit, exposed, on the
         // critical path of every f < 1 frame)
@@ -214,29 +216,29 @@ __device__ __forceinline__ void residue_fast_1024(const float2 *__restrict__ tw3
         const float2 s2 = cmul(tsum, w);
         rt[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
         ys[j] = rotate_route<R_, 10>(rt[j], s2, tw32);
-        id[j] = b;
         if (dbg_X && b < upper_end) { dbg_X[2 * b] = s2.x; dbg_X[2 * b + 1] = s2.y; }
     }
 }
 
-// Rare path (f < 1 frames whose last region reads above Nyquist): rebuild what fft.js's in-place real DIT leaves at positions
-// N/2+1..N-1 -- one quarter of the buffer at a time (quarter 2 = sub-FFT of x[4n+2], positions 512..767; quarter 3 = x[4n+3], 768..1023),
+// Rare path (f < 1 frames whose last region reads above Nyquist beyond position 640): rebuild what fft.js's in-place real DIT leaves at
+// positions N/2+1..N-1 -- one quarter of the buffer at a time (quarter 2 = sub-FFT of x[4n+2], positions 512..767; quarter 3 = x[4n+3], 768..1023),
 // by re-running the reference's stage structure (bundle:306-442,468-508) on that quarter in fp32 -- and add those sources into Y.
 // Kept out of line so that its registers do not count against the main pipeline (3 waves per SIMD need <= 168 VGPRs).
+// plain: the frame passed the pairwise test, nothing but the residue itself lands on the residue's targets (the continuation of the last region):
+// stores instead of claim rounds.
 template <int R_>
-__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(const float *in, const float *hist, int hist_len, bool sys, long s0, const float *__restrict__ hann,
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(const float *in, const float *hist, int hist_len, bool sys, long s0,
                                                                const float2 *__restrict__ tw32, unsigned wave_off, int l, int upper_end, int up_delta,
-                                                               unsigned up_ridx, double *dbg_X)
+                                                               unsigned up_ridx, double *dbg_X, bool plain)
 {
     constexpr int N = 1024, H = 513;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    float2 *Y = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_Y);
-    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + OFF_ROUTE);
+    unsigned char *Yb = smem_all + wave_off + OFF_Y;
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + OFF_CLAIM);
     float2 *Q = reinterpret_cast<float2 *>(smem_all + wave_off + OFF_RESQ);
     // 0.5 * Hann of sample s = 2n + c, n = ln + 64 r, from the pair-interleaved shared table (entry [(r >> 1) * 64 + ln] = rows 2j, 2j+1)
     const float *HWf = reinterpret_cast<const float *>(smem_all + TAB_HANN);
     auto hw_at = [&](int smp) { const int n = smp >> 1, ln = n & 63, r = n >> 6; return HWf[4 * ((r >> 1) * 64 + ln) + 2 * (r & 1) + (smp & 1)]; };
-    (void)hann;
     const WaveSrc src{in, hist, hist_len, sys};
     for (int base = N / 2; base < N && base < upper_end; base += N / 4) {
         {   // base stage: radix-4 blocks t = base/4 + l (bundle:468-508), input index = base-4 digit reversal of t
@@ -293,7 +295,13 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(co
             ys[j] = rotate_route<R_, 10>(rt[j], Q[l + 64 * j], tw32);
             id[j] = b;
         }
-        claim_rounds<4, false>(rt, ys, id, Y, CLAIM);
+        if (plain) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (rt[j] != NOROUTE) *reinterpret_cast<float2 *>(Yb + yslot_bytes(rt[j] & 0xFFFFu)) = ys[j];
+            wave_sync();
+        } else {
+            claim_rounds<4, false>(rt, ys, id, Yb, CLAIM);
+        }
     }
 }
 
@@ -315,95 +323,40 @@ __device__ __attribute__((noinline)) void build_shift_table_1024(float f, unsign
     }
 }
 
-// f < 1: the whole colliding scatter (two passes or claim rounds, + residue) lives out of line, so that its registers (nine routes, nine rotated values,
-// the batched claim reads) do not count against the main pipeline, whose f >= 1 path needs every one of its 168 VGPRs.
-struct Spectrum9 { float2 a[4], b[4], h; };     // bins l + 64 r, 512 - l - 64 r (r < 4), and 256 (lane 0)
-
-#ifndef PV_COLLIDE_ATTR
-#define PV_COLLIDE_ATTR __attribute__((noinline))
-#endif
-#ifndef PV_PAIRWISE
-#define PV_PAIRWISE 1                                                       // 0: every f < 1 frame goes through the claim rounds (A/B, tools/experiments)
-#endif
+// f < 1, frames that fail the pairwise test (f below ~0.65 with dense peaks): the colliding scatter with claim rounds, out of line.  It takes
+// its nine routes (bins 8 l + i, and bin 512 in lane 63's ninth) as arguments and its sources from the stash the frame wrote anyway.
+struct Routes9 { unsigned r[9]; };
 template <int R_>
-__device__ PV_COLLIDE_ATTR PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 X, unsigned wave_off, int l, int tmod, int last_peak, int upper_end, bool pairwise,
-                                                                               const float *in, const float *hist, int hist_len, bool sys, long s0,
-                                                                               const float *__restrict__ hann, const float2 *__restrict__ tw32, double *dbg_X)
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void scatter_claims_1024(Routes9 RT, unsigned wave_off, int l, int tmod, int last_peak, int upper_end,
+                                                                            const float *in, const float *hist, int hist_len, bool sys, long s0,
+                                                                            const float2 *__restrict__ tw32, double *dbg_X)
 {
     constexpr int N = 1024, H = 513;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     unsigned char *smem = smem_all + wave_off;
-    float2 *Y = reinterpret_cast<float2 *>(smem + OFF_Y);
-    const unsigned *ROUTE = reinterpret_cast<const unsigned *>(smem + OFF_ROUTE);
-    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + OFF_ROUTE);
+    unsigned char *Yb = smem + OFF_Y;
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + OFF_CLAIM);
+    const unsigned char *XSb = smem + OFF_XS;
     const short *DSH = reinterpret_cast<const short *>(smem + OFF_PSH);
     unsigned rt[9];
     float2 ys[9];
     int id[9];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        id[r] = l + 64 * r; rt[r] = ROUTE[id[r]]; ys[r] = X.a[r];
-        id[4 + r] = 512 - l - 64 * r; rt[4 + r] = ROUTE[id[4 + r]]; ys[4 + r] = X.b[r];
-    }
-    rt[8] = (l == 0) ? ROUTE[256] : NOROUTE;
-    ys[8] = X.h;
-    id[8] = 256;
-    // rotations: none when tmod = 0, signs only when tmod = N/2 (bit 25 of the route), the general form otherwise (wave-uniform)
-    if (tmod == N / 2) {
+    for (int i = 0; i < 9; i++) rt[i] = RT.r[i];
 #pragma unroll
-        for (int r = 0; r < 9; r++) {
-            const unsigned sg = (rt[r] << 6) & 0x80000000u;
-            ys[r] = float2{__uint_as_float(__float_as_uint(ys[r].x) ^ sg), __uint_as_float(__float_as_uint(ys[r].y) ^ sg)};
-        }
-    } else if (tmod != 0) {
+    for (int i = 0; i < 8; i++) { id[i] = 8 * l + i; ys[i] = *reinterpret_cast<const float2 *>(XSb + 8 * l + 544 * i); }
+    id[8] = 512;
+    ys[8] = *reinterpret_cast<const float2 *>(XSb + 512);                // slot(512) = 64: every lane reads it, only lane 63's ninth route is valid
 #pragma unroll
-        for (int r = 0; r < 9; r++) ys[r] = rotate_route<R_, 10>(rt[r], ys[r], tw32);
-    }
-    const bool need_res = upper_end > H && !(PV_ABL & 32);
+    for (int i = 0; i < 9; i++) ys[i] = rotate_route<R_, 10>(rt[i], ys[i], tw32);
+    const bool need_res = upper_end > H;
     const bool fast_res = need_res && (upper_end <= H + 128);
     // sources above Nyquist, all owned by the last peak (pv:133)
     const int up_delta = need_res ? (int)DSH[last_peak < 0 ? 0 : last_peak] : 0;
     const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
-    if (pairwise) {
-        // Two passes instead of claim rounds (see the peak search: every collision is falling side x rising side): pass A, the falling-side sources
-        // and the residue (it continues the falling side of the last peak) store into the zeroed Y; pass B, the rising-side sources read, add, store.
-        if (fast_res) {
-            float2 *XS = reinterpret_cast<float2 *>(smem + OFF_XS);
-#pragma unroll
-            for (int r = 0; r < 4; r++) { XS[l + 64 * r] = X.a[r]; XS[512 - l - 64 * r] = X.b[r]; }
-            if (l == 0) XS[256] = X.h;
-        }
-        unsigned key[9];
-#pragma unroll
-        for (int r = 0; r < 9; r++) key[r] = rt[r] & 0x8000FFFFu;         // side bit | target: < 513 = a valid falling-side source
-#pragma unroll
-        for (int r = 0; r < 9; r++) if (key[r] < 513u) Y[key[r]] = ys[r];
-        wave_sync();
-        float2 o[9];
-#pragma unroll
-        for (int r = 0; r < 9; r++) o[r] = Y[rt[r] & 0x3FFu];              // (any address inside the wave's own region will do for the sources that do not add)
-        if (fast_res) {
-            unsigned rt2[2];
-            float2 ys2[2];
-            int id2[2];
-            residue_fast_1024<R_>(tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X, rt2, ys2, id2);
-#pragma unroll
-            for (int j = 0; j < 2; j++) if ((rt2[j] & 0xFFFFu) < 513u) Y[rt2[j] & 0xFFFFu] = ys2[j];
-        }
-#pragma unroll
-        for (int r = 0; r < 9; r++) if (key[r] - 0x80000000u < 513u) Y[rt[r] & 0x3FFu] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
-        if (need_res && !fast_res) residue_scatter_1024<R_>(in, hist, hist_len, sys, s0, hann, tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
-        return;
-    }
+    // fill the claim words of this frame's targets?  No: a claim word is only ever compared with the ids posted in the SAME round, stale words are harmless.
+    claim_rounds<9, true>(rt, ys, id, Yb, CLAIM);
     if (fast_res) {
-        // fast form of the residue: stash the fp32 spectrum, run the nine ordinary sources through their claim rounds, then the two residue
-        // sources of every lane through a series of their own.  (Measured in round 3: ONE series over eleven sources is 9 % slower at f = 0.8 --
-        // the eleven-wide round spills inside this function -- and forming the residue sources inline instead of in a nested call is worth 2 %.)
-        float2 *XS = reinterpret_cast<float2 *>(smem + OFF_XS);
-#pragma unroll
-        for (int r = 0; r < 4; r++) { XS[l + 64 * r] = X.a[r]; XS[512 - l - 64 * r] = X.b[r]; }
-        if (l == 0) XS[256] = X.h;
-        wave_sync();                                                   // (also: routes are in registers, CLAIM may overwrite ROUTE)
         // The residue sources b = 513 .. upper_end - 1 land on the targets 513 + delta .. upper_end - 1 + delta, above every target of the last
         // region's ordinary sources (b <= 512).  Unless a source of an EARLIER region reaches up there too (only when the last region is shorter
         // than the overlap of its neighbour), nothing else touches those bins: they are still zero and the residue is stored, no claim rounds.
@@ -411,33 +364,34 @@ __device__ PV_COLLIDE_ATTR PV_NO_DS_MERGE void scatter_colliding_1024(Spectrum9 
 #pragma unroll
         for (int r = 0; r < 9; r++) { const unsigned t = rt[r] & 0xFFFFu; clash |= (t < 513u) && ((int)t > 512 + up_delta); }
         const bool plain_res = !__any(clash);
-        claim_rounds<9, true>(rt, ys, id, Y, CLAIM);
         unsigned rt2[2];
         float2 ys2[2];
-        int id2[2];
-        residue_fast_1024<R_>(tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X, rt2, ys2, id2);
+        residue_fast_1024<R_>(tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X, rt2, ys2);
         if (plain_res) {
 #pragma unroll
-            for (int j = 0; j < 2; j++) if ((rt2[j] & 0xFFFFu) < 513u) Y[rt2[j] & 0xFFFFu] = float2{0.f + ys2[j].x, 0.f + ys2[j].y};
+            for (int j = 0; j < 2; j++) if ((rt2[j] & 0xFFFFu) < 513u) *reinterpret_cast<float2 *>(Yb + yslot_bytes(rt2[j] & 0xFFFFu)) = float2{0.f + ys2[j].x, 0.f + ys2[j].y};
         } else {
-            claim_rounds<2, false>(rt2, ys2, id2, Y, CLAIM);
+            const int id2[2] = {513 + l, 513 + 64 + l};
+            claim_rounds<2, false>(rt2, ys2, id2, Yb, CLAIM);
         }
-        return;
+    } else if (need_res) {
+        residue_scatter_1024<R_>(in, hist, hist_len, sys, s0, tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X, false);
     }
-    wave_sync();                                                       // routes are in registers: CLAIM may overwrite ROUTE
-    if (PV_ABL & 64) {                                                 // timing-only build: plain stores (collisions lose contributions)
-#pragma unroll
-        for (int r = 0; r < 9; r++) if ((rt[r] & 0xFFFFu) < 513u) Y[rt[r] & 0xFFFFu] = ys[r];
-    } else
-    claim_rounds<9, true>(rt, ys, id, Y, CLAIM);
-    if (need_res) residue_scatter_1024<R_>(in, hist, hist_len, sys, s0, hann, tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg_X);
 }
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
 // AUX = true: test-tap instance (pv_debug_frame); the production instance carries no tap code.
 // RESIDENT = true: streaming instance that stays on the GPU (PV_FLAG_PERSISTENT_STREAM): after its quantum a wave polls the control block in pinned host memory
 // for the next sequence number instead of ending (pv_capi.hip: persist_*); a quantum then costs no launch.  One wave per channel slot, 1 hop per quantum.
-template <int S_ROWS, bool AUX, bool RESIDENT = false>
+// SPREAD = true: the instance for frame chains whose pitchFactor is >= 1 on EVERY frame (chosen per chain: pv_classify_chains below / the host for a
+// streaming quantum).  Its regions only spread, every target has one source: the spectrum stays in the registers the split pass leaves it in (lane l
+// <-> bins l + 64 r, 512 - l - 64 r), the routes travel from the lanes that compute them (8 consecutive bins each) through a table in LDS, Y is a
+// plain array, and none of the f < 1 machinery exists in the instance.  SPREAD = false handles every pitchFactor; there the SPECTRUM travels instead:
+// rounded to fp32 into a transposed stash, read back by the lanes that compute the routes, which then scatter their own 8 bins into a transposed Y --
+// no route table, and the stash is what the above-Nyquist residue is computed from anyway: an f < 1 frame makes three dependent LDS round trips in
+// its scatter where round 3 made five.  (One instance that chooses per frame was tried first: the register allocator does not keep the two flows
+// apart, at 168 VGPRs the f >= 1 flow then reloads its source bins from scratch memory.)
+template <int S_ROWS, bool AUX, bool RESIDENT = false, bool SPREAD = false>
 __global__ __launch_bounds__(64 * (RESIDENT ? RES_WAVES : WAVES), RESIDENT ? 1 : PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void pv_wave_kernel_1024(const PvKernelParams p)
 {
     constexpr int WGW = RESIDENT ? RES_WAVES : WAVES;                    // waves per workgroup of this instance
@@ -447,9 +401,18 @@ __global__ __launch_bounds__(64 * (RESIDENT ? RES_WAVES : WAVES), RESIDENT ? 1 :
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // chains are numbered channel-major over (channel, chunk) and packed 12 to a workgroup regardless of the channel they belong to: many short
     // streams (one chunk per channel) fill the workgroups exactly like one long stream does
-    const long chain = (long)blockIdx.x * WGW + wv;
+    // batch launches: the chains of this instance's class come from the list pv_classify_chains compacted (p.chain_list: [0, nchains) the SPREAD class,
+    // [nchains, 2 nchains) the other; p.chain_count[class] entries); a streaming quantum / the tap instance numbers its chains directly
+    long chain = (long)blockIdx.x * WGW + wv;
+    bool listed = true;
+    if (!RESIDENT && p.chain_list) {
+        const long total = (long)p.nch * p.nchunks;
+        listed = chain < (long)p.chain_count[SPREAD ? 0 : 1];
+        chain = listed ? (long)p.chain_list[(SPREAD ? 0 : total) + chain] : total;
+    }
     const int ch = (int)(chain / p.nchunks), chunk = (int)(chain - (long)ch * p.nchunks);
 
+    if (!RESIDENT && p.chain_list && (long)blockIdx.x * WGW >= (long)p.chain_count[SPREAD ? 0 : 1]) return;     // no chain of this class left for the workgroup (uniform): not even the tables
     // ---- LDS carve (all dynamic, 16-byte aligned): shared tables, then one private region per wave ----
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const double2 *TW1 = reinterpret_cast<const double2 *>(smem_all + TAB_TW1);
@@ -467,24 +430,18 @@ __global__ __launch_bounds__(64 * (RESIDENT ? RES_WAVES : WAVES), RESIDENT ? 1 :
             const int k = i >> 6, ln = i & 63;
             const double2 w = p.tw64[(2 * ln * k) & (N - 1)];
             t1[i] = w;
-#ifdef PV_INV_FP64
-            reinterpret_cast<double2 *>(smem_all + TAB_TW1C)[i] = double2{w.x, -w.y};
-#endif
             t1f[2 * ((k >> 1) * 64 + ln) + (k & 1)] = float2{(float)w.x, -(float)w.y};
             hh[2 * ((k >> 1) * 64 + ln) + (k & 1)] = float2{0.5f * p.hann[2 * i], 0.5f * p.hann[2 * i + 1]};   // n = i = ln + 64 k: row k
             if (i < 64) {
                 const int k2 = i >> 3, n0 = i & 7;
                 const double2 w2 = p.tw64[(16 * n0 * k2) & (N - 1)];
                 t2[i] = w2;
-#ifdef PV_INV_FP64
-                reinterpret_cast<double2 *>(smem_all + TAB_TW2C)[i] = double2{w2.x, -w2.y};
-#endif
                 t2f[2 * ((k2 >> 1) * 8 + n0) + (k2 & 1)] = float2{(float)w2.x, -(float)w2.y};
             }
         }
     }
     __syncthreads();                                                     // the only workgroup-wide barrier
-    if (ch >= p.nch) return;
+    if (!listed || ch >= p.nch) return;
     // what changes from quantum to quantum in the resident form (constants of the launch otherwise)
     const float *hist_in = p.hist_in, *acc_in = p.acc_in;
     float *hist_out = p.hist_out, *acc_out = p.acc_out;
@@ -520,19 +477,13 @@ resident_top:
         }
     }
 
-#ifdef PV_PT_STATIC
-    {   // experiment: static priority by the wave's rank on its SIMD (waves wv, wv + 4, wv + 8 share one)
-        const int rank = (PV_PT_STATIC == 1) ? 2 - (wv >> 2) : (wv >> 2);
-        if (rank == 2) __builtin_amdgcn_s_setprio(2); else if (rank == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-    }
-#endif
     const unsigned wave_off = TAB_BYTES + wv * WAVE_LDS;
     unsigned char *smem = smem_all + wave_off;
     double2 *S64 = reinterpret_cast<double2 *>(smem);                    // 8*72*16 = 9216 B: fp64 transposes
     float2 *S32 = reinterpret_cast<float2 *>(smem);                      // fp32 transposes (first 4608 B)
-    float2 *Y = reinterpret_cast<float2 *>(smem + OFF_Y);                // shifted spectrum Y[0..512], between the FFTs
-    float *MAG = reinterpret_cast<float *>(smem + OFF_ROUTE);            // MAG[4 + k], k in [-4, 524): |X|^2 exchange
-    unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + OFF_ROUTE);    // aliases MAG once the flags are taken: route of source bin b
+    unsigned char *Yb = smem + OFF_Y;                                    // shifted spectrum Y[0..512], transposed (yslot_bytes), between the FFTs
+    unsigned char *XSb = smem + OFF_XS;                                  // fp32 copy of the spectrum, transposed: split pass -> scatter
+    float *MAG = reinterpret_cast<float *>(smem + OFF_MAG);              // MAG[4 + k], k in [-4, 516): |X|^2 exchange
     short *DSH = reinterpret_cast<short *>(smem + OFF_PSH);              // shift Math.round(p * f) - p per candidate peak bin p (DROP: peak dropped)
     unsigned psh_key = 0u;                                               // bit pattern of the f the table was built for
     bool psh_valid = false;                                              // ... once one has been built (any bit pattern, NaNs included, is a legal f)
@@ -627,11 +578,7 @@ resident_top:
         //      X[k] = E - j W^k O and X[512-k] = conj(E + j W^k O).  Lane l owns the pairs k = l + 64 r, r < 4 (partner value from lane
         //      64-l, register 7-r), i.e. bins XA[r] = X[l + 64 r] and XB[r] = X[512 - l - 64 r]; lane 0 also owns the self-paired bin 256.
         pv_prio(PH_SPLITX);
-        float2 XA[4], XB[4];               // fp32 copy of the spectrum: the only thing the shift needs after the decisions
-        float2 x256f{0.f, 0.f};
-#ifdef PV_INV_FP64
-        double2 XAd[4], XBd[4], x256d{0.0, 0.0};
-#endif
+        float2 XA[4], XB[4], x256f{0.f, 0.f};                              // fp32 copy of the spectrum: the only thing the shift needs after the decisions
         {
             // partner values through the (now free) transpose scratch: rows 4..7 written lane-contiguous, read back reversed.  Element
             // 512 - k of the pair k = l + 64 r sits at (3 - r) * 64 + (64 - l) for every lane (lane 0: 64 (8 - r), its own register
@@ -656,14 +603,12 @@ resident_top:
                         xb = double2{2.0 * (z[0].x - z[0].y), 0.0};
                     }
                 }
-                // ---- |X|^2 -> f32 (pv:82-92), exchanged through LDS for the neighbour tests ----
+                // ---- |X|^2 -> f32 (pv:82-92) for the neighbour tests, and the spectrum itself, rounded to fp32 (the only thing the shift needs after
+                //      the decisions), into the transposed stash: the lanes that take the decisions (8 consecutive bins each) also move the bins ----
                 MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
                 MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
                 XA[r] = float2{(float)xa.x, (float)xa.y};
                 XB[r] = float2{(float)xb.x, (float)xb.y};
-#ifdef PV_INV_FP64
-                XAd[r] = xa; XBd[r] = xb;
-#endif
                 if (dbg) {
                     const int ka = l + 64 * r, kb = 512 - ka;
                     p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
@@ -674,10 +619,20 @@ resident_top:
                 const double2 x256{2.0 * z[4].x, -2.0 * z[4].y};              // k = 256 pairs with itself: W^256 = -j, X = 2 conj(Z)
                 MAG[4 + 256] = (float)(x256.x * x256.x + x256.y * x256.y);
                 x256f = float2{(float)x256.x, (float)x256.y};
-#ifdef PV_INV_FP64
-                x256d = x256;
-#endif
                 if (dbg) { p.dbg_X[2 * 256] = x256.x; p.dbg_X[2 * 256 + 1] = x256.y; }
+            }
+            if constexpr (!SPREAD) {
+                // strided-order addresses of the transposed stash: bin l + 64 r at ystr + 64 r, bin 512 - l - 64 r at ystr_m + 64 (3 - r).  Formed HERE from an
+                // opaque copy of the lane id (four instructions per frame): as loop invariants they would live in registers across the forward FFT, the
+                // register peak of the kernel, and push other addresses into scratch
+                unsigned ystr, ystr_m;
+                { int lq = l; asm volatile("" : "+v"(lq)); ystr = yslot_bytes((unsigned)lq); ystr_m = yslot_bytes((unsigned)(512 - 192 - lq)); }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    *reinterpret_cast<float2 *>(XSb + ystr + 64 * r) = XA[r];
+                    *reinterpret_cast<float2 *>(XSb + ystr_m + 64 * (3 - r)) = XB[r];
+                }
+                if (l == 0) *reinterpret_cast<float2 *>(XSb + 256) = x256f;                           // slot(256) = 32
             }
         }
         // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change.  BEFORE the prefetch is issued: the
@@ -687,7 +642,6 @@ resident_top:
             const unsigned pfb = __float_as_uint(pfm);
             if (!psh_valid || pfb != psh_key) { psh_key = pfb; psh_valid = true; build_shift_table_1024(pfm, wave_off, l); }
         }
-#ifndef PV_RELOAD_ROWS
         // slide the window: the rows the next frame adds are issued here and land behind the shift + inverse FFT
 #pragma unroll
         for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
@@ -696,15 +650,18 @@ resident_top:
             load_rows(&raw[8 - S_ROWS], S_ROWS, 8 - S_ROWS, mn);
             pf_next = pitch_row[mn];
         }
-#endif
         wave_sync();
         PV_STAMP(4);
         pv_prio(PH_PEAKS);
-        // ---- peak flags (pv:95-116) for bins 8l..8l+7, nearest peaks by wave scans, then one ROUTE word per source bin ----
+        // ---- peak flags (pv:95-116) for bins 8l..8l+7, nearest peaks by wave scans, then one route per source bin -- and the source bins themselves:
+        //      lane l takes bins 8l .. 8l+7 (lane 63 also bin 512) out of the stash and moves them along its own routes ----
         int last_peak = -1, last_shift = 0;
         bool pairwise = false;                                              // wave-uniform, f < 1: every collision of this frame is a (falling side, rising side) pair
         bool nonfinite = false;                                             // wave-uniform: a magnitude of this frame is Inf or NaN
-        if (!(PV_ABL & 16)) {
+        unsigned rt[8];
+        unsigned rt512 = NOROUTE;
+        float2 xs[8], xs512;                                                // !SPREAD only: the lane's own source bins 8 l + i (and 512), from the stash
+        {
             // |X|^2 >= 0, so the fp32 order of two magnitudes is the order of their bit patterns as unsigned integers: the strict test
             // "greater than all four neighbours" (pv:100-110, `>=` rejects) becomes c > max(neighbours) with v_max3_u32 -- two instructions per
             // bin plus eight shared pair maxima, instead of four compares and three mask ANDs.
@@ -716,6 +673,13 @@ resident_top:
             const v4u q1 = *(lds_v4u)(&MAG[4 + 8 * l]);
             const v4u q2 = *(lds_v4u)(&MAG[4 + 8 * l + 4]);
             const v2u q3 = *(lds_v2u)(&MAG[4 + 8 * l + 8]);
+            const v4u dq = *(lds_v4u)(&DSH[8 * l]);
+            if constexpr (!SPREAD) {
+                // the lane's source bins, natural order: bin 8 l + i sits in row i of the transposed stash, lane-contiguous (conflict-free ds_read_b64)
+#pragma unroll
+                for (int i = 0; i < 8; i++) xs[i] = *reinterpret_cast<const float2 *>(XSb + 8 * l + 8 * YROW * i);
+                xs512 = *reinterpret_cast<const float2 *>(XSb + 512);       // slot(512) = 64; only lane 63 uses it
+            }
             mg[0] = q0.x; mg[1] = q0.y; mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w;
             mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w; mg[10] = q3.x; mg[11] = q3.y;
             unsigned pm[11];
@@ -741,7 +705,6 @@ resident_top:
             // 16-byte read of the shift table (a per-bin DSH[owner] lookup is a 4-way bank conflict by construction: lanes l and l + 16 sit
             // 256 bytes apart), and the neighbour lanes' peaks bring their shift along in the same bpermute.  Packed words order like bins.
             constexpr int NEGPD = -(2048 << 16), POSPD = 4096 << 16;        // "no peak on this side"
-            const v4u dq = *(lds_v4u)(&DSH[8 * l]);
             int pd[8];
 #pragma unroll
             for (int i = 0; i < 8; i++)                                     // bytes {d.lo, d.hi, bin.lo, bin.hi}
@@ -764,8 +727,6 @@ resident_top:
             int cprev = __shfl(last_in, src_lo, 64), cnext = __shfl(first_in, src_hi, 64);
             if (!below) cprev = NEGPD;
             if (!above) cnext = POSPD;
-            unsigned rt[8];
-            unsigned rt512 = NOROUTE;
             if (occ == 0ull) {                                              // no peak at all (wave-uniform): nothing moves (pv:122 loop is empty)
 #pragma unroll
                 for (int i = 0; i < 8; i++) rt[i] = NOROUTE;
@@ -776,7 +737,7 @@ resident_top:
                 // owner rule (pv:132-141): regions tile [0, N); a bin belongs to the peak on its left iff it is strictly closer to it
                 // (b < prv + ceil(gap/2)  <=>  b - prv < nxt - b; the midpoint of an even gap goes right).  Sentinels make the first
                 // region start at 0 (pv:132) and the last one end at N (pv:133); at least one side is a real peak here.
-                // shift (pv:147-152): ROUTE = ((delta * t) mod N) << 16 | target; a route is valid iff its target field is < H
+                // shift (pv:147-152): route = ((delta * t) mod N) << 16 | target; a route is valid iff its target field is < H
                 // (pv:127-129 via DROP, pv:150-152, negative index); bits above the 10 rotation bits are don't-care.
                 auto route_of = [&](int b, int pp, int pn) -> unsigned {
                     const int own = (b - (pp >> 16) < (pn >> 16) - b) ? pp : pn;
@@ -786,15 +747,15 @@ resident_top:
 #pragma unroll
                 for (int i = 0; i < 8; i++) rt[i] = route_of(8 * l + i, max(lastown[i], cprev), min(firstown[i], cnext));
                 if (l == 63) rt512 = route_of(512, max(last_in, cprev), POSPD);   // source bin N/2: owner is the last peak
-                if (!(pf >= 1.0)) {
+                if (!SPREAD && !(pf >= 1.0)) {
                     // f < 1: regions compress and their targets overlap (pv:169-170).  The targets of a region are contiguous, so the overlap of two
                     // neighbours is the LAST ov = delta_i - delta_{i+1} targets of region i against the FIRST ov of region i+1.  While ov <= floor(gap / 2)
                     // -- the length of the rising side of peak i+1, the shorter of the two sides that meet -- every collision is ONE source from the falling
                     // side of a peak (owned by the peak on its left, the peak bin included) against ONE from the rising side of the next peak (owned by the
                     // peak on its right), never two of a kind.  The scatter then needs no claim rounds: falling-side sources store, rising-side sources add
-                    // (scatter_colliding_1024) -- in the reference's order, region i before region i+1 (pv:122,146).  Bit 31 of a route = rising side
-                    // (route_of leaves a stray bit of delta * t there; the rotation ignores it); one gap with a longer overlap (f below ~0.6, or very
-                    // close peaks) sends the whole frame through the claim rounds instead.  tests/test_pairwise_rule.py checks the rule on random peak sets.
+                    // -- in the reference's order, region i before region i+1 (pv:122,146).  Bit 31 of a route = rising side (route_of leaves a stray bit
+                    // of delta * t there; the rotation ignores it); one gap with a longer overlap (f below ~0.6, or very close peaks) sends the whole frame
+                    // through the claim rounds instead.  tests/test_pairwise_rule.py checks the rule on random peak sets.
                     rt512 &= 0x7FFFFFFFu;                               // bin N/2: falling side of the last peak
                     bool bad = false;
 #pragma unroll
@@ -805,150 +766,157 @@ resident_top:
                         const int gap = (pn >> 16) - (pp >> 16), ov = __builtin_amdgcn_sbfe(pp, 0, 16) - __builtin_amdgcn_sbfe(pn, 0, 16);
                         bad |= ov > (gap >> 1);                             // (a missing neighbour is a sentinel thousands of bins away)
                     }
-                    pairwise = PV_PAIRWISE && !__any(bad);
+                    pairwise = !__any(bad);
                 }
             }
-            // MAG is dead now (every lane has its 12 magnitudes in registers): ROUTE aliases it
-            wave_sync();
-            *reinterpret_cast<uint4 *>(&ROUTE[8 * l]) = uint4{rt[0], rt[1], rt[2], rt[3]};
-            *reinterpret_cast<uint4 *>(&ROUTE[8 * l + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
-            if (l == 63) ROUTE[512] = rt512;
-        } else {                                                            // timing-only build: identity routes, no search
-            wave_sync();
-#pragma unroll
-            for (int i = 0; i < 8; i++) ROUTE[8 * l + i] = (unsigned)(8 * l + i);
-            if (l == 63) ROUTE[512] = 512u;
         }
         PV_STAMP(5);
         pv_prio(PH_SCATTER);
         int upper_end = H;
         if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
-#ifdef PV_INV_FP64
-        pk::c32 zi[8];
-        {
-            double2 *Yd = reinterpret_cast<double2 *>(smem + OFF_Y);
-#pragma unroll
-            for (int r = 0; r < 8; r++) Yd[l + 64 * r] = double2{0.0, 0.0};
-            if (l == 0) Yd[512] = double2{0.0, 0.0};
-            wave_sync();
-            if (pf >= 1.0) {                                                // (this variant moves nothing when f < 1)
-                auto rotd = [&](unsigned rt, double2 v) -> double2 {         // exp(+2 pi j ridx / N), R = 4: j^q exactly; else the fp64 table
-                    const unsigned ridx = (rt >> 16) & (N - 1);
-                    if (R == 4) { const unsigned q = ridx >> 8; return q == 0 ? v : q == 1 ? double2{-v.y, v.x} : q == 2 ? double2{-v.x, -v.y} : double2{v.y, -v.x}; }
-                    return cmul(v, cconj(p.tw64[ridx]));
-                };
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const unsigned ra = ROUTE[l + 64 * r], ta = ra & 0xFFFFu;
-                    const unsigned rb = ROUTE[512 - l - 64 * r], tb = rb & 0xFFFFu;
-                    if (ta < (unsigned)H) Yd[ta] = rotd(ra, XAd[r]);
-                    if (tb < (unsigned)H) Yd[tb] = rotd(rb, XBd[r]);
-                }
-                if (l == 0) { const unsigned rt = ROUTE[256], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Yd[tg] = rotd(rt, x256d); }
-            }
-            wave_sync();
-            // c2r pre-pass in fp64: Z[k] = SC ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)), conjugate pairs as in the product
-            double2 zd[8], zb[4];
-            const double sc = (double)SC;
-            const double2 wlc{wl.x, -wl.y};                                 // e^{+2 pi j l / N}
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int k = l + 64 * r;
-                double2 yk = Yd[k], ym = Yd[M - k];
-                if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
-                const double2 E{yk.x + ym.x, yk.y - ym.y}, O{yk.x - ym.x, yk.y + ym.y};
-                const double2 c = cmul(mul_w16<double, true>(O, r), wlc);
-                zd[r] = double2{(E.x - c.y) * sc, (E.y + c.x) * sc};        // E + j c
-                zb[r] = double2{(E.x + c.y) * sc, -(E.y - c.x) * sc};       // conj(E - j c)
-            }
-            const double2 y256 = Yd[256];
-            double2 *XCHd = reinterpret_cast<double2 *>(smem + OFF_RESQ);
-#pragma unroll
-            for (int r = 0; r < 4; r++) XCHd[r * 64 + l] = zb[r];
-            wave_sync();
-#pragma unroll
-            for (int r = 0; r < 4; r++) zd[7 - r] = XCHd[r * 64 + 64 - l];
-            if (l == 0) zd[4] = double2{2.0 * y256.x * sc, -2.0 * y256.y * sc};
-            wave_sync();
-            // inverse 512-point FFT in fp64: the forward routine with conjugated twiddles (LDS copies TW1C / TW2C built below the fp64 tables)
-            fft512_wave<double, true>(zd, S64, reinterpret_cast<const double2 *>(smem_all + TAB_TW1C), reinterpret_cast<const double2 *>(smem_all + TAB_TW2C), l);
-#pragma unroll
-            for (int r = 0; r < 8; r++) zi[r] = pk::c32{(float)zd[r].x, (float)zd[r].y};    // fromComplexArray -> Float32Array (bundle:46-51)
-        }
-#else
-        // ---- zero Y (pv:121); the transposes of the forward FFT are done with the scratch.  16 bytes per lane and store: four
-        //      ds_write_b128 (+ bin 512) instead of eight ds_write_b64 ----
-#pragma unroll
-        for (int r = 0; r < 4; r++) *reinterpret_cast<v4f *>(&Y[2 * l + 128 * r]) = v4f{0.f, 0.f, 0.f, 0.f};
-        if (l == 0) Y[512] = float2{0.f, 0.f};
-        // ---- residue above Nyquist only when the last region reads it ----
+        // ---- zero Y (pv:121).  The magnitudes have been read (LDS instructions of a wave execute in order): the routes (SPREAD) / Y's tail (!SPREAD) may overwrite them ----
         wave_sync();
-        // ---- shiftPeaks (pv:119-173): each lane moves its own source bins (registers) along the precomputed routes ----
+        float2 *Yn = reinterpret_cast<float2 *>(smem + OFF_Y);               // SPREAD: Y as a plain array of 513 bins
+        if constexpr (SPREAD) {
+            unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + OFF_ROUTE);
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * l]) = uint4{rt[0], rt[1], rt[2], rt[3]};
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * l + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
+            if (l == 63) ROUTE[512] = rt512;
+#pragma unroll
+            for (int r = 0; r < 4; r++) *reinterpret_cast<v4f *>(&Yn[2 * l + 128 * r]) = v4f{0.f, 0.f, 0.f, 0.f};     // 16 bytes per lane and store
+            if (l == 0) Yn[512] = float2{0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) *reinterpret_cast<v4f *>(Yb + 16 * l + 1024 * r) = v4f{0.f, 0.f, 0.f, 0.f};
+            { int lq = l; asm volatile("" : "+v"(lq)); *reinterpret_cast<v4f *>(Yb + ((lq < 16) ? 4096 + 16 * lq : 16 * lq)) = v4f{0.f, 0.f, 0.f, 0.f}; }   // the last 256 of the 4352 bytes (the other lanes repeat their first store: no exec mask)
+        }
+        wave_sync();
+        // ---- shiftPeaks (pv:119-173) ----
         {
-            // For f >= 1, delta_i = round(p_i f) - p_i is non-decreasing in i, so the shifted regions stay disjoint: plain stores.
-            const bool disjoint = (pf >= 1.0);
-            if (disjoint) {
-                // every rotation of this frame is exp(2 pi j delta (m mod R) / R) and m mod R is wave-uniform: a frame with m = 0 (mod R) moves its
-                // bins unrotated, m = R/2 (mod R) only flips signs (bit 9 of the rotation index = bit 25 of the route)
+            // every rotation of a frame is exp(2 pi j delta (m mod R) / R) and m mod R is wave-uniform: a frame with m = 0 (mod R) moves its bins unrotated,
+            // m = R/2 (mod R) only flips signs (bit 9 of the rotation index = bit 25 of the route); tmod = (m mod R) * N/R
+            auto rot_mode = [&](auto mode_tag, unsigned r_, float2 v) -> float2 {
+                constexpr int MODE = decltype(mode_tag)::value;
+                if (MODE == 0) return v;
+                if (MODE == 2) {
+                    const unsigned sg = (r_ << 6) & 0x80000000u;
+                    return float2{__uint_as_float(__float_as_uint(v.x) ^ sg), __uint_as_float(__float_as_uint(v.y) ^ sg)};
+                }
+                return rotate_route<R, 10>(r_, v, p.tw32);
+            };
+            [[maybe_unused]] auto ystore = [&](unsigned t, float2 v) { *reinterpret_cast<float2 *>(Yb + yslot_bytes(t)) = v; };
+            // a source without a valid target stores into slot 543, which is no bin's (row 7 ends at slot 539): straight-line code instead of a branch per store
+            [[maybe_unused]] auto ystore_if = [&](bool ok, unsigned t, float2 v) { *reinterpret_cast<float2 *>(Yb + (ok ? yslot_bytes(t) : 8u * (YSLOTS - 1))) = v; };
+            if constexpr (SPREAD) {
+                // delta_i = round(p_i f) - p_i is non-decreasing in i for f >= 1, the shifted regions stay disjoint: plain stores of the register-resident
+                // source bins along the routes of the table
+                const unsigned *ROUTE = reinterpret_cast<const unsigned *>(smem + OFF_ROUTE);
                 auto scatter = [&](auto mode_tag) {
-                    constexpr int MODE = decltype(mode_tag)::value;
-                    auto rot = [&](unsigned rt, float2 v) -> float2 {
-                        if (MODE == 0) return v;
-                        if (MODE == 2) {
-                            const unsigned sg = (rt << 6) & 0x80000000u;
-                            return float2{__uint_as_float(__float_as_uint(v.x) ^ sg), __uint_as_float(__float_as_uint(v.y) ^ sg)};
-                        }
-                        return rotate_route<R, 10>(rt, v, p.tw32);
-                    };
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const unsigned ra = ROUTE[l + 64 * r], ta = ra & 0xFFFFu;
                         const unsigned rb = ROUTE[512 - l - 64 * r], tb = rb & 0xFFFFu;
-                        if (ta < (unsigned)H) Y[ta] = rot(ra, float2{XA[r].x, XA[r].y});
-                        if (tb < (unsigned)H) Y[tb] = rot(rb, float2{XB[r].x, XB[r].y});
+                        if (ta < (unsigned)H) Yn[ta] = rot_mode(mode_tag, ra, XA[r]);
+                        if (tb < (unsigned)H) Yn[tb] = rot_mode(mode_tag, rb, XB[r]);
                     }
-                    if (l == 0) { const unsigned rt = ROUTE[256], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, float2{x256f.x, x256f.y}); }
+                    if (l == 0) { const unsigned r256 = ROUTE[256], tg = r256 & 0xFFFFu; if (tg < (unsigned)H) Yn[tg] = rot_mode(mode_tag, r256, x256f); }
                 };
-                // tmod = (m mod R) * N/R: 0 -> no rotation at all, N/2 -> signs only (R = 2: always one of the two; R = 1: always 0)
                 if (tmod == 0) scatter(std::integral_constant<int, 0>{});
                 else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
                 else scatter(std::integral_constant<int, 1>{});
+            } else if (pf >= 1.0) {
+                // (a frame with f >= 1 in a chain that also has frames below 1: disjoint regions, plain stores, each lane its own 8 bins)
+                auto scatter = [&](auto mode_tag) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { const unsigned t = rt[i] & 0xFFFFu; ystore_if(t < (unsigned)H, t, rot_mode(mode_tag, rt[i], xs[i])); }
+                    { const unsigned t = rt512 & 0xFFFFu; ystore_if(t < (unsigned)H, t, rot_mode(mode_tag, rt512, xs512)); }
+                };
+                if (tmod == 0) scatter(std::integral_constant<int, 0>{});
+                else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
+                else scatter(std::integral_constant<int, 1>{});
+            } else if (pairwise) {
+                // f < 1, every collision is (falling side, rising side): pass A, the falling-side sources -- and the residue above Nyquist, which continues
+                // the falling side of the last peak -- store into the zeroed Y; pass B, the rising-side sources read, add, store (the reference's order).
+                const bool need_res = upper_end > H;
+                const bool fast_res = need_res && (upper_end <= H + 128);
+                const int up_delta = need_res ? last_shift : 0;                                        // sources above Nyquist: all owned by the last peak (pv:133), whose shift came with it
+                const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+                float2 ys[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) ys[i] = rotate_route<R, 10>(rt[i], xs[i], p.tw32);
+                const float2 ys512 = rotate_route<R, 10>(rt512, xs512, p.tw32);
+                unsigned key[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) key[i] = rt[i] & 0x8000FFFFu;   // side bit | target: < 513 = a valid falling-side source
+#pragma unroll
+                for (int i = 0; i < 8; i++) ystore_if(key[i] < 513u, key[i], ys[i]);
+                ystore_if((rt512 & 0xFFFFu) < 513u, rt512 & 0xFFFFu, ys512);
+                if (fast_res) {
+                    unsigned rt2[2];
+                    float2 ys2[2];
+                    residue_fast_1024<R>(p.tw32, wave_off, l, upper_end, up_delta, up_ridx, dbg ? p.dbg_X : nullptr, rt2, ys2);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) ystore_if((rt2[j] & 0xFFFFu) < 513u, rt2[j] & 0xFFFFu, ys2[j]);
+                }
+                wave_sync();
+                unsigned ab[8];
+                float2 o[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {                                   // rising-side sources: their target's slot; everybody else: the dummy slot
+                    ab[i] = (key[i] - 0x80000000u < 513u) ? yslot_bytes(key[i] & 0xFFFFu) : 8u * (YSLOTS - 1);
+                    o[i] = *reinterpret_cast<const float2 *>(Yb + ab[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) *reinterpret_cast<float2 *>(Yb + ab[i]) = float2{o[i].x + ys[i].x, o[i].y + ys[i].y};
+                if (need_res && !fast_res) {
+                    wave_sync();
+                    residue_scatter_1024<R>(src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.tw32, wave_off, l, upper_end, up_delta, up_ridx,
+                                            dbg ? p.dbg_X : nullptr, true);
+                }
             } else {
-                scatter_colliding_1024<R>(Spectrum9{{XA[0], XA[1], XA[2], XA[3]}, {XB[0], XB[1], XB[2], XB[3]}, x256f}, wave_off, l, tmod, last_peak, upper_end, pairwise,
-                                          src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw32, dbg ? p.dbg_X : nullptr);
+                scatter_claims_1024<R>(Routes9{{rt[0], rt[1], rt[2], rt[3], rt[4], rt[5], rt[6], rt[7], rt512}}, wave_off, l, tmod, last_peak, upper_end,
+                                       src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.tw32, dbg ? p.dbg_X : nullptr);
             }
         }
-        if (nonfinite && l == 0) Y[1] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};   // see "Non-finite magnitudes" above
+        if (nonfinite && l == 0) *reinterpret_cast<float2 *>(Yb + (SPREAD ? 8u : yslot_bytes(1u))) = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};   // bin 1; see "Non-finite magnitudes" above
         wave_sync();
         PV_STAMP(6);
         pv_prio(PH_C2R);
+        // strided-order addresses of Y: bin l + 64 r at ystr + YR r, bin 512 - l - 64 r at ystr_m + YR (3 - r) -- plain array (SPREAD): 8 l, 8 (320 - l), YR = 512;
+        // transposed: yslot_bytes, YR = 64, from an opaque copy of the lane id (four instructions per frame; see the split pass)
+        constexpr int YR = SPREAD ? 512 : 64;
+        unsigned ystr, ystr_m;
+        if constexpr (SPREAD) { ystr = 8u * (unsigned)l; ystr_m = 8u * (unsigned)(512 - 192 - l); }
+        else { int lq = l; asm volatile("" : "+v"(lq)); ystr = yslot_bytes((unsigned)lq); ystr_m = yslot_bytes((unsigned)(512 - 192 - lq)); }
         if (dbg) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) { const int k = l + 64 * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
-            if (l == 0) { p.dbg_Y[1024] = Y[512].x; p.dbg_Y[1025] = Y[512].y; }
+            for (int r = 0; r < 8; r++) {
+                const int k = l + 64 * r;
+                const float2 y = *reinterpret_cast<const float2 *>(Yb + (SPREAD ? 8u * (unsigned)k : yslot_bytes((unsigned)k)));
+                p.dbg_Y[2 * k] = y.x; p.dbg_Y[2 * k + 1] = y.y;
+            }
+            if (l == 0) { const float2 y = *reinterpret_cast<const float2 *>(Yb + (SPREAD ? 4096 : 512)); p.dbg_Y[1024] = y.x; p.dbg_Y[1025] = y.y; }
         }
         // ---- c2r pre-pass (bundle:69-76,102-114 folded): Z[k] = SC ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)), packed fp32 ----
         pk::c32 zi[8];
         {
             const float sc = SC;
             const pk::c32 scsc{sc, sc};
-            const pk::c32 *Yc = reinterpret_cast<const pk::c32 *>(Y);
             {
                 // conjugate pairs again: with E = Yk + conj(Ym), O = Yk - conj(Ym), c = e^{+2 pi j k/N} O / N (m = 512 - k):
                 // Z[k] = E / N + j c and Z[m] = conj(E / N - j c); lane l computes k = l + 64 r, r < 4, and hands Z[m] to lane 64-l, register 7-r
                 pk::c32 zb[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int k = l + 64 * r;
-                    pk::c32 yk = Yc[k], ym = Yc[M - k];
-                    if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
+                    pk::c32 yk = *reinterpret_cast<const pk::c32 *>(Yb + ystr + YR * r), ym = *reinterpret_cast<const pk::c32 *>(Yb + ystr_m + YR * (3 - r));
+                    if (r == 0 && l == 0) { yk.y = 0.f; ym.y = 0.f; }
                     const pk::c32 E = pk::add_conj(yk, ym), O = pk::sub_conj(yk, ym);
                     const pk::c32 c = pk::cmul(mul_w16_inv_pk(O, r), wlfs);
                     zi[r] = pk::fma_addj(E, scsc, c);
                     zb[r] = pk::fma_conj_subj(E, scsc, c);
                 }
-                const pk::c32 y256 = Yc[256];
-                // hand-over through LDS (the residue quarter buffer is free here): Z[m] of the pair (l', r') lands in lane 64 - l', register
+                const pk::c32 y256 = *reinterpret_cast<const pk::c32 *>(Yb + (SPREAD ? 2048 : 256));   // bin 256: byte 2048 of the plain array, slot 32 of the transposed one
+                // hand-over through LDS (the stash is dead here): Z[m] of the pair (l', r') lands in lane 64 - l', register
                 // 7 - r'; read address r * 64 + 64 - l for every lane (lane 0 pairs with itself one register higher, and its register 4
                 // is the self-paired bin 256, replaced below)
                 pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem + OFF_RESQ);
@@ -961,19 +929,11 @@ resident_top:
             }
         }
         wave_sync();
-#ifdef PV_RELOAD_ROWS
-        {   // experiment: no rows carried through the forward FFT (its register peak): the whole window of the next frame is (re)loaded here
-            const int mn = (m + 1 < last_out) ? m + 1 : m;
-            load_rows(raw, 8, 0, mn);
-            pf_next = pitch_row[mn];
-        }
-#endif
 #ifdef PV_STAMPS
         stamps.mark(7);
         fft512_wave_inv_pk<true>(zi, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l, [&](int id) { if (id & 1) stamps.mark(8 + id); else stamps.mark(8 + id, true); });
 #else
         fft512_wave_inv_pk(zi, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l);
-#endif
 #endif
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         pv_prio(PH_OLA);
@@ -1021,32 +981,84 @@ resident_top:
             // the history of the next call = the last N - hop samples of the stream = rows S_ROWS..7 of the last frame's window, which the slide has
             // left in raw[0 .. 8 - S_ROWS): stored from registers (re-reading them costs a streaming quantum an exposed memory -- or PCIe -- round trip)
             float *hs = hist_out + (long)ch * (N - HOP) + 2 * l + 128 * r;
-#ifdef PV_RELOAD_ROWS
-            const long s = (long)p.nhops * HOP - (N - HOP) + 2 * l + 128 * r;
-            hs[0] = src.at(s); hs[1] = src.at(s + 1);
-#else
             hs[0] = raw[r].x; hs[1] = raw[r].y;
-#endif
         }
     }
     pv_signal_done<false>(p.done, done_seq, chain);
     if (RESIDENT) goto resident_top;
 }
 
-template <int S_ROWS, bool AUX>
-hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+// One wave per chain: are all its pitchFactors >= 1?  The chain is appended to the list of its class -- sixteen chains per workgroup, one atomic
+// per class and workgroup (3000 waves bumping one counter each cost the headline launch 38 us).  The order of the workgroups' blocks within a class is
+// whatever the atomics make it: chains are independent, the results do not depend on it.  list = {count[2], class 0 [nchains], class 1 [nchains]}.
+constexpr int CLS_WAVES = 16;
+template <int S_ROWS>
+__global__ __launch_bounds__(64 * CLS_WAVES) void pv_classify_chains(const PvKernelParams p, unsigned *list)
 {
-    static std::atomic<bool> attr_done[16];
-    auto k = pv_wave_kernel_1024<S_ROWS, AUX>;
+    constexpr int HOP = 128 * S_ROWS, R = 1024 / HOP;
+    __shared__ unsigned cls_of[CLS_WAVES], base[2];
+    const long nchains = (long)p.nch * p.nchunks;
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const long chain = (long)blockIdx.x * CLS_WAVES + wv;
+    unsigned cls = 2u;                                                     // 2 = no chain
+    if (chain < nchains) {
+        const int ch = (int)(chain / p.nchunks), chunk = (int)(chain - (long)ch * p.nchunks);
+        const int first_out = chunk * p.frames_per_chunk;
+        int last_out = first_out + p.frames_per_chunk;
+        if (last_out > p.nhops) last_out = p.nhops;
+        int first_frame = first_out - (R - 1);
+        if (first_frame < 0) first_frame = 0;
+        const float *pitch_row = p.pitch + (p.pitch_stride ? (long)(ch / p.ch_per_stream) * p.pitch_stride : 0);
+        bool low = false;
+        for (int m = first_frame + l; m < last_out; m += 64) low |= !(pitch_row[m] >= 1.0f);  // NaN counts as "not >= 1", as in the kernel
+        cls = __any(low) ? 1u : 0u;
+    }
+    if (l == 0) cls_of[wv] = cls;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned n[2] = {0u, 0u};
+        for (int w = 0; w < CLS_WAVES; w++) if (cls_of[w] < 2u) n[cls_of[w]]++;
+        base[0] = n[0] ? atomicAdd(&list[0], n[0]) : 0u;
+        base[1] = n[1] ? atomicAdd(&list[1], n[1]) : 0u;
+    }
+    __syncthreads();
+    if (l == 0 && cls < 2u) {
+        unsigned before = 0;
+        for (int w = 0; w < wv; w++) before += (cls_of[w] == cls) ? 1u : 0u;
+        list[2 + cls * nchains + base[cls] + before] = (unsigned)chain;
+    }
+}
+
+template <int S_ROWS, bool AUX>
+hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st, int spread, unsigned *list)
+{
+    static std::atomic<bool> attr_done[16], attr_done_s[16];
+    auto k = pv_wave_kernel_1024<S_ROWS, AUX, false, false>;
+    auto ks = pv_wave_kernel_1024<S_ROWS, false, false, true>;
     {
-        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_wave_lds_bytes());
+        hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_wave_lds_bytes());
+        if (e == hipSuccess && !AUX) e = pv_set_dynamic_lds_once(attr_done_s, reinterpret_cast<const void *>(ks), (int)pv_wave_lds_bytes());
         if (e != hipSuccess) return e;
     }
     PvKernelParams q = p;
     q.nchunks = nchunks;
     q.nch = nch;
     const long chains = (long)nch * nchunks;
-    hipLaunchKernelGGL(k, dim3((unsigned)((chains + WAVES - 1) / WAVES), 1, 1), dim3(64 * WAVES, 1, 1), pv_wave_lds_bytes(), st, q);
+    const dim3 grid((unsigned)((chains + WAVES - 1) / WAVES), 1, 1), block(64 * WAVES, 1, 1);
+    if (AUX || spread == 0 || (spread < 0 && !list)) {                     // one instance that handles every pitchFactor
+        hipLaunchKernelGGL(k, grid, block, pv_wave_lds_bytes(), st, q);
+    } else if (spread > 0) {
+        if (!AUX) hipLaunchKernelGGL(ks, grid, block, pv_wave_lds_bytes(), st, q);
+    } else {
+        // classify on the device, then both instances over the whole grid: a workgroup beyond its class's count leaves at once
+        hipError_t e = hipMemsetAsync(list, 0, 2 * sizeof(unsigned), st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(pv_classify_chains<S_ROWS>, dim3((unsigned)((chains + CLS_WAVES - 1) / CLS_WAVES), 1, 1), dim3(64 * CLS_WAVES, 1, 1), 0, st, q, list);
+        q.chain_count = list;
+        q.chain_list = list + 2;
+        if (!AUX) hipLaunchKernelGGL(ks, grid, block, pv_wave_lds_bytes(), st, q);
+        hipLaunchKernelGGL(k, grid, block, pv_wave_lds_bytes(), st, q);
+    }
     return hipGetLastError();
 }
 
@@ -1070,10 +1082,7 @@ hipError_t launch_wave_resident(const PvKernelParams &p, int nslots, hipStream_t
 
 }  // namespace
 
-#ifndef PV_LDS_PAD
-#define PV_LDS_PAD 0        // occupancy experiments only: extra bytes that keep a second workgroup off the CU
-#endif
-size_t pv_wave_lds_bytes() { return TAB_BYTES + WAVES * WAVE_LDS + PV_LDS_PAD; }
+size_t pv_wave_lds_bytes() { return TAB_BYTES + WAVES * WAVE_LDS; }
 
 int pv_wave_threads() { return 64 * WAVES; }
 
@@ -1090,14 +1099,14 @@ hipError_t pv_launch_wave_resident(const PvKernelParams &p, int nslots, hipStrea
     }
 }
 
-hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st, int spread, unsigned *list)
 {
     const bool aux = (p.dbg_mag != nullptr);
     switch (p.hop) {
-    case 128: return aux ? launch_wave<1, true>(p, nch, nchunks, st) : launch_wave<1, false>(p, nch, nchunks, st);
-    case 256: return aux ? launch_wave<2, true>(p, nch, nchunks, st) : launch_wave<2, false>(p, nch, nchunks, st);
-    case 512: return aux ? launch_wave<4, true>(p, nch, nchunks, st) : launch_wave<4, false>(p, nch, nchunks, st);
-    case 1024: return aux ? launch_wave<8, true>(p, nch, nchunks, st) : launch_wave<8, false>(p, nch, nchunks, st);
+    case 128: return aux ? launch_wave<1, true>(p, nch, nchunks, st, 0, nullptr) : launch_wave<1, false>(p, nch, nchunks, st, spread, list);
+    case 256: return aux ? launch_wave<2, true>(p, nch, nchunks, st, 0, nullptr) : launch_wave<2, false>(p, nch, nchunks, st, spread, list);
+    case 512: return aux ? launch_wave<4, true>(p, nch, nchunks, st, 0, nullptr) : launch_wave<4, false>(p, nch, nchunks, st, spread, list);
+    case 1024: return aux ? launch_wave<8, true>(p, nch, nchunks, st, 0, nullptr) : launch_wave<8, false>(p, nch, nchunks, st, spread, list);
     default: return hipErrorInvalidValue;
     }
 }

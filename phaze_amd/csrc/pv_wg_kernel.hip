@@ -39,6 +39,9 @@ namespace {
 #ifndef PV_WG_REG_T2
 #define PV_WG_REG_T2 1        // G = 8: transpose 2 of both FFTs in registers (0 = the round-2 LDS form, for A/B builds)
 #endif
+#ifndef PV_WG_INV_SPLIT
+#define PV_WG_INV_SPLIT 1     // G = 8: transposes 1 and 3 of the inverse FFT in separate halves of the scratch, 4 barriers less per frame (0 = round-3 form, A/B)
+#endif
 template <int G, bool CT = false>
 struct WgCfg {
     static constexpr int T = 64 * G, M = 512 * G, N = 1024 * G, H = M + 1;
@@ -165,10 +168,16 @@ __device__ __forceinline__ void fft_wg(typename v2t<T_>::type (&a)[8], typename 
 // The inverse instance in packed fp32 (pv_pk_math.h): same layouts as fft_wg<float, true, G>, twiddles conjugated and rounded from the fp64 tables.
 __device__ __forceinline__ pk::c32 twc_inv_pk(double2 w) { return pk::c32{(float)w.x, -(float)w.y}; }
 
+// G = 8 (round 4, PV_WG_INV_SPLIT): the packed-fp32 elements are half the size of the forward's, so transposes 1 and 3 each get their OWN half of the
+// scratch (transpose 2 runs in registers) and the second barrier of both exchanges goes: a transpose only has to wait until its data has been
+// WRITTEN, the readers of the other half are not in its way.  With the c2r hand-over in a third place (OFF_RESQ: read before transpose 1's
+// barrier, overwritten by transpose 3 after it) an inverse costs 3 workgroup barriers + the end-of-frame one instead of 7.
 template <int G, bool CT>
 __device__ __forceinline__ void fft_wg_inv_pk(pk::c32 (&a)[8], pk::c32 *S, const double2 *TWA, const double2 *TWB, const double2 *TWC, int t)
 {
     using C = WgCfg<G>;
+    constexpr bool SPLIT = (G == 8) && PV_WG_REG_T2 && PV_WG_INV_SPLIT;
+    static_assert(!SPLIT || (8 * C::P1 * 8 + 8 * C::P3 * 8 <= C::SCRATCH), "the two halves of the inverse's scratch do not fit");
     pk::radix8_inv(a);
 #pragma unroll
     for (int k = 1; k < 8; k++) {
@@ -187,7 +196,7 @@ __device__ __forceinline__ void fft_wg_inv_pk(pk::c32 (&a)[8], pk::c32 *S, const
     const int kA1 = t / (8 * G), tlo = t % (8 * G);
 #pragma unroll
     for (int n = 0; n < 8; n++) a[n] = S[kA1 * C::P1 + n * 8 * G + tlo];
-    __syncthreads();
+    if (!SPLIT) __syncthreads();
     pk::radix8_inv(a);
 #pragma unroll
     for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], twc_inv_pk(TWB[(k - 1) * 8 * G + tlo]));
@@ -210,13 +219,14 @@ __device__ __forceinline__ void fft_wg_inv_pk(pk::c32 (&a)[8], pk::c32 *S, const
     pk::radix8_inv(a);
 #pragma unroll
     for (int k = 1; k < 8; k++) a[k] = pk::cmul(a[k], twc_inv_pk(TWC[(k - 1) * G + ulo]));
+    pk::c32 *S3 = SPLIT ? S + 8 * C::P1 : S;                // SPLIT: the half behind transpose 1's rows
 #pragma unroll
-    for (int k = 0; k < 8; k++) S[k * C::P3 + kA1 * (8 * G + C::A3) + kB2 * G + ulo] = a[k];
+    for (int k = 0; k < 8; k++) S3[k * C::P3 + kA1 * (8 * G + C::A3) + kB2 * G + ulo] = a[k];
     __syncthreads();
     const int kA3 = t & 7, kB3 = (t >> 3) & 7, c3 = t >> 6;
 #pragma unroll
-    for (int q = 0; q < 8; q++) a[q] = S[(c3 + G * (q / G)) * C::P3 + kA3 * (8 * G + C::A3) + kB3 * G + (q % G)];
-    __syncthreads();
+    for (int q = 0; q < 8; q++) a[q] = S3[(c3 + G * (q / G)) * C::P3 + kA3 * (8 * G + C::A3) + kB3 * G + (q % G)];
+    if (!SPLIT) __syncthreads();                            // (SPLIT: the end-of-frame barrier stands between these reads and the next frame's writes)
     if (G == 8) {
         pk::radix8_inv(a);
     } else if (G == 4) {
@@ -601,7 +611,11 @@ resident_top:
                 xb[0] = double2{2.0 * (z[0].x - z[0].y), 0.0};
                 xH = double2{2.0 * z[4].x, -2.0 * z[4].y};                    // k = M/2 pairs with itself: W^{N/4} = -j, X = 2 conj(Z)
             }
-            __syncthreads();                                               // partner reads done: the scratch becomes MAG / Y / ROUTE
+            // partner reads done: the scratch becomes MAG / Y / ROUTE.  MAG / ROUTE sit behind the four partner rows ([0, 4T) double2 = [0, OFF_ROUTE)),
+            // only the f < 1 spectrum stash (in the Y region) overwrites them: an f >= 1 frame needs no barrier here (pf is uniform in the workgroup;
+            // the barrier behind the shift table is the next one, Y is zeroed behind the one after that)
+            static_assert(C::OFF_ROUTE >= 16 * 4 * T, "MAG must not alias the partner rows of the split pass");
+            if (!(pf >= 1.0) || !PV_WG_INV_SPLIT) __syncthreads();
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 MAG[4 + tq + T * r] = (float)(xa[r].x * xa[r].x + xa[r].y * xa[r].y);
@@ -943,7 +957,9 @@ resident_top:
             for (int r = 4; r < 8; r++) zi[r] = XCH[tq + T * (r - 4)];
             if (tq == 0) zi[4] = pk::c32{2.0f * yH.x * sc, -2.0f * yH.y * sc};   // the self-paired bin M/2
         }
-        __syncthreads();
+        // G = 8 with the split scratch: transpose 1 of the inverse writes [0, 32 KB) -- Y, whose reads all sit in front of the hand-over's barrier -- and
+        // leaves the hand-over buffer alone (transpose 3 takes it over, behind transpose 1's barrier): no barrier here
+        if (!(G == 8 && PV_WG_REG_T2 && PV_WG_INV_SPLIT)) __syncthreads();
         fft_wg_inv_pk<G, RING>(zi, reinterpret_cast<pk::c32 *>(S32), TWA, TWB, TWC, tq);
         // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
         {
