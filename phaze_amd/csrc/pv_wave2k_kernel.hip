@@ -51,11 +51,14 @@ constexpr int T2_HANN = T2_TW2F + 4 * 8 * 16;     // float4[8*64]   0.5 * Hann a
 constexpr int T2_ROT = T2_HANN + 8 * 64 * 16;     // float2[16]     exp(+2 pi j q / 16): the rotations of pv:155-170 when the hop is N / 8 or N / 16 (R = 8, 16)
 constexpr int T2_BYTES = T2_ROT + 16 * 8;         // 22144
 
+constexpr int MAG0_WORDS = 8;                     // (= MAG0 below)
 // per-wave LDS (byte offsets)
 constexpr int O2_S = 0;                           // fp64 transpose scratch 9216 B | partner exchange | Y float2[1025] | fp32 transposes | spectrum stash (f < 1)
 constexpr int O2_ROUTE = 9216;                    // routes u32 | f32 mags (alias) -- both in the padded layout below, running on into RESQ -- | u16 claim ids (alias) | c2r hand-over (alias)
 constexpr int O2_RESQ = O2_ROUTE + 4160;          // float2[512] one quarter of the above-Nyquist residue (general form only)
+constexpr int O2_CACHE = O2_RESQ + 1024;          // v4f[3 * 64] rows 0..2 of the NEXT frame's raw window (aliases the quarter buffer behind the KB the padded routes run into)
 constexpr int WAVE2_LDS = O2_RESQ + 4096;         // 17472: 22144 + 8 * 17472 = 161920 B per workgroup (<= 160 KB)
+static_assert(O2_ROUTE + 4 * (MAG0_WORDS + 1281) <= O2_CACHE, "the padded magnitudes / routes run into the row cache");
 
 constexpr int N2 = 2048, M2 = 1024, H2 = 1025;
 
@@ -399,6 +402,19 @@ resident_top:
             }
         }
     };
+    // the same for a frame whose rows 0..2 sit in the LDS row cache: only the others are fetched
+    constexpr bool ROWCACHE = !RESIDENT && HOP + 768 <= N;                // (hops of 2048 / 1024 leave less than three old rows: hop 1024 keeps rows 4..6)
+    auto load_rows_except = [&](v4f *w, int frame) {
+        const long s0 = (long)(frame + 1) * HOP - N + 4 * lane;
+#pragma unroll
+        for (int r = 3; r < 8; r++) {
+            const long sx = s0 + 256 * r;
+            const float *q = sx < 0 ? src.hist + sx + src.hist_len : src.in + sx;
+            if (vec_in) w[r] = *reinterpret_cast<const v4f *>(q);
+            else w[r] = v4f{q[0], q[1], q[2], q[3]};
+        }
+    };
+    bool cache_ok = false;
     v4f raw[8];
     load_rows(raw, first_frame);
     float pf_next = (RESIDENT && src.sys) ? __hip_atomic_load(pitch_row + first_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : pitch_row[first_frame];
@@ -436,6 +452,22 @@ resident_top:
             const v4f xw = raw[r] * hw[r];
             zlo[r] = double2{(double)xw.x, (double)xw.y};                  // ze[l + 64 r] = z[2 n']
             zhi[r] = double2{(double)xw.z, (double)xw.w};                  // zo[l + 64 r] = z[2 n' + 1]
+        }
+        if (ROWCACHE) {
+            // 768 samples of the window stay in LDS for the next frame (round 4) -- the OLDEST ones the next frame still needs, its rows 0..2: the registers
+            // cannot carry them through the frame (the forward FFTs need every one), and re-reading the whole 8 KB window per frame left the oldest rows
+            // to L2, where the streaming traffic of 512 chains per XCD (new rows in, results out) had evicted a third of them by the time of their last
+            // use (HBM traffic 1.29x algorithmic on BASELINE configs[2], 1.33x on 2048 / 128).  The quarter buffer of the general residue (behind its
+            // first KB, which the padded magnitudes / routes run into) is free in all but the rare frames that take that path: they invalidate the cache.
+            // Sample s of this window (HOP <= s < HOP + 768) is sample s - HOP of the next one: byte 4 (s - HOP).
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if (256 * r + 256 <= HOP || 256 * r >= HOP + 768) continue;
+                const int s = 256 * r + 4 * l;
+                if ((256 * r >= HOP && 256 * r + 256 <= HOP + 768) || (s >= HOP && s < HOP + 768))      // (whole rows: no lane test)
+                    *reinterpret_cast<v4f *>(smem + O2_CACHE + 4 * (s - HOP)) = raw[r];
+            }
+            cache_ok = true;
         }
         fft512_wave<double, false>(zlo, S64, TW1, TW2, l);
         fft512_wave<double, false>(zhi, S64, TW1, TW2, l);
@@ -726,6 +758,7 @@ resident_top:
                 } else {
                     residue_scatter_2k<R>(src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw32, wave_off, l, upper_end, up_delta, up_ridx,
                                           dbg ? p.dbg_X : nullptr);
+                    cache_ok = false;                                        // the quarter buffer held the cached rows
                 }
             }
         }
@@ -776,7 +809,14 @@ resident_top:
         }
         {   // every global access of the next frame, issued here (no row is carried through the forward FFTs)
             const int mn = (m + 1 < last_out) ? m + 1 : m;
-            load_rows(raw, mn);
+            if (ROWCACHE && cache_ok && mn == m + 1) {
+                // rows 0..2 of the next frame come from LDS, the others from memory
+                load_rows_except(raw, mn);
+#pragma unroll
+                for (int r = 0; r < 3; r++) raw[r] = *reinterpret_cast<const v4f *>(smem + O2_CACHE + 16 * l + 1024 * r);
+            } else {
+                load_rows(raw, mn);
+            }
             pf_next = pitch_row[mn];
         }
         // hop 128 runs the synthesis side of odd frames under the lane id L ^ 32: an exchange through LDS addresses follows the relabelling for
