@@ -606,6 +606,23 @@ def main():
         sw = (0.5 + 1.5 * (torch.arange(T2, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
         add("sweep", f"headline shape with pitchFactor swept 0.5->2.0 per hop (period 64 hops): mono 48 kHz FFT=1024 hop=256, 1 ch x {T2} hops resident",
             1024, 256, 1, T2, sw, steps=12, warm=4)
+        # ---- the reference-width flavour of the headline kernel (never the product; build/exp/libphaze_fp64.so, `make -C phaze_amd/csrc fp64`): shifted spectrum,
+        #      scatter, residue, c2r pass and inverse FFT in fp64 like the reference's JS doubles.  A library is chosen at import time, so it runs in a child ----
+        flib = os.path.join(ROOT, "build", "exp", "libphaze_fp64.so")
+        if os.path.exists(flib) and not os.environ.get("PHAZE_LIB"):
+            for pf_, lab in ((1.5, "pitchFactor=1.5"), (0.8, "pitchFactor=f32(0.8)")):
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--allow-lib-override", "--steps", "10", "--warmup", "3",
+                                    "--repeats", "3", "--pitch", str(pf_)], capture_output=True, text=True, timeout=600, env=dict(os.environ, PHAZE_LIB=flib))
+                try:
+                    fj = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                    extras.append({"workload": f"headline shape in reference-width arithmetic (fp64 end to end: forward FFT, shift, residue, c2r, inverse FFT; fp32 only where the "
+                                               f"reference rounds to Float32Array): mono 48 kHz FFT=1024 hop=256 {lab}, 1 ch x {1 << 20} hops resident -- the all-fp64 FLAVOUR "
+                                               "(build/exp/libphaze_fp64.so), not the product",
+                                   "dtype": "f64", "value": fj["value"], "unit": "frames/s", "steps": fj["steps"], "warmup": fj["warmup"], "ms_per_step": fj["ms_per_step"],
+                                   "kernel_ms": fj["roofline"]["kernel_ms"], "kernel": fj["roofline"]["kernel"], "roofline_frac": fj["roofline"]["frac"],
+                                   "parity_rms_vs_oracle": fj["parity_rms_vs_oracle"], "lib": "build/exp/libphaze_fp64.so"})
+                except Exception as e:
+                    extras.append({"workload": "headline shape in reference-width arithmetic (fp64 end to end)", "dtype": "f64", "error": f"{e}: {(r.stderr or r.stdout)[-300:]}"})
         out["configs"] = extras
         # ---- the product boundary with HOST pointers (round-3 verdict, Weak 4): what a Node / C caller that owns host memory gets, PCIe included.
         #      Never `value`; each line carries the fraction of this box's pinned hipMemcpy bandwidth (both directions busy) it reaches. ----

@@ -411,17 +411,17 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
         // ---- 12. Hann (pv:67), overlap-add in reference order (ola:149-157), emit hop (ola:111-118), shift (ola:130-137) ----
         const bool emit = (m >= first_out);
         for (int j = tid; j < hop; j += THREADS) {
-            const float fr = frame[j] * p.hann[j];
+            const float fr = __fmul_rn(frame[j], p.hann[j]);               // rounded to fp32 before the accumulation (Float32Array, pv:67)
             float a = 0.f;
             int slot = 0;
             if (L > 0) { slot = ring + j; if (slot >= L) slot -= L; a = acc[slot]; }
             const float o = a + fr * invR;
             if (emit) outp[(long)m * hop + j] = o;
-            if (L > 0) acc[slot] = frame[j + L] * p.hann[j + L] * invR;   // freed slot receives the new tail (0 + x)
+            if (L > 0) acc[slot] = __fmul_rn(frame[j + L], p.hann[j + L]) * invR;   // freed slot receives the new tail (0 + x)
         }
         for (int j = hop + tid; j < L; j += THREADS) {
             int slot = ring + j; if (slot >= L) slot -= L;
-            acc[slot] = acc[slot] + frame[j] * p.hann[j] * invR;
+            acc[slot] = acc[slot] + __fmul_rn(frame[j], p.hann[j]) * invR;
         }
         if (L > 0) { ring += hop; if (ring >= L) ring -= L; }
         __syncthreads();

@@ -909,7 +909,8 @@ __global__ __launch_bounds__(128, 2) PV_NO_DS_MERGE void pv_pair_kernel(const Pv
             const bool emit_out = (m >= emit_v);
             v4f fr[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) fr[r] = v4f{zA[r].x, zA[r].y, zB[r].x, zB[r].y} * hw[r];
+            for (int r = 0; r < 8; r++)                                    // rounded to fp32 BEFORE the accumulation like the reference's Float32Array (pv:67): no contraction into the adds
+                fr[r] = v4f{__fmul_rn(zA[r].x, hw[r].x), __fmul_rn(zA[r].y, hw[r].y), __fmul_rn(zB[r].x, hw[r].z), __fmul_rn(zB[r].y, hw[r].w)};
 #pragma unroll
             for (int r = 0; r < S_ROWS; r++) {
                 const v4f o = acc[r] + fr[r];

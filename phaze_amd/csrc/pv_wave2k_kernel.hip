@@ -831,7 +831,8 @@ resident_top:
             for (int r = 0; r < 8; r++) hw[r] = HW4[r * 64 + li];           // HOPQ >= 2: stays live for the next frame's analysis window
             v4f fr[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) fr[r] = v4f{zA[r].x, zA[r].y, zB[r].x, zB[r].y} * hw[r];
+            for (int r = 0; r < 8; r++)                                    // rounded to fp32 BEFORE the accumulation like the reference's Float32Array (pv:67): no contraction into the adds
+                fr[r] = v4f{__fmul_rn(zA[r].x, hw[r].x), __fmul_rn(zA[r].y, hw[r].y), __fmul_rn(zB[r].x, hw[r].z), __fmul_rn(zB[r].y, hw[r].w)};
             if (HALF) {
                 // lane L holds samples 256 r + 4 (L ^ 32 par) ..: the half of the lanes with li < 32 holds the earlier half row
                 const bool early = li < 32;

@@ -34,12 +34,22 @@
 
 namespace {
 
+// Reference-width flavour (never the product; `make fp64` -> build/exp/libphaze_fp64.so): with -DPV_FP64_FLAVOUR=1 the shifted spectrum,
+// the scatter (plain stores for f >= 1, claim rounds for f < 1), the above-Nyquist residue, the c2r pass and the inverse FFT run in fp64 like the
+// reference (freqComplexBufferShifted / inverseTransform are JS doubles, bundle:102-114; phase-vocoder.js:37-39,161-170) -- for every pitchFactor.
+// It is the SPREAD flow below (sources in registers, routes through LDS, Y a plain array) extended by the colliding scatter; 8 waves per workgroup
+// (double-width Y, hand-over and quarter buffers), one kernel instance for all chains.  It exists to price the fp32 shift / inverse of the product
+// (parity against the oracle tightens from ~6e-9 to ~1e-10 RMS) and is run by tests/test_gpu_fp64_flavour.py and one line of bench.py.
+#ifndef PV_FP64_FLAVOUR
+#define PV_FP64_FLAVOUR 0
+#endif
 #ifndef PV_WAVES
-#define PV_WAVES 12
+#define PV_WAVES (PV_FP64_FLAVOUR ? 8 : 12)
 #endif
 #ifndef PV_WAVES_PER_SIMD
-#define PV_WAVES_PER_SIMD 3
+#define PV_WAVES_PER_SIMD (PV_FP64_FLAVOUR ? 2 : 3)
 #endif
+constexpr bool FP64 = PV_FP64_FLAVOUR != 0;
 constexpr int WAVES = PV_WAVES;                  // independent frame chains per workgroup (they only share the LDS tables)
 constexpr int RES_WAVES = 4;                    // ... of the resident streaming instance: one wave per SIMD, i.e. the whole register file (no spills on the latency path)
 constexpr int TAB_TW1 = 0;                       // double2[8*64]  W_512^{l k}
@@ -51,7 +61,9 @@ constexpr int TAB_TW2F = TAB_TW1F + 4 * 64 * 16; // float4[4*8]    conj(W_64^{n0
 constexpr int TAB_HANN = TAB_TW2F + 4 * 8 * 16;  // float4[4*64]   0.5 * Hann at samples 2n, 2n+1 for n = l + 64 r: entry [j*64 + l] = (r = 2j, r = 2j+1).
                                                  //                ONE table serves both windows: the 1/2 of the split pass is folded in for the analysis
                                                  //                window, and the synthesis side folds 2/R into the scale of the c2r pass (all exact)
-constexpr int TAB_BYTES = TAB_HANN + 4 * 64 * 16;  // 17920
+constexpr int TAB_TW1C = TAB_HANN + 4 * 64 * 16;   // fp64 flavour only: double2[8*64] conj(W_512^{l k}), double2[8*8] conj(W_64^{n0 k}) for its fp64 inverse FFT
+constexpr int TAB_TW2C = TAB_TW1C + 8 * 64 * 16;
+constexpr int TAB_BYTES = FP64 ? TAB_TW2C + 8 * 8 * 16 : TAB_TW1C;   // 17920 (27136)
 
 // conj(W_512^{l k}) in fp32 from the pair-interleaved table (residue paths)
 __device__ __forceinline__ float2 tw1f_at(int k, int l)
@@ -123,8 +135,10 @@ constexpr int OFF_ROUTE = 4352;     // u32[528]      f >= 1 frames: route of sou
                                     //               the head of the stash, which only f < 1 frames use)
 constexpr int OFF_XS = 6224;        // float2[544]   fp32 spectrum stash, transposed: written by the split pass (strided), read by the scatter (natural) and the fast residue
 constexpr int OFF_RESQ = 6224;      // float2[256]   one quarter of the above-Nyquist residue at a time (general path) | c2r hand-over -- alias XS: never live together
-constexpr int OFF_PSH = OFF_XS + 8 * YSLOTS;   // i16[512]  shift table Math.round(p * f) - p
-constexpr int WAVE_LDS = OFF_PSH + 1024;       // 11600: 17920 + 12 * 11600 = 157120 B per workgroup (<= 160 KB)
+// fp64 flavour (SPREAD flow only): Y double2[513] at 0 | routes, later claim words at F64_ROUTE | one quarter of the residue / c2r hand-over, double2[256], at F64_Q
+constexpr int F64_ROUTE = 8224, F64_Q = F64_ROUTE + 2112;
+constexpr int OFF_PSH = FP64 ? F64_Q + 4096 : OFF_XS + 8 * YSLOTS;   // i16[512]  shift table Math.round(p * f) - p
+constexpr int WAVE_LDS = OFF_PSH + 1024;       // 11600: 17920 + 12 * 11600 = 157120 B per workgroup (<= 160 KB); fp64 flavour 15456: 27136 + 8 * 15456 = 150784
 
 // f < 1: regions compress and `+=` collisions happen (pv:169-170).  LDS float atomics serialise per lane (measured: half of the frame
 // time), so collisions that are not simple pairs (see "pairwise" in the kernel) are resolved by CLAIM ROUNDS: every pending source writes its id
@@ -306,6 +320,115 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024(co
 }
 
 
+// ---- fp64 flavour (PV_FP64_FLAVOUR): the colliding scatter and the above-Nyquist residue in doubles, on a plain array Y[513] ----
+__device__ __forceinline__ double2 rotate_route_d(int r_, unsigned route, double2 v, const double2 *__restrict__ tw64)
+{
+    const unsigned ridx = (route >> 16) & 1023u;
+    if (r_ == 4) { const unsigned q = ridx >> 8; return q == 0 ? v : q == 1 ? double2{-v.y, v.x} : q == 2 ? double2{-v.x, -v.y} : double2{v.y, -v.x}; }   // j^q exactly
+    const double2 w = tw64[ridx];                                          // exp(-2 pi j ridx / N): v * conj(w), roundings spelled out (see rotate_route)
+    return double2{__fma_rn(v.x, w.x, __dmul_rn(v.y, w.y)), __fma_rn(v.y, w.x, -__dmul_rn(v.x, w.y))};
+}
+
+template <int NS, bool YZERO>
+__device__ __forceinline__ void claim_rounds_d(const unsigned (&rt)[NS], const double2 (&ys)[NS], const int (&id)[NS], double2 *Y, unsigned short *CLAIM)
+{
+    unsigned pend = 0, tg[NS];
+#pragma unroll
+    for (int r = 0; r < NS; r++) {
+        const unsigned t = rt[r] & 0xFFFFu;
+        const bool ok = t < 513u;
+        pend |= ok ? (1u << r) : 0u;
+        tg[r] = ok ? t : 0u;
+    }
+    bool first = YZERO;
+    while (__any(pend != 0u)) {
+#pragma unroll
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) CLAIM[tg[r]] = (unsigned short)id[r];
+        wave_sync();
+        unsigned short c[NS];
+#pragma unroll
+        for (int r = 0; r < NS; r++) c[r] = CLAIM[tg[r]];
+#pragma unroll
+        for (int r = 0; r < NS; r++) {
+            if ((pend & (1u << r)) && c[r] == (unsigned short)id[r]) {
+                const double2 o = first ? double2{0.0, 0.0} : Y[tg[r]];
+                Y[tg[r]] = double2{o.x + ys[r].x, o.y + ys[r].y};              // (0 + v: what the reference's += leaves in a zeroed bin)
+                pend &= ~(1u << r);
+            }
+        }
+        first = false;
+        wave_sync();
+    }
+}
+
+// residue_scatter_1024 in doubles: the reference's stage structure (bundle:306-442,468-508) re-run on one quarter at a time, twiddles from the
+// forward FFT's fp64 table (row 2m of W_512^{l k} = W_1024^{4 m l}), the window product rounded to fp32 as the reference's Float32Array does (pv:55).
+template <int R_>
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_1024_d(const float *in, const float *hist, int hist_len, long s0, const float *__restrict__ hann,
+                                                                               const double2 *__restrict__ tw64, unsigned wave_off, int l, int upper_end, int up_delta,
+                                                                               unsigned up_ridx, double *dbg_X)
+{
+    constexpr int N = 1024, H = 513;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    double2 *Y = reinterpret_cast<double2 *>(smem_all + wave_off + OFF_Y);
+    unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem_all + wave_off + F64_ROUTE);
+    double2 *Q = reinterpret_cast<double2 *>(smem_all + wave_off + F64_Q);
+    const double2 *TW1 = reinterpret_cast<const double2 *>(smem_all + TAB_TW1);
+    const WaveSrc src{in, hist, hist_len, false};
+    for (int base = N / 2; base < N && base < upper_end; base += N / 4) {
+        {
+            const int t = base / 4 + l;
+            const unsigned rv = __brev((unsigned)t) >> (32 - 8);
+            const int off = (int)(((rv & 0x55555555u) << 1) | ((rv >> 1) & 0x55555555u));
+            const double a = (double)__fmul_rn(src.at(s0 + off), hann[off]), b = (double)__fmul_rn(src.at(s0 + off + N / 4), hann[off + N / 4]);
+            const double c = (double)__fmul_rn(src.at(s0 + off + N / 2), hann[off + N / 2]), d = (double)__fmul_rn(src.at(s0 + off + 3 * N / 4), hann[off + 3 * N / 4]);
+            const double t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+            Q[4 * l] = double2{t0 + t2, 0.0};
+            Q[4 * l + 1] = double2{t1, -t3};
+            Q[4 * l + 2] = double2{t0 - t2, 0.0};
+            Q[4 * l + 3] = double2{t1, t3};
+        }
+        wave_sync();
+#pragma unroll
+        for (int log2m = 4; log2m <= 8; log2m += 2) {
+            const int q = (1 << log2m) >> 2, hq = q >> 1;
+            const int nblocks = 256 >> log2m, step = 256 >> log2m;
+            if (l < nblocks * (hq + 1)) {
+                int blk, i;
+                if (l < nblocks * hq) { blk = l / hq; i = l - blk * hq; } else { blk = l - nblocks * hq; i = hq; }
+                const int o = blk << log2m;
+                const double2 A = Q[o + i];
+                const double2 Bv = cmul(Q[o + q + i], TW1[2 * 64 + i * step]);
+                const double2 C = cmul(Q[o + 2 * q + i], TW1[4 * 64 + i * step]);
+                const double2 D = cmul(Q[o + 3 * q + i], TW1[6 * 64 + i * step]);
+                const double2 T0 = cadd(A, C), T1 = csub(A, C), T2 = cadd(Bv, D), T3 = csub(Bv, D);
+                Q[o + i] = cadd(T0, T2);
+                Q[o + q + i] = double2{T1.x + T3.y, T1.y - T3.x};
+                if (i == 0) {
+                    Q[o + 2 * q] = csub(T0, T2);
+                } else if (i != hq) {
+                    Q[o + q - i] = double2{T1.x - T3.y, -(T1.y + T3.x)};
+                    Q[o + 2 * q - i] = double2{T0.x - T2.x, -(T0.y - T2.y)};
+                }
+            }
+            wave_sync();
+        }
+        if (dbg_X)
+            for (int i = l; i < N / 4; i += 64) if (base + i >= H) { dbg_X[2 * (base + i)] = Q[i].x; dbg_X[2 * (base + i) + 1] = Q[i].y; }
+        unsigned rt[4];
+        double2 ys[4];
+        int id[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int b = base + l + 64 * j, tgt = b + up_delta;
+            rt[j] = (b >= H && b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+            ys[j] = rotate_route_d(R_, rt[j], Q[l + 64 * j], tw64);
+            id[j] = b;
+        }
+        claim_rounds_d<4, false>(rt, ys, id, Y, CLAIM);
+    }
+}
+
 // Shift table DSH[p] = Math.round(p * f) - p (pv:125,147) for every candidate peak bin, DROP where the reference skips the peak (pv:127-129).
 // Runs once per chain when f is constant; out of line so that its fp64 temporaries stay out of the main loop's register budget.
 __device__ __attribute__((noinline)) void build_shift_table_1024(float f, unsigned wave_off, int l)
@@ -430,12 +553,14 @@ __global__ __launch_bounds__(64 * (RESIDENT ? RES_WAVES : WAVES), RESIDENT ? 1 :
             const int k = i >> 6, ln = i & 63;
             const double2 w = p.tw64[(2 * ln * k) & (N - 1)];
             t1[i] = w;
+            if (FP64) reinterpret_cast<double2 *>(smem_all + TAB_TW1C)[i] = double2{w.x, -w.y};
             t1f[2 * ((k >> 1) * 64 + ln) + (k & 1)] = float2{(float)w.x, -(float)w.y};
             hh[2 * ((k >> 1) * 64 + ln) + (k & 1)] = float2{0.5f * p.hann[2 * i], 0.5f * p.hann[2 * i + 1]};   // n = i = ln + 64 k: row k
             if (i < 64) {
                 const int k2 = i >> 3, n0 = i & 7;
                 const double2 w2 = p.tw64[(16 * n0 * k2) & (N - 1)];
                 t2[i] = w2;
+                if (FP64) reinterpret_cast<double2 *>(smem_all + TAB_TW2C)[i] = double2{w2.x, -w2.y};
                 t2f[2 * ((k2 >> 1) * 8 + n0) + (k2 & 1)] = float2{(float)w2.x, -(float)w2.y};
             }
         }
@@ -579,6 +704,7 @@ resident_top:
         //      64-l, register 7-r), i.e. bins XA[r] = X[l + 64 r] and XB[r] = X[512 - l - 64 r]; lane 0 also owns the self-paired bin 256.
         pv_prio(PH_SPLITX);
         float2 XA[4], XB[4], x256f{0.f, 0.f};                              // fp32 copy of the spectrum: the only thing the shift needs after the decisions
+        [[maybe_unused]] double2 XAd[4], XBd[4], x256d{0.0, 0.0};         // (fp64 flavour: the spectrum itself)
         {
             // partner values through the (now free) transpose scratch: rows 4..7 written lane-contiguous, read back reversed.  Element
             // 512 - k of the pair k = l + 64 r sits at (3 - r) * 64 + (64 - l) for every lane (lane 0: 64 (8 - r), its own register
@@ -609,6 +735,7 @@ resident_top:
                 MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
                 XA[r] = float2{(float)xa.x, (float)xa.y};
                 XB[r] = float2{(float)xb.x, (float)xb.y};
+                if constexpr (FP64) { XAd[r] = xa; XBd[r] = xb; }
                 if (dbg) {
                     const int ka = l + 64 * r, kb = 512 - ka;
                     p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
@@ -619,6 +746,7 @@ resident_top:
                 const double2 x256{2.0 * z[4].x, -2.0 * z[4].y};              // k = 256 pairs with itself: W^256 = -j, X = 2 conj(Z)
                 MAG[4 + 256] = (float)(x256.x * x256.x + x256.y * x256.y);
                 x256f = float2{(float)x256.x, (float)x256.y};
+                if constexpr (FP64) x256d = x256;
                 if (dbg) { p.dbg_X[2 * 256] = x256.x; p.dbg_X[2 * 256 + 1] = x256.y; }
             }
             if constexpr (!SPREAD) {
@@ -774,6 +902,86 @@ resident_top:
         pv_prio(PH_SCATTER);
         int upper_end = H;
         if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
+        pk::c32 zi[8];
+        if constexpr (SPREAD && FP64) {
+            // ---- fp64 flavour: shift, c2r pass and inverse FFT in doubles (see PV_FP64_FLAVOUR at the top) ----
+            wave_sync();
+            double2 *Yd = reinterpret_cast<double2 *>(smem + OFF_Y);
+            unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + F64_ROUTE);
+            unsigned short *CLAIM = reinterpret_cast<unsigned short *>(smem + F64_ROUTE);
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * l]) = uint4{rt[0], rt[1], rt[2], rt[3]};
+            *reinterpret_cast<uint4 *>(&ROUTE[8 * l + 4]) = uint4{rt[4], rt[5], rt[6], rt[7]};
+            if (l == 63) ROUTE[512] = rt512;
+#pragma unroll
+            for (int r = 0; r < 8; r++) *reinterpret_cast<v4f *>(smem + OFF_Y + 16 * l + 1024 * r) = v4f{0.f, 0.f, 0.f, 0.f};      // Y[0 .. 512)
+            if (l == 0) Yd[512] = double2{0.0, 0.0};
+            wave_sync();
+            if (pf >= 1.0) {                                                // disjoint regions: plain stores
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned ra = ROUTE[l + 64 * r], ta = ra & 0xFFFFu;
+                    const unsigned rb = ROUTE[512 - l - 64 * r], tb = rb & 0xFFFFu;
+                    if (ta < (unsigned)H) Yd[ta] = rotate_route_d(R, ra, XAd[r], p.tw64);
+                    if (tb < (unsigned)H) Yd[tb] = rotate_route_d(R, rb, XBd[r], p.tw64);
+                }
+                if (l == 0) { const unsigned r256 = ROUTE[256], tg = r256 & 0xFFFFu; if (tg < (unsigned)H) Yd[tg] = rotate_route_d(R, r256, x256d, p.tw64); }
+            } else {
+                // f < 1 (and NaN): `+=` collisions (pv:169-170) resolved by claim rounds, then the sources above Nyquist (all owned by the last peak, pv:133)
+                // from the re-run stage structure -- this flavour has neither the pairwise scatter nor the closed form of the residue
+                unsigned rc[9];
+                double2 ys[9];
+                int id[9];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    id[r] = l + 64 * r; rc[r] = ROUTE[id[r]]; ys[r] = rotate_route_d(R, rc[r], XAd[r], p.tw64);
+                    id[4 + r] = 512 - l - 64 * r; rc[4 + r] = ROUTE[id[4 + r]]; ys[4 + r] = rotate_route_d(R, rc[4 + r], XBd[r], p.tw64);
+                }
+                rc[8] = (l == 0) ? ROUTE[256] : NOROUTE;
+                ys[8] = rotate_route_d(R, rc[8], x256d, p.tw64);
+                id[8] = 256;
+                wave_sync();                                               // routes are in registers: the claim words may overwrite them
+                claim_rounds_d<9, true>(rc, ys, id, Yd, CLAIM);
+                if (upper_end > H) {
+                    const int up_delta = last_shift;
+                    residue_scatter_1024_d<R>(src.in, src.hist, src.hist_len, (long)(m + 1) * HOP - N, p.hann, p.tw64, wave_off, l, upper_end, up_delta,
+                                              (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1), dbg ? p.dbg_X : nullptr);
+                }
+            }
+            if (nonfinite && l == 0) Yd[1] = double2{__longlong_as_double(0x7FF8000000000000ll), __longlong_as_double(0x7FF8000000000000ll)};
+            wave_sync();
+            if (dbg) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) { const int k = l + 64 * r; p.dbg_Y[2 * k] = (float)Yd[k].x; p.dbg_Y[2 * k + 1] = (float)Yd[k].y; }
+                if (l == 0) { p.dbg_Y[1024] = (float)Yd[512].x; p.dbg_Y[1025] = (float)Yd[512].y; }
+            }
+            // c2r pre-pass in fp64: Z[k] = SC ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)), conjugate pairs as in the product
+            double2 zd[8], zb[4];
+            const double sc = (double)SC;
+            const double2 wlc{wl.x, -wl.y};                                 // e^{+2 pi j l / N}
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = l + 64 * r;
+                double2 yk = Yd[k], ym = Yd[M - k];
+                if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
+                const double2 E{yk.x + ym.x, yk.y - ym.y}, O{yk.x - ym.x, yk.y + ym.y};
+                const double2 c = cmul(mul_w16<double, true>(O, r), wlc);
+                zd[r] = double2{(E.x - c.y) * sc, (E.y + c.x) * sc};        // E + j c
+                zb[r] = double2{(E.x + c.y) * sc, -(E.y - c.x) * sc};       // conj(E - j c)
+            }
+            const double2 y256 = Yd[256];
+            double2 *XCHd = reinterpret_cast<double2 *>(smem + F64_Q);
+#pragma unroll
+            for (int r = 0; r < 4; r++) XCHd[r * 64 + l] = zb[r];
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 4; r++) zd[7 - r] = XCHd[r * 64 + 64 - l];
+            if (l == 0) zd[4] = double2{2.0 * y256.x * sc, -2.0 * y256.y * sc};
+            wave_sync();
+            pv_prio(PH_IA);
+            fft512_wave<double, true>(zd, S64, reinterpret_cast<const double2 *>(smem_all + TAB_TW1C), reinterpret_cast<const double2 *>(smem_all + TAB_TW2C), l);
+#pragma unroll
+            for (int r = 0; r < 8; r++) zi[r] = pk::c32{(float)zd[r].x, (float)zd[r].y};    // fromComplexArray -> Float32Array (bundle:46-51)
+        } else {
         // ---- zero Y (pv:121).  The magnitudes have been read (LDS instructions of a wave execute in order): the routes (SPREAD) / Y's tail (!SPREAD) may overwrite them ----
         wave_sync();
         float2 *Yn = reinterpret_cast<float2 *>(smem + OFF_Y);               // SPREAD: Y as a plain array of 513 bins
@@ -898,7 +1106,6 @@ resident_top:
             if (l == 0) { const float2 y = *reinterpret_cast<const float2 *>(Yb + (SPREAD ? 4096 : 512)); p.dbg_Y[1024] = y.x; p.dbg_Y[1025] = y.y; }
         }
         // ---- c2r pre-pass (bundle:69-76,102-114 folded): Z[k] = SC ((Yk + Ym*) + j e^{+2 pi j k/N} (Yk - Ym*)), packed fp32 ----
-        pk::c32 zi[8];
         {
             const float sc = SC;
             const pk::c32 scsc{sc, sc};
@@ -935,6 +1142,7 @@ resident_top:
 #else
         fft512_wave_inv_pk(zi, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l);
 #endif
+        }
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         pv_prio(PH_OLA);
         {
@@ -943,7 +1151,8 @@ resident_top:
 #pragma unroll
             for (int j = 0; j < 4; j++) { const v4f h = HW4[j * 64 + l]; hw[2 * j] = pk::c32{h.x, h.y}; hw[2 * j + 1] = pk::c32{h.z, h.w}; }   // stays live for the next frame
 #pragma unroll
-            for (int r = 0; r < 8; r++) { const pk::c32 f = zi[r] * hw[r]; fr[r] = float2{f.x, f.y}; }
+            for (int r = 0; r < 8; r++) { const pk::c32 f = pk::mul(zi[r], hw[r]); fr[r] = float2{f.x, f.y}; }   // the windowed frame is ROUNDED to fp32 before it is accumulated
+                                                                                                               // (Float32Array, pv:67): an asm multiply -- a plain one is contracted into the adds below (v_pk_fma_f32), one rounding less than the reference
 #pragma unroll
             for (int r = 0; r < S_ROWS; r++) {
                 const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
@@ -1045,7 +1254,9 @@ hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_
     q.nch = nch;
     const long chains = (long)nch * nchunks;
     const dim3 grid((unsigned)((chains + WAVES - 1) / WAVES), 1, 1), block(64 * WAVES, 1, 1);
-    if (AUX || spread == 0 || (spread < 0 && !list)) {                     // one instance that handles every pitchFactor
+    if (FP64 && !AUX) {                                                    // reference-width flavour: ONE instance (the SPREAD flow with its own colliding scatter)
+        hipLaunchKernelGGL(ks, grid, block, pv_wave_lds_bytes(), st, q);
+    } else if (AUX || spread == 0 || (spread < 0 && !list)) {              // one instance that handles every pitchFactor
         hipLaunchKernelGGL(k, grid, block, pv_wave_lds_bytes(), st, q);
     } else if (spread > 0) {
         if (!AUX) hipLaunchKernelGGL(ks, grid, block, pv_wave_lds_bytes(), st, q);

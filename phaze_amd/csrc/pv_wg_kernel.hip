@@ -966,7 +966,8 @@ resident_top:
             const bool emit_out = (m >= emit_v);
             float2 fr[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) fr[r] = float2{zi[r].x * (hw[r].x * invR), zi[r].y * (hw[r].y * invR)};
+            for (int r = 0; r < 8; r++)                                    // rounded to fp32 BEFORE the accumulation like the reference's Float32Array (pv:67): no contraction into the adds
+                fr[r] = float2{__fmul_rn(zi[r].x, hw[r].x * invR), __fmul_rn(zi[r].y, hw[r].y * invR)};
             if (RING) {
                 // phase 1: samples below N - hop read their slot (emit the first hop, accumulate the rest); phase 2: the last hop samples
                 // of the frame take over the slots the emitted hop freed (0 + x, ola:130-137)

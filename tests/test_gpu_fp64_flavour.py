@@ -1,0 +1,66 @@
+"""The reference-width flavour of the N = 1024 kernel (build/exp/libphaze_fp64.so, `make -C phaze_amd/csrc fp64`; never the product): shifted spectrum,
+scatter, above-Nyquist residue, c2r pass and inverse FFT in fp64 like the reference (bundle:102-114, phase-vocoder.js:37-39,161-170), for EVERY
+pitchFactor.  Run in a subprocess (the library is chosen at import time through PHAZE_LIB) against the N = 1024 goldens generated from the
+reference itself and against the oracle on random cases; the bar is the flavour's own: 1e-9 RMS (the product's bar is 2e-6, its measured error ~6e-9)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "build", "exp", "libphaze_fp64.so")
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import phaze_amd, oracle_lib, signals as S
+assert phaze_amd.library_path().endswith("libphaze_fp64.so")
+out = {"golden": {}, "fuzz_worst": 0.0, "fuzz_cases": 0, "kernel": None}
+for c in S.load_manifest()["cases"]:
+    if c.get("fft") != 1024 or c.get("events") or c.get("arate"):
+        continue
+    h, T, nch = c["hop"], c["store_hops"], c["store_ch"]
+    sig = np.stack([S.make_signal(c["signal"], ch, c["nhops"] * h) for ch in range(nch)])
+    pitch = S.pitch_schedule(c["pitch"], c["nhops"])
+    gold = S.load_golden_out(c)
+    pv = phaze_amd.PhaseVocoder(fft_size=1024, hop_size=h, max_channels=nch, max_hops=T)
+    y = pv.process_batch(sig[:, :T * h], pitch[:T])
+    out["kernel"] = pv.info()["kernel_name"]
+    pv.close()
+    out["golden"][c["name"]] = float(S.rms(y.astype(np.float64) - gold))
+rng = np.random.default_rng(64)
+for it in range(60):
+    hop = int(rng.choice([128, 256, 512, 1024]))
+    nch, T = int(rng.integers(1, 3)), int(rng.integers(4, 40))
+    mode = it % 4
+    p = (rng.uniform(0.3, 3.0, T) if mode == 0 else np.full(T, rng.choice([0.5, 0.6, 0.7, 0.8, 0.9, 1.0, 1.5, 2.0])) if mode == 1
+         else rng.uniform(0.35, 1.0, T) if mode == 2 else rng.choice([0.0, -1.0, 0.8, 1.2, 100.0, 1e-3], size=T)).astype(np.float32)
+    x = np.stack([S.make_signal(["noise", "tonal"][it % 2], c, T * hop, stream=it) for c in range(nch)])
+    pv = phaze_amd.PhaseVocoder(fft_size=1024, hop_size=hop, max_channels=nch, max_hops=T, frames_per_chunk=int(rng.choice([0, 3, 7])))
+    T1 = int(rng.integers(1, T))
+    y = np.concatenate([pv.process_batch(x[:, :T1 * hop], p[:T1]), pv.process_batch(x[:, T1 * hop:], p[T1:])], axis=1)
+    pv.close()
+    yo = oracle_lib.Oracle(1024, hop, nch).process_planar(x, p)
+    assert np.all(np.isfinite(y))
+    out["fuzz_worst"] = max(out["fuzz_worst"], float(S.rms(y.astype(np.float64) - yo)))
+    out["fuzz_cases"] += 1
+print(json.dumps(out))
+'''
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="build/exp/libphaze_fp64.so not built (make -C phaze_amd/csrc fp64)")
+def test_reference_width_flavour_matches_the_reference(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=900, env=dict(os.environ, PHAZE_LIB=LIB))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    print(j)
+    assert j["kernel"] == "pv_wave_kernel_1024" and len(j["golden"]) >= 8 and j["fuzz_cases"] == 60
+    worst = max(j["golden"].values())
+    assert worst < 1e-9, j["golden"]
+    assert j["fuzz_worst"] < 1e-9, j["fuzz_worst"]
