@@ -38,7 +38,7 @@ def dominant_counters(pattern):
     for f in glob.glob(pattern, recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
-            if "pv_" in kn and "pitch_scan" not in kn:
+            if "pv_" in kn and "pitch_scan" not in kn and "classify" not in kn:
                 per.setdefault(kn, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     if not per:
         return {}, ""
@@ -64,7 +64,16 @@ def main():
         lines.append(f"| `{r['Name'][:100]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.2f} | "
                      f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} |")
     for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if "pv_" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if "pv_" in r["Kernel_Name"] and "classify" not in r["Kernel_Name"]]
+        # round 4: an N = 1024 batch launch is a classification kernel + two instances of pv_wave_kernel_1024, one of which returns at once:
+        # the statistics below are those of the instance that does the work (the dispatches of the kernel name with the largest total time)
+        tot = {}
+        for r in rows:
+            tot[r["Kernel_Name"]] = tot.get(r["Kernel_Name"], 0) + int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if tot:
+            kbest = max(tot, key=tot.get)
+            rows = [r for r in rows if r["Kernel_Name"] == kbest]
+            lines += ["", f"dominant kernel: `{kbest[:110]}`"]
         durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
         if durs:
             steady = durs[len(durs) // 3:]
@@ -73,7 +82,7 @@ def main():
                           f"grid {r['Grid_Size_X']}, workgroup {r['Workgroup_Size_X']}, LDS {r['LDS_Block_Size']} B, VGPR {r['VGPR_Count']}, scratch {r['Scratch_Size']} B/lane"]
     open(os.path.join(ROOT, "profiles", f"{tag}_kernel_trace.md"), "w").write("\n".join(lines) + "\n")
     # ---- headline PMC ----
-    c, n = counters(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), "pv_wave")
+    c, _kn = dominant_counters(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"))
     frames = None
     try:
         j = json.loads([l for l in open(os.path.join(d, "pmc_1.log")) if l.startswith("{")][-1])
@@ -119,7 +128,7 @@ def main():
     json.dump(tj, open(tj_path, "w"), indent=1)
     # ---- workgroup kernel ----
     lines = [f"# {tag}: counters of the other shapes' kernels (pv_wave2k_kernel at N = 2048, pv_wg_kernel above), per computed frame (separate --pmc passes)", ""]
-    for name in ("c3", "c3f15", "c3f07", "c4", "c5", "native", "c2f08"):
+    for name in ("c3", "c3f15", "c3f07", "c4", "c5", "c5f08", "c5sweep", "native", "c2f08"):
         c, kname = dominant_counters(os.path.join(d, f"wg_{name}_*", "**", "*counter_collection.csv"))
         if not c:
             continue
