@@ -45,7 +45,8 @@ typedef struct pv_handle pv_handle;
 
 /* Version of this header's binary interface (struct layouts + semantics).  pv_abi_version() returns the value the LIBRARY was built with;
  * 2 = round 3: pv_config carries its own size, unknown pv_config.flags bits are rejected, PV_FLAG_PERSISTENT_STREAM;
- * 3 = round 4: pv_host_alloc / pv_host_free (page-locked host buffers: pv_process_batch pipelines them), PV_FLAG_TEST_NO_HDP_FLUSH. */
+ * 3 = round 4: pv_host_alloc / pv_host_free (page-locked host buffers: pv_process_batch pipelines them), PV_FLAG_TEST_NO_HDP_FLUSH,
+ *     pv_reset_channels_part + PV_FLAG_HOST_CHANNEL_BOOKKEEPING. */
 #define PV_ABI_VERSION 3
 
 /* Construction options.  Replaces `new PhaseVocoderProcessor(options)` (phase-vocoder.js:24-43,
@@ -96,7 +97,10 @@ enum {
                                   * (hipDeviceAttributeHdpMemFlushCntl).  The library then must not hand quanta over through the BAR -- a host store
                                   * could still sit in the device's host data path when the kernel reads -- and falls back to the pinned-memory
                                   * form on its own; tests/test_gpu_stream_forms.py runs every hand-over form under this bit */
-    PV_FLAG_ALL = 127            /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
+    PV_FLAG_HOST_CHANNEL_BOOKKEEPING = 128, /* pv_process / pv_process_begin do NOT reset the channel state when nch differs from the previous call: the host does the
+                                  * reference's bookkeeping itself with pv_reset_channels_part -- input and output buffers separately, ola-processor.js:38-52 -- as
+                                  * phaze_amd/node/phase-vocoder.js does for hosts whose outputs do not mirror their inputs */
+    PV_FLAG_ALL = 255            /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
 };
 
 typedef struct pv_info {
@@ -132,6 +136,11 @@ PV_API int pv_reset(pv_handle *h);
 /* Zero history + accumulator of channel slots [first, first+count): what allocateInputChannels /
  * allocateOutputChannels do when a channel count changes (ola-processor.js:38-52,54-88).  timeCursor kept. */
 PV_API int pv_reset_channels(pv_handle *h, int32_t first, int32_t count);
+/* The same for ONE side of the state: the reference reallocates inputBuffers when inputs[i].length changes (ola-processor.js:40-44,54-71: the input history
+ * restarts from zeros) and outputBuffers when outputs[i].length changes (:46-51,73-88: the pending overlap-add sums restart from zeros) -- two separate
+ * events for a host whose outputs do not mirror its inputs.  parts = PV_STATE_HISTORY | PV_STATE_ACCUMULATOR bits. */
+enum { PV_STATE_HISTORY = 1, PV_STATE_ACCUMULATOR = 2 };
+PV_API int pv_reset_channels_part(pv_handle *h, int32_t first, int32_t count, int32_t parts);
 /* timeCursor (phase-vocoder.js:31,71): samples consumed so far = hops * hop_size.  The reference only ever
  * advances it by hop_size (pv:71), so a value that is negative or not a multiple of hop_size is rejected
  * with PV_ERR_ARGUMENT (the register kernels rely on t = m * hop for their exact rotations). */

@@ -21,7 +21,7 @@ EXPORTS = [
     "pv_create", "pv_destroy", "pv_last_error", "pv_status_string", "pv_get_info", "pv_reset", "pv_reset_channels",
     "pv_get_time_cursor", "pv_set_time_cursor", "pv_process", "pv_process_batch", "pv_process_batch_device",
     "pv_set_stream", "pv_synchronize", "pv_debug_frame", "pv_export_state", "pv_import_state", "pv_abi_version",
-    "pv_process_begin", "pv_process_end", "pv_device_count", "pv_host_alloc", "pv_host_free",
+    "pv_process_begin", "pv_process_end", "pv_device_count", "pv_host_alloc", "pv_host_free", "pv_reset_channels_part",
 ]
 
 
@@ -46,6 +46,8 @@ ABI_VERSION = 3          # PV_ABI_VERSION of include/phaze_amd.h this binding wa
 # pv_config.flags (include/phaze_amd.h): explicit A/B switches; the library reads no environment variables
 FLAG_GENERIC_KERNEL, FLAG_STREAM_COPY, FLAG_WORKGROUP_KERNEL, FLAG_STREAM_EVENT_WAIT, FLAG_STREAM_PINNED_INPUT, FLAG_PERSISTENT_STREAM = 1, 2, 4, 8, 16, 32
 FLAG_TEST_NO_HDP_FLUSH = 64      # test hook (tests/test_gpu_stream_forms.py)
+FLAG_HOST_CHANNEL_BOOKKEEPING = 128
+STATE_HISTORY, STATE_ACCUMULATOR = 1, 2
 
 
 class _Info(C.Structure):
@@ -95,6 +97,7 @@ def load_library():
     L.pv_get_info.argtypes = [vp, C.POINTER(_Info)]
     L.pv_reset.argtypes = [vp]
     L.pv_reset_channels.argtypes = [vp, C.c_int32, C.c_int32]
+    L.pv_reset_channels_part.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
     L.pv_get_time_cursor.argtypes = [vp, C.POINTER(C.c_int64)]
     L.pv_set_time_cursor.argtypes = [vp, C.c_int64]
     L.pv_process.argtypes = [vp, C.POINTER(fp), C.POINTER(fp), C.c_int32, C.c_int32, C.c_float]
@@ -174,6 +177,8 @@ class PhaseVocoder:
             raise PvError(rc, msg)
         self.fft_size, self.hop_size = fft_size, hop_size
         self.max_channels, self.max_hops = max_channels, max_hops
+        self._host_channels = bool(flags & FLAG_HOST_CHANNEL_BOOKKEEPING)
+        self._nin = self._nout = 1                          # "default to 1 channel per input / output until we know more" (ola-processor.js:24-33)
 
     # -- lifetime --
     def close(self):
@@ -195,8 +200,8 @@ class PhaseVocoder:
     def reset(self):
         self._check(self._L.pv_reset(self._h))
 
-    def reset_channels(self, first, count):
-        self._check(self._L.pv_reset_channels(self._h, first, count))
+    def reset_channels(self, first, count, parts=STATE_HISTORY | STATE_ACCUMULATOR):
+        self._check(self._L.pv_reset_channels_part(self._h, first, count, parts))
 
     @property
     def time_cursor(self):
@@ -242,6 +247,16 @@ class PhaseVocoder:
         parameters['pitchFactor']: float32 array, last element used (phase-vocoder.js:47).  Returns True."""
         chans = inputs[0]
         nch = len(chans)
+        if self._host_channels:
+            # the reference's reallocateChannelsIfNeeded (ola-processor.js:38-52): inputs and outputs are two separate events
+            if len(outputs[0]) < nch:
+                raise TypeError("outputs[0] has fewer channels than inputs[0]: the reference's processOLA dereferences outputs[i][j] (phase-vocoder.js:51) and throws")
+            if nch != self._nin:
+                self.reset_channels(0, self.max_channels, STATE_HISTORY)
+                self._nin = nch
+            if len(outputs[0]) != self._nout:
+                self.reset_channels(0, self.max_channels, STATE_ACCUMULATOR)
+                self._nout = len(outputs[0])
         pf = np.asarray(parameters["pitchFactor"], dtype=np.float32)
         pitch = float(pf[-1])
         paused = nch > 0 and len(chans[0]) == 0                                 # ola-processor.js:93

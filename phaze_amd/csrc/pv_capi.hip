@@ -72,6 +72,7 @@ struct pv_handle {
     int pending_nch;                             // > 0: a quantum launched by pv_process_begin waits for pv_process_end
     int pending_cur, pending_active_nch;         // ... and what to restore if that wait fails
     int64_t pending_time_cursor;
+    bool host_channels;                          // PV_FLAG_HOST_CHANNEL_BOOKKEEPING: a changed nch resets nothing here
     bool use_wave;                               // N = 1024: wave-per-frame kernel (pv_wave_kernel.hip)
     bool use_wg;                                 // N = 2048..8192, R <= 8: register-resident workgroup kernel (pv_wg_kernel.hip)
     bool use_wave2k;                             // N = 2048, hop 128..2048: one wave per frame (pv_wave2k_kernel.hip)
@@ -362,6 +363,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     h->max_channels = maxch; h->max_hops = maxhops; h->device = cfg->device_id;
     h->frames_per_chunk_cfg = cfg->frames_per_chunk;
     h->active_nch = -1;
+    h->host_channels = (cfg->flags & PV_FLAG_HOST_CHANNEL_BOOKKEEPING) != 0;
     {
         const bool generic = (cfg->flags & PV_FLAG_GENERIC_KERNEL) != 0;      // explicit A/B switch (tests, measurements); no environment is read
         h->use_wave = pv_wave_supported(log2n, hop) && !generic;
@@ -542,20 +544,27 @@ int pv_get_info(const pv_handle *h, pv_info *out)
     return PV_OK;
 }
 
-int pv_reset_channels(pv_handle *h, int32_t first, int32_t count)
+int pv_reset_channels_part(pv_handle *h, int32_t first, int32_t count, int32_t parts)
 {
     if (!live(h)) return PV_ERR_DESTROYED;
     { const int rs_ = resident_stop(h); if (rs_ != PV_OK) return rs_; }
     if (first < 0 || count < 0 || first + count > h->max_channels) return fail(h, PV_ERR_ARGUMENT, "pv_reset_channels: range out of bounds");
+    if (parts <= 0 || (parts & ~(PV_STATE_HISTORY | PV_STATE_ACCUMULATOR))) return fail(h, PV_ERR_ARGUMENT, "pv_reset_channels_part: parts must be PV_STATE_HISTORY and / or PV_STATE_ACCUMULATOR");
     if (count == 0 || h->L == 0) return PV_OK;
     HIPCHK(h, hipSetDevice(h->device));
     const size_t off = (size_t)first * h->L, bytes = sizeof(float) * (size_t)count * h->L;
     for (int i = 0; i < 2; i++) {                                  // both ping-pong halves: a zeroed slot stays zero across flips without a copy
-        HIPCHK(h, hipMemsetAsync(h->d_hist[i] + off, 0, bytes, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_acc[i] + off, 0, bytes, h->stream));
+        if (parts & PV_STATE_HISTORY) HIPCHK(h, hipMemsetAsync(h->d_hist[i] + off, 0, bytes, h->stream));
+        if (parts & PV_STATE_ACCUMULATOR) HIPCHK(h, hipMemsetAsync(h->d_acc[i] + off, 0, bytes, h->stream));
     }
-    if (first + count >= h->used_channels && first < h->used_channels) h->used_channels = first;
+    // (a slot is only "unused" -- zero in both halves, no copy across a flip -- when BOTH sides were zeroed)
+    if (parts == (PV_STATE_HISTORY | PV_STATE_ACCUMULATOR) && first + count >= h->used_channels && first < h->used_channels) h->used_channels = first;
     return PV_OK;
+}
+
+int pv_reset_channels(pv_handle *h, int32_t first, int32_t count)
+{
+    return pv_reset_channels_part(h, first, count, PV_STATE_HISTORY | PV_STATE_ACCUMULATOR);
 }
 
 int pv_reset(pv_handle *h)
@@ -645,7 +654,7 @@ int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t 
     if (!paused && nsamples != h->hop) return fail(h, PV_ERR_ARGUMENT, "pv_process: nsamples must equal hop_size (or 0 when paused)");
     HIPCHK(h, hipSetDevice(h->device));
     const Commit before{h->cur, h->time_cursor, h->active_nch};
-    if (h->active_nch >= 0 && nch != h->active_nch) {                           // ola-processor.js:38-52
+    if (h->active_nch >= 0 && nch != h->active_nch && !h->host_channels) {      // ola-processor.js:38-52
         const int rc = pv_reset_channels(h, 0, h->max_channels);
         if (rc != PV_OK) return rc;
     }

@@ -8,7 +8,9 @@
  * region shift -> inverse FFT -> Hann -> overlap-add) runs as HIP kernels behind the N-API addon; this file
  * only keeps the bookkeeping the reference does in JS around that call:
  *   - one native handle per input (channels of one input share a launch),
- *   - channel (re)allocation: a changed channel count zeroes that input's state (ola-processor.js:38-52,54-88),
+ *   - channel (re)allocation as the reference does it, inputs and outputs SEPARATELY (ola-processor.js:38-52): a changed inputs[i].length restarts the
+ *     input history of that input from zeros (:54-71), a changed outputs[i].length its pending overlap-add sums (:73-88); only the input-count
+ *     channels are processed and written (phase-vocoder.js:49-51, ola-processor.js:111-118),
  *   - the paused branch (ola-processor.js:93-100),
  *   - k-rate pitchFactor = last element of the parameter array (phase-vocoder.js:47).
  * There is no JS fallback for the DSP: without the addon / a GPU, construction throws.
@@ -16,6 +18,7 @@
 const path = require("path");
 const native = require(path.join(__dirname, "phaze_napi.node"));
 
+const HOST_CHANNEL_BOOKKEEPING = 128, STATE_HISTORY = 1, STATE_ACCUMULATOR = 2;   // PV_FLAG_HOST_CHANNEL_BOOKKEEPING, PV_STATE_* of include/phaze_amd.h
 const BUFFERED_BLOCK_SIZE = 2048;   // reference default (phase-vocoder.js:6)
 const WEBAUDIO_BLOCK_SIZE = 128;    // reference default (ola-processor.js:3)
 
@@ -48,8 +51,10 @@ class PhaseVocoderProcessor extends Base {
         this._flags = po.flags | 0;                                     // PV_FLAG_* of include/phaze_amd.h (e.g. 32 = resident streaming kernel); 0 in normal use
         this._maxHops = Math.max(1, po.maxHops | 0);                   // staging size of the throughput entry point (processBatch)
         this._handles = [];
-        this._channels = [];
+        this._channels = [];                                            // inputs[i].length the input side was "allocated" for
+        this._outChannels = [];                                         // outputs[i].length the output side was "allocated" for
         this._capacity = [];
+        this._flags |= HOST_CHANNEL_BOOKKEEPING;                        // the resets below replace the C ABI's own (mirrored) channel-count rule
         for (let i = 0; i < (this.nbInputs | 0); i++) {
             // "default to 1 channel per input until we know more" (ola-processor.js:24-27); capacity 2 avoids a
             // re-create for the common mono->stereo switch.  Throws Error('FFT size must be a power of two and
@@ -57,27 +62,36 @@ class PhaseVocoderProcessor extends Base {
             this._capacity.push(2);
             this._handles.push(native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: 2, maxHops: this._maxHops, deviceId: this.deviceId, flags: this._flags }));
             this._channels.push(1);
+            this._outChannels.push(1);
         }
     }
 
     get timeCursor() { return this._handles.length ? native.timeCursor(this._handles[0]) : 0; }   // phase-vocoder.js:31
 
-    /** Handles dynamic reallocation of input/output channels (ola-processor.js:38-52): state of that input restarts from zero. */
+    /** Handles dynamic reallocation of input/output channels buffer (ola-processor.js:38-52): inputs and outputs are two events. */
     reallocateChannelsIfNeeded(inputs, outputs) {
         for (let i = 0; i < this._handles.length; i++) {
             const nb = inputs[i].length;
-            if (nb !== this._channels[i]) {
-                if (nb > this._capacity[i]) {
-                    const t = native.timeCursor(this._handles[i]);
-                    native.destroy(this._handles[i]);
-                    this._capacity[i] = Math.max(nb, 2 * this._capacity[i]);
-                    this._handles[i] = native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: this._capacity[i], maxHops: this._maxHops, deviceId: this.deviceId, flags: this._flags });
-                    native.timeCursor(this._handles[i], t);     // timeCursor survives a reallocation (phase-vocoder.js:31,71)
-                } else {
-                    native.reset(this._handles[i], 0, this._capacity[i]);
-                }
-                this._channels[i] = nb;
+            const nbOut = (outputs && outputs[i]) ? outputs[i].length : nb;          // (the batch entry points have no output arrays: mirrored)
+            const inChanged = nb !== this._channels[i], outChanged = nbOut !== this._outChannels[i];
+            if (!inChanged && !outChanged) continue;
+            if (Math.max(nb, nbOut) > this._capacity[i]) {
+                // more channel slots than the handle owns: a bigger handle.  What the reference would keep across this call -- the side that did NOT change --
+                // moves over (the other side starts from zeros anyway); timeCursor survives (phase-vocoder.js:31,71)
+                const old = this._handles[i], oldCap = this._capacity[i], t = native.timeCursor(old);
+                const keep = [];
+                if (!inChanged || !outChanged) for (let c = 0; c < oldCap; c++) keep.push(native.exportState(old, c));
+                native.destroy(old);
+                this._capacity[i] = Math.max(nb, nbOut, 2 * oldCap);
+                this._handles[i] = native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: this._capacity[i], maxHops: this._maxHops, deviceId: this.deviceId, flags: this._flags });
+                native.timeCursor(this._handles[i], t);
+                for (let c = 0; c < keep.length; c++) native.importState(this._handles[i], c, inChanged ? null : keep[c].hist, outChanged ? null : keep[c].acc);
+            } else {
+                if (inChanged) native.reset(this._handles[i], 0, this._capacity[i], STATE_HISTORY);          // allocateInputChannels: fresh zeroed input buffers
+                if (outChanged) native.reset(this._handles[i], 0, this._capacity[i], STATE_ACCUMULATOR);     // allocateOutputChannels: fresh zeroed output buffers
             }
+            this._channels[i] = nb;
+            this._outChannels[i] = nbOut;
         }
     }
 
@@ -87,6 +101,9 @@ class PhaseVocoderProcessor extends Base {
         const pitchFactor = pf[pf.length - 1];                  // "no automation, take last value" (phase-vocoder.js:47)
         // paused: the newest hop of EVERY input is treated as zeros (ola-processor.js:93-100)
         const paused = inputs.length > 0 && inputs[0].length > 0 && inputs[0][0].length === 0;
+        for (let i = 0; i < this._handles.length; i++)
+            if ((outputs[i] ? outputs[i].length : 0) < inputs[i].length)       // the reference's processOLA dereferences outputs[i][j] for every input channel (phase-vocoder.js:51)
+                throw new TypeError(`outputs[${i}] has fewer channels than inputs[${i}]`);
         if (this._handles.length === 1) {
             const ins = paused ? inputs[0].map(() => PhaseVocoderProcessor._EMPTY) : inputs[0];
             native.process(this._handles[0], ins, outputs[0] || [], pitchFactor);

@@ -522,17 +522,18 @@ static napi_value js_device_count(napi_env env, napi_callback_info info)
 
 static napi_value js_reset(napi_env env, napi_callback_info info)
 {
-    size_t argc = 3;
-    napi_value argv[3];
+    size_t argc = 4;
+    napi_value argv[4];
     NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
     pv_slot *slot = unwrap(env, argv[0]);
     if (!slot) return NULL;
     int rc;
     if (argc >= 3) {
-        int32_t first = 0, count = 0;
+        int32_t first = 0, count = 0, parts = PV_STATE_HISTORY | PV_STATE_ACCUMULATOR;
         napi_get_value_int32(env, argv[1], &first);
         napi_get_value_int32(env, argv[2], &count);
-        rc = pv_reset_channels(slot->h, first, count);     /* ola-processor.js:54-88 */
+        if (argc >= 4) napi_get_value_int32(env, argv[3], &parts);           /* 1: input history (ola-processor.js:54-71), 2: overlap-add sums (:73-88) */
+        rc = pv_reset_channels_part(slot->h, first, count, parts);
     } else {
         rc = pv_reset(slot->h);
     }

@@ -92,15 +92,18 @@ function runCase(c) {
   const out = []; for (let ch = 0; ch < maxCh; ch++) out.push(new Float32Array(T * h));
   const dumps = {};
   let nch = c.nch;
+  let nout = -1;                       // 'out_channels' event: outputs[0].length differs from inputs[0].length from that hop on (-1: outputs mirror the inputs)
   for (let m = 0; m < T; m++) {
     let paused = false;
-    for (const e of (c.events || [])) if (e.hop === m) { if (e.type === 'pause') paused = true; if (e.type === 'channels') nch = e.nch; }
+    for (const e of (c.events || [])) if (e.hop === m) { if (e.type === 'pause') paused = true; if (e.type === 'channels') nch = e.nch; if (e.type === 'out_channels') nout = e.nch; }
     const inputs = [[]], outputs = [[]];
     for (let ch = 0; ch < nch; ch++) {
       // host-owned blocks, valid only during the call (src/ola-processor.js:64)
       inputs[0].push(paused ? new Float32Array(0) : Float32Array.from(sig[ch].subarray(m * h, (m + 1) * h)));
       outputs[0].push(new Float32Array(h));
     }
+    // the reference reallocates output buffers by outputs[0].length on its own (src/ola-processor.js:46-51) and writes input-count channels (:111-118)
+    for (let ch = nch; ch < nout; ch++) outputs[0].push(new Float32Array(h).fill(123.0));
     let pf;
     if (c.arate) { pf = new Float32Array(h); pf.fill(0.7); pf[h - 1] = pitch[m]; } else pf = Float32Array.of(pitch[m]);
     const ret = proc.process(inputs, outputs, { pitchFactor: pf });

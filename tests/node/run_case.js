@@ -21,11 +21,11 @@ if (!(N === 2048 && h === 128 && spec.use_defaults)) opts.processorOptions = { f
 if (spec.flags) opts.processorOptions = Object.assign(opts.processorOptions || {}, { flags: spec.flags });   // PV_FLAG_* (32: resident streaming kernel)
 const proc = new Cls(opts);
 const out = new Float32Array(maxCh * T * h);
-let nch = spec.nch;
+let nch = spec.nch, nout = -1;
 const t0 = process.hrtime.bigint();
 for (let m = 0; m < T; m++) {
   let paused = false;
-  for (const e of (spec.events || [])) if (e.hop === m) { if (e.type === "pause") paused = true; if (e.type === "channels") nch = e.nch; }
+  for (const e of (spec.events || [])) if (e.hop === m) { if (e.type === "pause") paused = true; if (e.type === "channels") nch = e.nch; if (e.type === "out_channels") nout = e.nch; }
   const inputs = [[]], outputs = [[]];
   for (let c = 0; c < nch; c++) {
     inputs[0].push(paused ? new Float32Array(0) : x.subarray(c * T * h + m * h, c * T * h + (m + 1) * h));
@@ -33,6 +33,7 @@ for (let m = 0; m < T; m++) {
   }
   let pf;
   if (spec.arate) { pf = new Float32Array(h); pf.fill(0.7); pf[h - 1] = pitch[m]; } else pf = Float32Array.of(pitch[m]);
+  for (let c = nch; c < nout; c++) outputs[0].push(new Float32Array(h));        // outputs that do not mirror the inputs (ola-processor.js:46-51)
   if (proc.process(inputs, outputs, { pitchFactor: pf }) !== true) throw new Error("process() must return true");
   for (let c = 0; c < nch; c++) out.set(outputs[0][c], c * T * h + m * h);
 }

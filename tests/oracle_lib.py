@@ -31,6 +31,8 @@ def lib():
         L.pvo_destroy.argtypes = [C.c_void_p]
         L.pvo_process.restype = C.c_int
         L.pvo_process.argtypes = [C.c_void_p, C.POINTER(fp), C.POINTER(fp), C.c_int, C.c_int, C.c_float]
+        L.pvo_process2.restype = C.c_int
+        L.pvo_process2.argtypes = [C.c_void_p, C.POINTER(fp), C.POINTER(fp), C.c_int, C.c_int, C.c_int, C.c_float]
         L.pvo_process_planar.restype = C.c_int
         L.pvo_process_planar.argtypes = [C.c_void_p, fp, fp, C.c_int, C.c_int, C.c_long, fp]
         for name, rt in (("pvo_debug_X", C.POINTER(C.c_double)), ("pvo_debug_Y", C.POINTER(C.c_double)),
@@ -66,15 +68,18 @@ class Oracle:
     def __del__(self):
         self.close()
 
-    def process(self, blocks, pitch: float, paused: bool = False):
-        """blocks: list of float32[hop] per channel -> list of float32[hop] outputs."""
+    def process(self, blocks, pitch: float, paused: bool = False, nout: int = -1):
+        """blocks: list of float32[hop] per channel -> list of float32[hop] outputs.  nout: outputs[0].length when it differs from the input channel
+        count (ola-processor.js:46-51 reallocates the output buffers on its own); only the input-count channels are written (ola:111-118)."""
         nch = len(blocks)
         ins = [np.ascontiguousarray(b, dtype=np.float32) for b in blocks]
         outs = [np.zeros(self.hop, dtype=np.float32) for _ in range(nch)]
         fp = C.POINTER(C.c_float)
         ip = (fp * max(nch, 1))(*[_fptr(a) for a in ins])
         op = (fp * max(nch, 1))(*[_fptr(a) for a in outs])
-        lib().pvo_process(self.h, ip, op, nch, 1 if paused else 0, C.c_float(float(pitch)))
+        ok = lib().pvo_process2(self.h, ip, op, nch, nch if nout < 0 else nout, 1 if paused else 0, C.c_float(float(pitch)))
+        if not ok:
+            raise TypeError("outputs[0] has fewer channels than inputs[0] (the reference throws here)")
         return outs
 
     def process_planar(self, x: np.ndarray, pitch: np.ndarray) -> np.ndarray:
@@ -108,6 +113,7 @@ def run_case(case: dict, signals, pitch, collect_dumps=False):
     o = Oracle(N, h, nch)
     out = np.zeros((len(signals), T * h), dtype=np.float32)
     dumps = {}
+    nout = -1
     for m in range(T):
         paused = False
         for e in case.get("events", []):
@@ -116,8 +122,10 @@ def run_case(case: dict, signals, pitch, collect_dumps=False):
                     paused = True
                 if e["type"] == "channels":
                     nch = e["nch"]
+                if e["type"] == "out_channels":
+                    nout = e["nch"]
         blocks = [signals[c][m * h:(m + 1) * h] for c in range(nch)]
-        res = o.process(blocks, pitch[m], paused)
+        res = o.process(blocks, pitch[m], paused, nout=max(nout, nch) if nout >= 0 else -1)
         for c in range(nch):
             out[c, m * h:(m + 1) * h] = res[c]
         if collect_dumps and m in case.get("dump_hops", []):
