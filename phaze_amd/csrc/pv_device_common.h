@@ -94,6 +94,13 @@ struct WaveSrc {
 
 constexpr unsigned NOROUTE = 0xFFFFFFFFu;        // route = (rotation index << 16) | target bin
 
+// The pairwise test of the f < 1 scatter (pv_wave_kernel.hip: ov = delta_i - delta_{i+1} <= floor(gap / 2) for every pair of neighbouring peaks) cannot
+// fail when f >= 2/3: Math.round(x) lies in (x - 1/2, x + 1/2], so ov = gap - (round(p_{i+1} f) - round(p_i f)) < gap (1 - f) + 1 <= gap / 3 + 1, i.e.
+// ov <= ceil(gap / 3), and ceil(gap / 3) <= floor(gap / 2) for every gap >= 3 -- which is the least distance of two local maxima over +-2 bins
+// (pv:101-110); no peak is dropped in that range either (pv:127-129).  The kernels skip the test for such f (tests/test_pairwise_rule.py proves the
+// bound by exhaustion over peak positions and gaps for N <= 8192).
+constexpr float PV_PAIRWISE_SURE = 0.6667f;
+
 // Rotation exp(+2 pi j ridx / N) of one source value (pv:155-170).  R = 4: (delta * t) mod N is a multiple of N/4, so the rotation is
 // j^qd exactly: a swap and two sign-bit XORs (j^1 = (-y, x), j^2 = (-x, -y), j^3 = (y, -x)).
 template <int R_, int LOG2N_>

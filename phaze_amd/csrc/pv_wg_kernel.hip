@@ -800,8 +800,14 @@ resident_top:
                         const int pp = max(lastown[i], cprev), pn = min(firstown[i], cnext), b = 8 * tq + i;
                         const bool rising = !(b - (pp >> 16) < (pn >> 16) - b);
                         rt[i] = (rt[i] & 0x7FFFFFFFu) | (rising ? 0x80000000u : 0u);
-                        const int gap = (pn >> 16) - (pp >> 16), ov = __builtin_amdgcn_sbfe(pp, 0, 16) - __builtin_amdgcn_sbfe(pn, 0, 16);
-                        bad |= ov > (gap >> 1);
+                    }
+                    if (!(pfm >= PV_PAIRWISE_SURE)) {                       // (f >= 2/3: the test cannot fail, see pv_device_common.h)
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const int pp = max(lastown[i], cprev), pn = min(firstown[i], cnext);
+                            const int gap = (pn >> 16) - (pp >> 16), ov = __builtin_amdgcn_sbfe(pp, 0, 16) - __builtin_amdgcn_sbfe(pn, 0, 16);
+                            bad |= ov > (gap >> 1);
+                        }
                     }
                 }
             }

@@ -63,3 +63,31 @@ def test_pairwise_rule_implies_one_store_one_add(f, mean_gap):
             assert owner[bf] + 1 == owner[br]
     if f >= 0.75:
         assert accepted > 100          # the rule holds for (nearly) every frame in the range the fast residue covers
+
+
+def test_the_rule_cannot_fail_from_two_thirds_up():
+    """The kernels skip the wave-uniform test when pitchFactor >= PV_PAIRWISE_SURE = 0.6667f (pv_device_common.h): by exhaustion over every peak position
+    and every gap >= 3 (local maxima over +-2 bins are at least 3 bins apart) for N <= 8192, and for the f32 values around the threshold."""
+    thr = np.float32(0.6667)
+    fs = [thr, np.nextafter(thr, np.float32(1)), np.float32(0.67), np.float32(0.7), np.float32(0.75), np.float32(0.8), np.float32(0.8333333),
+          np.float32(0.9), np.float32(0.99), np.nextafter(np.float32(1), np.float32(0))]
+    rng = np.random.default_rng(5)
+    fs += list(rng.uniform(float(thr), 1.0, 6).astype(np.float32))
+    p = np.arange(0, 4097, dtype=np.int64)[:, None]
+    gap = np.arange(3, 4097, dtype=np.int64)[None, :]
+    for f in fs:
+        assert f >= thr
+        fd = np.float64(f)
+        d0 = np.floor(p * fd + 0.5).astype(np.int64) - p                          # Math.round(p f) - p
+        d1 = np.floor((p + gap) * fd + 0.5).astype(np.int64) - (p + gap)
+        assert bool(np.all(d0 - d1 <= (gap >> 1))), f
+        assert bool(np.all(np.floor(p * fd + 0.5) <= 4097)) and bool(np.all(np.floor(p * fd + 0.5) >= 0))   # no peak is dropped (pv:127-129)
+    # and just below 2/3 it does fail (gap 3): the threshold is not slack by more than the rounding of the constant
+    f = np.float64(np.float32(0.6666))
+    pp = np.arange(0, 4097, dtype=np.int64)
+    assert bool(np.any((np.floor(pp * f + 0.5) - pp) - (np.floor((pp + 3) * f + 0.5) - (pp + 3)) > 1))
+    # the sentinels of a missing neighbour (no peak on one side) pass as well: shift 0 at distance >= 4096
+    for f in fs:
+        fd = np.float64(f)
+        sh = (np.floor(pp * fd + 0.5) - pp).astype(np.int64)
+        assert bool(np.all(0 - sh <= ((pp + 4096) >> 1))) and bool(np.all(sh - 0 <= ((8192 - pp) >> 1)))
