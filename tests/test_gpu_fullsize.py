@@ -126,3 +126,46 @@ def test_many_short_streams_1024(nstreams, T):
     ref = oracle_lib.Oracle(fft, hop, cps).process_planar(base, np.full(T, 0.9, np.float32))
     assert S.rms(y[:cps].cpu().numpy().astype(np.float64) - ref) < 2e-6
     pv.close()
+
+
+@pytest.mark.parametrize("fft,hop,nch,T,pf", [(1024, 256, 1, 1 << 20, 1.5), (1024, 256, 1, 1 << 20, "sweep"), (2048, 512, 2, 1 << 18, 0.8),
+                                                (4096, 1024, 16, 64, 1.25), (8192, 2048, 8, 1 << 14, "sweep")])
+def test_windows_anywhere_in_a_full_size_run_match_the_oracle(fft, hop, nch, T, pf):
+    """BASELINE's full sizes against the ORACLE, not only on a prefix: the output of hop m is the sum of frames m - R + 1 .. m, a frame sees its own N
+    input samples, its pitchFactor and (m mod R) only -- so the oracle started at ANY hop a0 = 0 (mod R) on the same input reproduces the full-size
+    run from hop a0 + 2 (R - 1) on.  Windows of 48 hops at random offsets, at the first and last hops, and across the kernels' chunk boundaries."""
+    torch, pv, st = _setup(fft, hop, nch, T)
+    R = fft // hop
+    x = _noise(torch, nch, T * hop, seed=11) * 0.2
+    n = torch.arange(T * hop, device="cuda", dtype=torch.float32)
+    for c in range(nch):
+        x[c] += 0.3 * torch.sin(n * (0.031 * (c + 1))) + 0.2 * torch.sin(n * (0.173 + 0.01 * c)) + 0.1 * torch.sin(n * 1.3)
+    if pf == "sweep":
+        pitch = (0.5 + 1.5 * (torch.arange(T, device="cuda") % 64).float() / 63.0).float().contiguous()
+    else:
+        pitch = torch.full((T,), float(pf), device="cuda")
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        pv.process_batch_device(x.data_ptr(), y.data_ptr(), nch, T, T * hop, pitch.data_ptr())
+    pv.synchronize()
+    fpc = int(pv.info().get("frames_per_chunk", 0)) or 512
+    W = min(48, T)
+    rng = np.random.default_rng(fft + nch)
+    starts = {0, max(T - W, 0) // R * R}
+    if T > 4 * W:
+        for k in (1, 2, 5):                                   # windows straddling chunk boundaries
+            if k * fpc + W < T:
+                starts.add((k * fpc - W // 2) // R * R)
+        starts |= {int(s) // R * R for s in rng.integers(0, T - W, 6)}
+    chans = sorted({0, nch - 1})
+    worst = 0.0
+    for a0 in sorted(starts):
+        xs = x[chans, a0 * hop:(a0 + W) * hop].cpu().numpy()
+        ps = pitch[a0:a0 + W].cpu().numpy()
+        ref = oracle_lib.Oracle(fft, hop, len(chans)).process_planar(xs, ps)
+        skip = 0 if a0 == 0 else 2 * (R - 1)
+        got = y[chans, (a0 + skip) * hop:(a0 + W) * hop].cpu().numpy().astype(np.float64)
+        worst = max(worst, S.rms(got - ref[:, skip * hop:]))
+    assert worst < 2e-6, worst
+    pv.close()
