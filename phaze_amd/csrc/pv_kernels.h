@@ -90,6 +90,13 @@ size_t pv_wg_lds_bytes(int log2n, int hop);
 int pv_wg_threads(int log2n);
 hipError_t pv_launch_wg(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
 
+// four waves, sixteen elements per thread, two workgroups per CU: N = 8192, hop in {N/8, N/4, N/2, N} (pv_wg16_kernel.hip); dispatched by pv_launch_wg / pv_launch_wg_resident
+bool pv_wg16_supported(int log2n, int hop);
+size_t pv_wg16_lds_bytes();
+int pv_wg16_threads();
+hipError_t pv_launch_wg16(const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
+hipError_t pv_launch_wg16_resident(const PvKernelParams &p, int nslots, hipStream_t st);
+
 // wave-pair-per-frame kernel for N = 4096 (pv_pair_kernel.hip)
 bool pv_pair_supported(int log2n, int hop);
 size_t pv_pair_lds_bytes();

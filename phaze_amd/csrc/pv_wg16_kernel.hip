@@ -1,0 +1,954 @@
+// pv_wg16_kernel.hip -- N = 8192 (BASELINE configs[4]), hop in {N/8, N/4, N/2, N}: a workgroup of FOUR wavefronts per frame chain, 16 packed complex elements per
+// thread, TWO workgroups per CU.
+//
+// pv_wg_kernel.hip holds an 8192-point frame in eight waves of eight elements: 157 KB of LDS and 250 VGPRs, i.e. ONE workgroup per CU whose waves move in lock-step
+// between ~13 barriers -- LDS phases idle the VALUs and arithmetic phases idle the LDS (VALU 53 % busy).  Here the same pipeline runs with
+//   * 16 elements per thread, T = 256 threads: M = N/2 = 4096 = 16 * 16 * 16 -- three radix-16 passes with ONE cross-wave exchange and one exchange inside a wave
+//     per transform (the eight-wave kernel: four passes, two cross-wave exchanges and a register transpose), no LDS twiddle table for the per-thread pass
+//     (W^{ts k} = products of four loaded powers), no shift table in LDS (a thread computes the shifts of its own 16 candidate bins);
+//   * 80 KB of LDS and <= 256 VGPRs: two workgroups per CU, each SIMD holds one wave of either, and the parked time of one workgroup (barriers, exchanges) is the
+//     other's issue time.
+//
+// Layout.  z[n] = xw[2n] + j xw[2n+1], n = n0 + 16 n1 + 256 n2.  Thread t = n1 + 16 n0 (n1 in the low four LANE bits, n0 = wave and lane bits 5..4), register r = n2:
+// thread t holds the complex elements ts + 256 r with ts = (t >> 4) + 16 (t & 15) -- the float2 at samples 2 ts + 512 r, i.e. the lanes of a load are 128 bytes
+// apart and the four waves together use every byte of a line (L2 merges; measured traffic in profiles/).  With k = k0 + 16 k1 + 256 k2:
+//   pass A over r = n2 -> k0, twiddle W_4096^{ts k0};  exchange inside groups of 16 lanes (register <-> low lane bits, XOR-swizzled, no barrier): registers n1
+//   pass B over n1 -> k1, twiddle W_256^{n0 k1};       cross-wave exchange (register <-> wave and lane bits 5..4): thread t' = k0 + 16 k1, registers n0
+//   pass C over n0 -> k2:  thread t', register r' <-> bin t' + 256 r'  -- the NATURAL bin order every stage between the transforms wants.
+// The inverse runs the same passes backwards (C, cross-wave, twiddle, B, in-wave, twiddle, A) in packed fp32 and lands in the sample layout it started from.
+// Everything between the transforms is pv_wg_kernel's / pv_wave2k_kernel's pipeline (16 consecutive bins per thread in the padded magnitude / route layout);
+// reference citations are those of pv_kernels.hip / pv_wave_kernel.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "pv_kernels.h"
+#include "pv_device_common.h"
+#include "pv_pk_math.h"
+#ifndef PV_PAIRWISE
+#define PV_PAIRWISE 1
+#endif
+
+namespace {
+
+struct QC {
+    static constexpr int T = 256, M = 4096, N = 8192, H = 4097, LOG2N = 13;
+    // inside the scratch, between the two FFTs:
+    static constexpr int OFF_Y = 0;                       // float2[H]                 | fp32 spectrum stash (f < 1) before Y is zeroed
+    static constexpr int MAG0 = 8;                        // magnitudes / routes start 8 words in (bins -2, -1 of thread 0's window stay inside)
+    static constexpr int OFF_ROUTE = 32784;               // u32 routes | f32 mags, both in the padded layout P(bin) = bin + 4 (bin >> 4) (pv_wave2k_kernel.hip) | u32 claim words [H] (plain)
+    static constexpr int ROUTE_WORDS = MAG0 + 5120 + 8;   // P(4096) = 5120
+    static constexpr int OFF_RESQ = 49184;                // float2[N / 4] one residue quarter | c2r hand-over
+    static constexpr int SCRATCH = OFF_RESQ + 16384;      // 65568
+    static_assert(8 * H <= OFF_ROUTE, "Y runs into the routes");
+    static_assert(OFF_ROUTE + 4 * ROUTE_WORDS <= SCRATCH && OFF_ROUTE + 4 * H <= OFF_RESQ, "routes / claim words");
+    static_assert(OFF_ROUTE >= 16 * 8 * T, "MAG must not alias the partner rows of the split pass");
+    // after the scratch:
+    static constexpr int OFF_NEAR = SCRATCH;              // i32 LASTIN[T], FIRSTIN[T]
+    static constexpr int OFF_OCC = OFF_NEAR + 8 * T;      // u64[4] occupancy | u32[4] "a gap fails the pairwise test" | broadcast word (resident)
+    static constexpr int OFF_TWB = OFF_OCC + 64;          // double2[15][16]  W_256^{n0 k1}, k1 = 1..15
+    static constexpr int OFF_TWBF = OFF_TWB + 16 * 15 * 16;   // float2[15][16] conj, fp32
+    static constexpr int OFF_XQ = OFF_TWBF + 8 * 15 * 16; // f32[N / 4] windowed samples xw[4n + 2] of the frame (f < 0.75): base stage of the general residue
+    static constexpr int LDS_BYTES = OFF_XQ + N;          // 81632: two workgroups per CU
+    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+};
+
+// ---- radix-16 butterflies, natural order in and out: X[q + 4 p] = sum_j W4^{j p} ( W16^{j q} sum_m a[j + 4 m] W4^{m q} ) ----
+__device__ __forceinline__ double2 dmul(double2 a, double2 w)          // a * w, the roundings spelled out (instances must agree bit for bit)
+{
+    return double2{__fma_rn(a.x, w.x, -__dmul_rn(a.y, w.y)), __fma_rn(a.x, w.y, __dmul_rn(a.y, w.x))};
+}
+__device__ __forceinline__ double2 dmulc(double2 a, double2 w) { return dmul(a, double2{w.x, -w.y}); }   // a * conj(w)
+
+__device__ __forceinline__ void radix16_fwd(double2 (&a)[16])
+{
+    const double c = 0.92387953251128675613, s = 0.38268343236508977173, h = 0.70710678118654752440;
+    double2 b[16];                                                      // b[4 j + q]
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const double2 x0 = a[j], x1 = a[j + 4], x2 = a[j + 8], x3 = a[j + 12];
+        const double2 s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = csub(x1, x3);
+        b[4 * j] = cadd(s02, s13);
+        b[4 * j + 1] = double2{d02.x + d13.y, d02.y - d13.x};          // d02 - j d13
+        b[4 * j + 2] = csub(s02, s13);
+        b[4 * j + 3] = double2{d02.x - d13.y, d02.y + d13.x};          // d02 + j d13
+    }
+    // W16^{j q} = exp(-2 pi j (j q) / 16)
+    b[5] = dmul(b[5], double2{c, -s});                                  // e = 1
+    b[6] = double2{(b[6].x + b[6].y) * h, (b[6].y - b[6].x) * h};      // e = 2: (h, -h)
+    b[7] = dmul(b[7], double2{s, -c});                                  // e = 3
+    b[9] = double2{(b[9].x + b[9].y) * h, (b[9].y - b[9].x) * h};      // e = 2
+    b[10] = double2{b[10].y, -b[10].x};                                 // e = 4: -j
+    b[11] = double2{(b[11].y - b[11].x) * h, -(b[11].x + b[11].y) * h}; // e = 6: (-h, -h)
+    b[13] = dmul(b[13], double2{s, -c});                                // e = 3
+    b[14] = double2{(b[14].y - b[14].x) * h, -(b[14].x + b[14].y) * h}; // e = 6
+    b[15] = dmul(b[15], double2{-c, s});                                // e = 9
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const double2 x0 = b[q], x1 = b[4 + q], x2 = b[8 + q], x3 = b[12 + q];
+        const double2 s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = csub(x1, x3);
+        a[q] = cadd(s02, s13);
+        a[q + 4] = double2{d02.x + d13.y, d02.y - d13.x};
+        a[q + 8] = csub(s02, s13);
+        a[q + 12] = double2{d02.x - d13.y, d02.y + d13.x};
+    }
+}
+
+// the inverse instance (exp(+2 pi j n k / 16)) in packed fp32
+__device__ __forceinline__ void radix16_inv_pk(pk::c32 (&a)[16])
+{
+    const float c = 0.92387953251128675613f, s = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    const pk::c32 hh{h, h};
+    pk::c32 b[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const pk::c32 x0 = a[j], x1 = a[j + 4], x2 = a[j + 8], x3 = a[j + 12];
+        const pk::c32 s02 = pk::add(x0, x2), d02 = pk::sub(x0, x2), s13 = pk::add(x1, x3), d13 = pk::sub(x1, x3);
+        b[4 * j] = pk::add(s02, s13);
+        b[4 * j + 1] = pk::add_j(d02, d13);                             // d02 + j d13
+        b[4 * j + 2] = pk::sub(s02, s13);
+        b[4 * j + 3] = pk::sub_j(d02, d13);
+    }
+    b[5] = pk::cmul(b[5], pk::c32{c, s});                               // exp(+2 pi j / 16)
+    b[6] = pk::mul(pk::add_j(b[6], b[6]), hh);                          // (1 + j) h
+    b[7] = pk::cmul(b[7], pk::c32{s, c});
+    b[9] = pk::mul(pk::add_j(b[9], b[9]), hh);
+    b[10] = pk::c32{-b[10].y, b[10].x};                                 // + j
+    b[11] = pk::mul(pk::neg_add_j(b[11], b[11]), hh);                   // (-1 + j) h
+    b[13] = pk::cmul(b[13], pk::c32{s, c});
+    b[14] = pk::mul(pk::neg_add_j(b[14], b[14]), hh);
+    b[15] = pk::cmul(b[15], pk::c32{-c, -s});                           // exp(+2 pi j 9 / 16)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const pk::c32 x0 = b[q], x1 = b[4 + q], x2 = b[8 + q], x3 = b[12 + q];
+        const pk::c32 s02 = pk::add(x0, x2), d02 = pk::sub(x0, x2), s13 = pk::add(x1, x3), d13 = pk::sub(x1, x3);
+        a[q] = pk::add(s02, s13);
+        a[q + 4] = pk::add_j(d02, d13);
+        a[q + 8] = pk::sub(s02, s13);
+        a[q + 12] = pk::sub_j(d02, d13);
+    }
+}
+
+// The fifteen per-thread twiddles of pass A from four of them: W^{ts k}, k = 1, 2, 4, 8 (exact table entries), the rest by products of at most three factors.
+struct TwA { double2 w1, w2, w4, w8; };
+
+// M = 4096-point complex FFT across the workgroup: in  thread t, reg r <-> element ts + 256 r (ts = (t >> 4) + 16 (t & 15)),
+//                                                     out thread t, reg r <-> bin t + 256 r.  S: the 64 KB scratch.
+__device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA &tw, const double2 *TWB, int t)
+{
+    radix16_fwd(a);
+    {
+        const double2 w3 = dmul(tw.w1, tw.w2), w5 = dmul(tw.w4, tw.w1), w6 = dmul(tw.w4, tw.w2), w7 = dmul(tw.w4, w3);
+        a[1] = dmul(a[1], tw.w1); a[2] = dmul(a[2], tw.w2); a[3] = dmul(a[3], w3); a[4] = dmul(a[4], tw.w4);
+        a[5] = dmul(a[5], w5); a[6] = dmul(a[6], w6); a[7] = dmul(a[7], w7); a[8] = dmul(a[8], tw.w8);
+        a[9] = dmul(a[9], dmul(tw.w8, tw.w1)); a[10] = dmul(a[10], dmul(tw.w8, tw.w2)); a[11] = dmul(a[11], dmul(tw.w8, w3));
+        a[12] = dmul(a[12], dmul(tw.w8, tw.w4)); a[13] = dmul(a[13], dmul(tw.w8, w5)); a[14] = dmul(a[14], dmul(tw.w8, w6)); a[15] = dmul(a[15], dmul(tw.w8, w7));
+    }
+    // exchange inside the groups of 16 lanes: [reg k0][lane n1] -> [reg n1][lane k0]; element (k0, n1) of group g at 256 g + 16 k0 + (n1 ^ k0)
+    const int c = t & 15, g = t >> 4;
+    double2 *Sg = S + 256 * g;
+#pragma unroll
+    for (int k = 0; k < 16; k++) Sg[16 * k + (c ^ k)] = a[k];
+    wave_sync();                                                        // the 16 lanes of a group sit in one wave: LDS traffic of a wave executes in order
+#pragma unroll
+    for (int n = 0; n < 16; n++) a[n] = Sg[16 * c + (n ^ c)];
+    radix16_fwd(a);
+#pragma unroll
+    for (int k = 1; k < 16; k++) a[k] = dmul(a[k], TWB[(k - 1) * 16 + g]);
+    __syncthreads();                                                    // every wave is done with its in-wave exchange: the rows below overwrite other waves' groups
+#pragma unroll
+    for (int k = 0; k < 16; k++) S[256 * k + t] = a[k];                 // [reg k1][thread (n0, k0)]
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 16; n++) a[n] = S[256 * g + 16 * n + c];        // thread t = k0 + 16 k1 takes (k1 = g, n0 = n, k0 = c)
+    __syncthreads();                                                    // the scratch is free again
+    radix16_fwd(a);
+}
+
+// The inverse in packed fp32, the same passes backwards: in thread t, reg r <-> bin t + 256 r, out thread t, reg r <-> element ts + 256 r.
+// The caller guarantees that nobody still reads the first 32 KB of the scratch; the data of the cross-wave exchange is consumed before the function returns its
+// in-wave exchange, which lives in the SECOND 32 KB (no barrier between the two).
+struct TwAf { pk::c32 w1, w2, w4, w8; };
+__device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, const TwAf &tw, const pk::c32 *TWBF, int t)
+{
+    const int c = t & 15, g = t >> 4;
+    radix16_inv_pk(a);
+#pragma unroll
+    for (int n = 0; n < 16; n++) S[256 * g + 16 * n + c] = a[n];        // thread (k1 = g, k0 = c), reg n0 = n
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = S[256 * k + t];                 // thread (n0 = g, k0 = c), reg k1
+#pragma unroll
+    for (int k = 1; k < 16; k++) a[k] = pk::cmul(a[k], TWBF[(k - 1) * 16 + g]);
+    radix16_inv_pk(a);
+    pk::c32 *Sg = S + 4096 + 256 * g;                                   // second half of the scratch (fp32 elements are half the size)
+#pragma unroll
+    for (int n = 0; n < 16; n++) Sg[16 * c + (n ^ c)] = a[n];           // thread (n0, k0 = c), reg n1 = n
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = Sg[16 * k + (c ^ k)];           // thread (n0, n1 = c), reg k0
+    {
+        const pk::c32 w3 = pk::cmul(tw.w1, tw.w2), w5 = pk::cmul(tw.w4, tw.w1), w6 = pk::cmul(tw.w4, tw.w2), w7 = pk::cmul(tw.w4, w3);
+        a[1] = pk::cmul(a[1], tw.w1); a[2] = pk::cmul(a[2], tw.w2); a[3] = pk::cmul(a[3], w3); a[4] = pk::cmul(a[4], tw.w4);
+        a[5] = pk::cmul(a[5], w5); a[6] = pk::cmul(a[6], w6); a[7] = pk::cmul(a[7], w7); a[8] = pk::cmul(a[8], tw.w8);
+        a[9] = pk::cmul(a[9], pk::cmul(tw.w8, tw.w1)); a[10] = pk::cmul(a[10], pk::cmul(tw.w8, tw.w2)); a[11] = pk::cmul(a[11], pk::cmul(tw.w8, w3));
+        a[12] = pk::cmul(a[12], pk::cmul(tw.w8, tw.w4)); a[13] = pk::cmul(a[13], pk::cmul(tw.w8, w5)); a[14] = pk::cmul(a[14], pk::cmul(tw.w8, w6));
+        a[15] = pk::cmul(a[15], pk::cmul(tw.w8, w7));
+    }
+    radix16_inv_pk(a);
+}
+
+// o * W_32^r (fp64, split pass) and o * exp(+2 pi j r / 32) (packed fp32, c2r pass), r = 0..7 compile-time: the row part of W_8192^{t + 256 r}
+__device__ __forceinline__ double2 mul_w32_16(double2 o, int r)
+{
+    constexpr double c[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708, 0.70710678118654752440,
+                             0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0};
+    if (r == 0) return o;
+    return cmul(o, double2{c[r], -c[8 - r]});
+}
+__device__ __forceinline__ pk::c32 mul_w32_inv_pk16(pk::c32 o, int r)
+{
+    constexpr float c[9] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                            0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.0f};
+    if (r == 0) return o;
+    return pk::cmul(o, pk::c32{c[r], c[8 - r]});
+}
+
+// Workgroup-wide claim rounds (pv_wg_kernel.hip): atomic MIN on the claim word, the smallest pending source bin wins the round.  CLAIM[0..H) all-ones on entry and exit.
+template <int NS>
+__device__ __forceinline__ void claim_rounds_wg16(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned *CLAIM)
+{
+    unsigned pend = 0;
+    unsigned tg[NS];
+#pragma unroll
+    for (int r = 0; r < NS; r++) {
+        const unsigned t = rt[r] & 0xFFFFu;
+        const bool ok = t < (unsigned)QC::H;
+        pend |= ok ? (1u << r) : 0u;
+        tg[r] = ok ? t : 0u;
+    }
+    while (__syncthreads_or(pend != 0u)) {
+#pragma unroll
+        for (int r = 0; r < NS; r++) if (pend & (1u << r)) atomicMin(&CLAIM[tg[r]], (unsigned)id[r]);
+        __syncthreads();
+        unsigned c[NS];
+        float2 o[NS];
+#pragma unroll
+        for (int r = 0; r < NS; r++) c[r] = CLAIM[tg[r]];
+#pragma unroll
+        for (int r = 0; r < NS; r++) o[r] = Y[tg[r]];
+#pragma unroll
+        for (int r = 0; r < NS; r++) {
+            if ((pend & (1u << r)) && c[r] == (unsigned)id[r]) {
+                Y[tg[r]] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
+                CLAIM[tg[r]] = 0xFFFFFFFFu;
+                pend &= ~(1u << r);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int digitrev4_16(int v, int nd)
+{
+    const unsigned r = __brev((unsigned)v) >> (32 - 2 * nd);
+    return (int)(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u));
+}
+
+// Rare path: above-Nyquist residue of fft.js's in-place real DIT, one quarter of the buffer at a time (log2 N odd: radix-2 base blocks, bundle:447-463,
+// then the radix-4 stages with their predicated stores, bundle:329-441), then its sources are added into Y.  See residue_scatter_wg.
+template <int R_>
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(const float *in, const float *hist, int hist_len, bool sys, long s0, const float *__restrict__ hann,
+                                                                               const float2 *__restrict__ tw32, int t, int upper_end, int up_delta, unsigned up_ridx,
+                                                                               double *dbg_X, bool plain)
+{
+    constexpr int N = QC::N, H = QC::H, T = QC::T, QN = N / 4, LOG2N = QC::LOG2N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *Y = reinterpret_cast<float2 *>(smem + QC::OFF_Y);
+    unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + QC::OFF_ROUTE);
+    float2 *Q = reinterpret_cast<float2 *>(smem + QC::OFF_RESQ);
+    const float *XQ = reinterpret_cast<const float *>(smem + QC::OFF_XQ);
+    const WaveSrc src{in, hist, hist_len, sys};
+    for (int base = N / 2; base < N && base < upper_end; base += QN) {
+        constexpr int nd = (LOG2N - 1) / 2;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                                      // QN / 2 = 1024 radix-2 blocks per quarter
+            const int lb = t + T * i;
+            const int off = digitrev4_16((base == N / 2 ? N / 4 : base / 2) + lb, nd);
+            float a, b;
+            if (base == N / 2) { a = XQ[(off - 2) >> 2]; b = XQ[((off - 2) >> 2) + N / 8]; }     // quarter 2: sub-FFT of xw[4n + 2], from the frame's stash
+            else { a = src.at(s0 + off) * hann[off]; b = src.at(s0 + off + N / 2) * hann[off + N / 2]; }
+            Q[2 * lb] = float2{a + b, 0.f};
+            Q[2 * lb + 1] = float2{a - b, 0.f};
+        }
+        __syncthreads();
+        for (int log2m = 3; log2m <= LOG2N - 2; log2m += 2) {              // block sizes 8, 32, 128, 512, 2048 inside the quarter
+            const int q = (1 << log2m) >> 2, hq = q >> 1;
+            const int nblocks = QN >> log2m;
+            const int tws = LOG2N - log2m;
+            for (int u = t; u < nblocks * (hq + 1); u += T) {
+                int blk, i;
+                if (u < nblocks * hq) { blk = u / hq; i = u - blk * hq; } else { blk = u - nblocks * hq; i = hq; }
+                const int o = blk << log2m;
+                const float2 A = Q[o + i];
+                const float2 w1 = tw32[i << tws];
+                const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);          // (the same forms as pv_wg_kernel: results agree bit for bit)
+                const float2 Bv = cmul(Q[o + q + i], w1);
+                const float2 Cc = cmul(Q[o + 2 * q + i], w2);
+                const float2 D = cmul(Q[o + 3 * q + i], w3);
+                const float2 T0 = cadd(A, Cc), T1 = csub(A, Cc), T2 = cadd(Bv, D), T3 = csub(Bv, D);
+                Q[o + i] = cadd(T0, T2);
+                Q[o + q + i] = float2{T1.x + T3.y, T1.y - T3.x};
+                if (i == 0) {
+                    Q[o + 2 * q] = csub(T0, T2);
+                } else if (i != hq) {
+                    Q[o + q - i] = float2{T1.x - T3.y, -(T1.y + T3.x)};
+                    Q[o + 2 * q - i] = float2{T0.x - T2.x, -(T0.y - T2.y)};
+                }
+            }
+            __syncthreads();
+        }
+        if (dbg_X)
+            for (int i = t; i < QN; i += T) if (base + i >= H) { dbg_X[2 * (base + i)] = Q[i].x; dbg_X[2 * (base + i) + 1] = Q[i].y; }
+        unsigned rt[8];
+        float2 ys[8];
+        int id[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int b = base + t + T * j, tgt = b + up_delta;
+            rt[j] = (b >= H && b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+            ys[j] = rotate_route<R_, LOG2N>(rt[j], Q[t + T * j], tw32);
+            id[j] = b - N / 2;
+        }
+        if (plain) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (rt[j] != NOROUTE) Y[rt[j] & 0xFFFFu] = ys[j];
+        } else {
+            claim_rounds_wg16<8>(rt, ys, id, Y, CLAIM);
+        }
+        __syncthreads();
+    }
+}
+
+// S_ROWS = hop / 512 in {2, 4, 8, 16}: the frame advances by whole register rows (512 samples), overlap-add accumulator and input window live in registers.
+// AUX: test-tap instance.  RESIDENT: streaming instance that stays on the GPU (see pv_wg_kernel.hip).
+template <int S_ROWS, bool AUX, bool RESIDENT = false>
+__global__ __launch_bounds__(256, 2) PV_NO_DS_MERGE void pv_wg16_kernel(const PvKernelParams p)
+{
+    using C = QC;
+    constexpr int N = C::N, M = C::M, H = C::H, T = C::T, LOG2N = C::LOG2N;
+    constexpr int HOP = 512 * S_ROWS, R = N / HOP, LROWS = 16 - S_ROWS, L = N - HOP;
+    constexpr int NEGPD = -(1 << 30), POSPD = 1 << 30;                    // packed (bin << 16 | shift) sentinels: no peak on this side
+    constexpr int DROP = 0x4000;
+    const int t = threadIdx.x;
+    const int ch = blockIdx.y, chunk = blockIdx.x;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2 *S64 = reinterpret_cast<double2 *>(smem);
+    float2 *Y = reinterpret_cast<float2 *>(smem + C::OFF_Y);
+    float *MAG = reinterpret_cast<float *>(smem + C::OFF_ROUTE);
+    unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);
+    unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);
+    int *LASTIN = reinterpret_cast<int *>(smem + C::OFF_NEAR), *FIRSTIN = LASTIN + T;
+    unsigned long long *OCC = reinterpret_cast<unsigned long long *>(smem + C::OFF_OCC);
+    unsigned *BADW = reinterpret_cast<unsigned *>(smem + C::OFF_OCC + 32);
+    double2 *TWB = reinterpret_cast<double2 *>(smem + C::OFF_TWB);
+    pk::c32 *TWBF = reinterpret_cast<pk::c32 *>(smem + C::OFF_TWBF);
+
+    // ---- table: W_256^{n0 k1} = tw[32 n0 k1] (tw[i] = exp(-2 pi j i / N)), and its conjugate in fp32 ----
+    if (t < 240) {
+        const int k1 = t / 16 + 1, n0 = t % 16;
+        const double2 w = p.tw64[(32 * n0 * k1) & (N - 1)];
+        TWB[t] = w;
+        TWBF[t] = pk::c32{(float)w.x, -(float)w.y};
+    }
+    const int ts = (t >> 4) + 16 * (t & 15);                              // this thread's complex elements: ts + 256 r
+
+    unsigned psh_key = 0u;
+    bool psh_valid = false;
+    v4u dq0{0u, 0u, 0u, 0u}, dq1{0u, 0u, 0u, 0u};                         // shifts of this thread's own 16 candidate bins (i16 each)
+    const float *hist_in = p.hist_in, *acc_in = p.acc_in;
+    float *hist_out = p.hist_out, *acc_out = p.acc_out;
+    int t0_mod_n = p.t0_mod_n;
+    unsigned done_seq = p.done_seq;
+    unsigned last_seq = p.done_seq;
+resident_top:
+    if (RESIDENT) {
+        unsigned *BC = reinterpret_cast<unsigned *>(smem + C::OFF_OCC + 48);
+        if (t == 0) {
+            unsigned word, idle = 0;
+            for (;;) {
+                word = __hip_atomic_load(p.ctl + 16 + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((word & 0xFFFFu) != (last_seq & 0xFFFFu)) break;
+                if (__hip_atomic_load(p.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || ++idle > 60000u) { word = 0u; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            BC[0] = word;
+        }
+        __syncthreads();
+        const unsigned word = BC[0];
+        __syncthreads();
+        if (word == 0u) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        const unsigned seq = word & 0xFFFFu, nch_now = (word >> 16) & 0x7Fu, cur = (word >> 23) & 1u;
+        t0_mod_n = (int)(((word >> 24) & 0xFFu) * HOP) & (N - 1);
+        hist_in = p.hist2[cur]; hist_out = p.hist2[cur ^ 1u];
+        acc_in = p.acc2[cur]; acc_out = p.acc2[cur ^ 1u];
+        done_seq = last_seq = seq;
+        if (nch_now == 0u) {
+            for (int j = t; j < L; j += T) { hist_out[(long)ch * L + j] = hist_in[(long)ch * L + j]; acc_out[(long)ch * L + j] = acc_in[(long)ch * L + j]; }
+            goto resident_top;
+        }
+    }
+    const int first_out = chunk * p.frames_per_chunk;
+    int last_out = first_out + p.frames_per_chunk;
+    if (last_out > p.nhops) last_out = p.nhops;
+    int first_frame = first_out - (R - 1);
+    const bool from_state = (first_frame <= 0);
+    if (from_state) first_frame = 0;
+
+    const long cbase = (long)ch * p.ch_stride;
+    const WaveSrc src{p.in + cbase, hist_in + (long)ch * L, L, RESIDENT && p.in_cached != 0};
+    float *outp = p.out + cbase;
+    const bool vec_out = (reinterpret_cast<uintptr_t>(outp) & 7u) == 0;
+    const bool vec_in = ((reinterpret_cast<uintptr_t>(src.in) | reinterpret_cast<uintptr_t>(src.hist)) & 7u) == 0;
+    const float *pitch_row = p.pitch + (p.pitch_stride ? (long)(ch / p.ch_per_stream) * p.pitch_stride : 0);
+
+    float2 hw[16];                                         // 0.5 * Hann (the second half of the table) at samples 2 (ts + 256 r), +1: the split pass's 1/2 folded into the window (exact)
+#pragma unroll
+    for (int r = 0; r < 16; r++) hw[r] = *reinterpret_cast<const float2 *>(p.hann + N + 2 * (ts + T * r));
+
+    float2 acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = float2{0.f, 0.f};
+    if (from_state) {
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) {
+            const float *a = acc_in + (long)ch * L + 2 * ts + 2 * T * r;
+            acc[r] = float2{a[0], a[1]};
+        }
+    }
+    auto load_rows = [&](float2 *w, int nrows, int first_row, int frame) {
+        const long s0 = (long)(frame + 1) * HOP - N + 2 * ts;
+#pragma unroll
+        for (int r = 0; r < nrows; r++) {
+            const long sx = s0 + 2 * T * (first_row + r);
+            if (RESIDENT && src.sys && vec_in && sx >= 0) {
+                const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src.in + sx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w[r] = float2{__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32))};
+            } else if (vec_in) w[r] = *reinterpret_cast<const float2 *>(sx < 0 ? src.hist + sx + src.hist_len : src.in + sx);
+            else w[r] = float2{src.at(sx), src.at(sx + 1)};
+        }
+    };
+    float2 raw[16];
+    load_rows(raw, 16, 0, first_frame);
+    float pf_next = (RESIDENT && src.sys) ? __hip_atomic_load(pitch_row + first_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : pitch_row[first_frame];
+    int emit_v = first_out;
+    asm volatile("" : "+v"(emit_v));
+    __syncthreads();
+
+    for (int m = first_frame; m < last_out; ++m) {
+        int tq = t;
+        asm volatile("" : "+v"(tq));                                       // LDS addresses are recomputed per frame instead of hoisted (see pv_wg_kernel.hip)
+        const int l = tq & 63, wv = __builtin_amdgcn_readfirstlane(tq >> 6);
+        const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));
+        const double pf = (double)pfm;
+        const int tmod = (int)(((long)t0_mod_n + (long)m * HOP) & (N - 1));
+        const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
+        const int pl = tq + 4 * (tq >> 4), ql = tq + 4 * ((tq + 15) >> 4);   // padded positions: P(tq + 256 r) = pl + 320 r, P(M - tq - 256 r) = 5120 - ql - 320 r
+
+        // Loop-invariant per-thread values that are only needed in ONE phase of the frame are re-loaded per frame (L1 / L2 hits, issued ahead of their use) through
+        // addresses derived from the opaque thread id, instead of occupying registers across the phases that need every one of them: the pass-A twiddles here,
+        // the Hann values and the inverse's twiddles in front of the inverse FFT.
+        const int tsq = (tq >> 4) + 16 * (tq & 15);
+        const TwA twa{p.tw64[(2 * tsq) & (N - 1)], p.tw64[(4 * tsq) & (N - 1)], p.tw64[(8 * tsq) & (N - 1)], p.tw64[(16 * tsq) & (N - 1)]};   // W_4096^{ts k}, k = 1, 2, 4, 8
+        const double2 wl = p.tw64[tq];                                      // split pass: W_N^{tq + 256 r} = wl * W_32^r
+        // ---- Hann (pv:55), pack, forward FFT in fp64 (the split pass's 1/2 is folded into the window, exact) ----
+        double2 z[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) z[r] = double2{(double)(raw[r].x * hw[r].x), (double)(raw[r].y * hw[r].y)};
+        if (pf < 0.75 && ((tq >> 4) & 1)) {
+            // the general residue (f < 0.75 only) rebuilds quarter 2 of fft.js's buffer from the windowed samples xw[4n + 2] = sample 2 (ts + 256 r) of the threads
+            // with an odd ts: stashed in natural order while they are in registers (pv_wg_kernel.hip)
+            float *XQ = reinterpret_cast<float *>(smem + C::OFF_XQ);
+#pragma unroll
+            for (int r = 0; r < 16; r++) XQ[(tsq + T * r - 1) >> 1] = raw[r].x * (2.0f * hw[r].x);
+        }
+        fft_wg16(z, S64, twa, TWB, tq);
+
+        // ---- split pass in conjugate pairs: thread tq owns the pairs k = tq + 256 r, r < 8: XA[r] = X[k], XB[r] = X[M - k]; thread 0 also the self-paired bin M/2.
+        //      The partner values Z[M - k] are rows 8..15 of other threads -> LDS ----
+        float2 XA[8], XB[8], xHf{0.f, 0.f};
+        {
+#pragma unroll
+            for (int r = 8; r < 16; r++) S64[tq + T * (r - 8)] = z[r];
+            __syncthreads();
+            double2 xH{0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = tq + T * r;
+                const double2 zm = (k == 0) ? z[0] : S64[8 * T - k];          // element M - k sits at (M - k) - 8T of the stored rows
+                const double2 E{z[r].x + zm.x, z[r].y - zm.y};
+                const double2 O{z[r].x - zm.x, z[r].y + zm.y};
+                const double2 WO = cmul(wl, mul_w32_16(O, r));
+                double2 xa{E.x + WO.y, E.y - WO.x};
+                double2 xb{E.x - WO.y, -(E.y + WO.x)};
+                if (r == 0 && tq == 0) {
+                    xa = double2{2.0 * (z[0].x + z[0].y), 0.0};               // X[0], X[M]: both real
+                    xb = double2{2.0 * (z[0].x - z[0].y), 0.0};
+                }
+                // (the magnitudes sit behind the partner rows: they may be written while other threads still read theirs; fp32 values at once: 16 doubles less to hold)
+                MAG[C::MAG0 + pl + 320 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                MAG[C::MAG0 + 5120 - ql - 320 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                XA[r] = float2{(float)xa.x, (float)xa.y};
+                XB[r] = float2{(float)xb.x, (float)xb.y};
+                if (dbg) {
+                    const int ka = tq + T * r, kb = M - ka;
+                    p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
+                    p.dbg_X[2 * kb] = xb.x; p.dbg_X[2 * kb + 1] = xb.y;
+                }
+            }
+            if (tq == 0) {
+                xH = double2{2.0 * z[8].x, -2.0 * z[8].y};                    // k = M/2 pairs with itself: X = 2 conj(Z)
+                MAG[C::MAG0 + 2560] = (float)(xH.x * xH.x + xH.y * xH.y);
+                if (dbg) { p.dbg_X[M] = xH.x; p.dbg_X[M + 1] = xH.y; }
+            }
+            xHf = float2{(float)xH.x, (float)xH.y};
+            if (pf < 1.0) {                                                // fp32 spectrum stash for the fast residue (Y is not live yet; it aliases the partner rows)
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 8; r++) { Y[tq + T * r] = XA[r]; Y[M - tq - T * r] = XB[r]; }
+                if (tq == 0) Y[M / 2] = xHf;
+            }
+        }
+        // slide the raw window; the rows the next frame adds are issued here
+        {
+            const int mn = (m + 1 < last_out) ? m + 1 : m;
+#pragma unroll
+            for (int r = 0; r < 16 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
+            if (!RESIDENT) {
+                load_rows(&raw[16 - S_ROWS], S_ROWS, 16 - S_ROWS, mn);
+                pf_next = pitch_row[mn];
+            }
+        }
+        // ---- shifts Math.round(peak * f) - peak (pv:125,147) of this thread's own 16 candidate bins, rebuilt only when f changes ----
+        {
+            const unsigned pfb = __float_as_uint(pfm);
+            if (!psh_valid || pfb != psh_key) {
+                psh_key = pfb;
+                psh_valid = true;
+                unsigned sh[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int pk = 16 * tq + i;
+                    const double ps = floor((double)pk * pf + 0.5);
+                    const bool ok = (ps <= (double)H) && (ps >= -(double)(2 * N));
+                    sh[i] = (unsigned)(ok ? ((int)ps - pk) : DROP) & 0xFFFFu;       // DROP pushes every target of the region out of range
+                }
+                dq0 = v4u{sh[0] | (sh[1] << 16), sh[2] | (sh[3] << 16), sh[4] | (sh[5] << 16), sh[6] | (sh[7] << 16)};
+                dq1 = v4u{sh[8] | (sh[9] << 16), sh[10] | (sh[11] << 16), sh[12] | (sh[13] << 16), sh[14] | (sh[15] << 16)};
+            }
+        }
+        __syncthreads();                                                   // magnitudes (and the stash) complete
+        // ---- above-Nyquist residue, fast form: W^{2k} S2[k] = (X[k] - X[k+N/4] + X[k+N/2] - X[k+3N/4]) / 4, k = 1 + tq + 256 j (see pv_wg_kernel.hip) ----
+        float2 s2v[4] = {float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}};
+        if (pf < 1.0) {
+            const float2 s2w0 = cconj(p.tw32[2 * (1 + tq)]);               // conj(W^{2k}) of this thread's first bin k = 1 + tq; k = 1 + tq + 256 j: times conj(W_16^j)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = 1 + tq + T * j;                                // k in [1, N/8]
+                const float2 x0 = Y[k], x1 = Y[k + M / 2], x2 = Y[M - k], x3 = Y[M / 2 - k];
+                const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
+                const float c8 = 0.92387953251128675613f, s8 = 0.38268343236508977173f, h8 = 0.70710678118654752440f;
+                const float2 wj = (j == 0) ? s2w0 : (j == 1) ? cmul(s2w0, float2{c8, s8}) : (j == 2) ? cmul(s2w0, float2{h8, h8}) : cmul(s2w0, float2{s8, c8});
+                s2v[j] = cmul(tsum, wj);
+            }
+        }
+        bool nonfinite = false;
+        // ---- peak flags on bins 16 tq .. 16 tq + 15 (pv:95-116) ----
+        int lastown[16], firstown[16];
+        int last_in, first_in;
+        {
+            unsigned mg[20];
+            typedef const volatile __attribute__((address_space(3))) v2u *lds_v2u;
+            typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
+            const v2u q0 = *(lds_v2u)(&MAG[C::MAG0 + 20 * tq - 6]);        // bins 16 tq - 2, 16 tq - 1
+            const v4u q1 = *(lds_v4u)(&MAG[C::MAG0 + 20 * tq]);
+            const v4u q2 = *(lds_v4u)(&MAG[C::MAG0 + 20 * tq + 4]);
+            const v4u q3 = *(lds_v4u)(&MAG[C::MAG0 + 20 * tq + 8]);
+            const v4u q4 = *(lds_v4u)(&MAG[C::MAG0 + 20 * tq + 12]);
+            const v2u q5 = *(lds_v2u)(&MAG[C::MAG0 + 20 * tq + 20]);       // bins 16 tq + 16, 16 tq + 17
+            mg[0] = q0.x; mg[1] = q0.y;
+            mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w; mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w;
+            mg[10] = q3.x; mg[11] = q3.y; mg[12] = q3.z; mg[13] = q3.w; mg[14] = q4.x; mg[15] = q4.y; mg[16] = q4.z; mg[17] = q4.w;
+            mg[18] = q5.x; mg[19] = q5.y;
+            unsigned pm[19];
+#pragma unroll
+            for (int j = 3; j < 19; j++) pm[j] = max(mg[j], mg[j + 1]);
+            bool fl[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                // candidates are 2 <= k < H - 2 (pv:97-100): thread 0 drops i < 2, the last thread drops i = 15
+                const bool in_range = (i < 2) ? (tq != 0) : (i == 15) ? (tq != T - 1) : true;
+                fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
+            }
+            {
+                unsigned mx = mg[2];
+#pragma unroll
+                for (int j = 3; j < 19; j += 2) mx = max(mx, pm[j]);
+                nonfinite = __any(mx >= 0x7F800000u);                      // Inf / NaN magnitude in this wave's bins (see pv_wave_kernel.hip)
+            }
+            if (dbg) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) { p.dbg_flags[16 * tq + i] = fl[i] ? 1 : 0; p.dbg_mag[16 * tq + i] = __uint_as_float(mg[i + 2]); }
+                if (tq == T - 1) { p.dbg_flags[M] = 0; p.dbg_mag[M] = __uint_as_float(mg[18]); }
+            }
+            int pd[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const unsigned w = (i < 8) ? dq0[i >> 1] : dq1[(i - 8) >> 1];
+                pd[i] = (int)__builtin_amdgcn_perm((unsigned)(16 * tq + i), w, (i & 1) ? 0x05040302u : 0x05040100u);
+            }
+            int cur = NEGPD;
+#pragma unroll
+            for (int i = 0; i < 16; i++) { cur = fl[i] ? pd[i] : cur; lastown[i] = cur; }
+            int nx = POSPD;
+#pragma unroll
+            for (int i = 15; i >= 0; i--) { firstown[i] = nx; nx = fl[i] ? pd[i] : nx; }
+            last_in = cur; first_in = nx;
+        }
+        // ---- nearest peaks outside this thread's 16 bins: per-wave occupancy ballots + per-thread last / first peak, through LDS ----
+        {
+            const unsigned long long occ = __ballot(last_in >= 0);
+            LASTIN[tq] = last_in;
+            FIRSTIN[tq] = first_in;
+            if (l == 0) OCC[wv] = occ;
+        }
+        __syncthreads();                                                   // also: every MAG read is done -> ROUTE may overwrite MAG
+        int cprev = NEGPD, cnext = POSPD, last_peak = -1, last_shift = 0;
+        {
+            const unsigned long long mine = OCC[wv];
+            {
+                int srcT = -1;
+                const unsigned long long below = mine & ((1ull << l) - 1ull);
+                if (below) srcT = wv * 64 + 63 - __clzll((long long)below);
+                else
+                    for (int w = wv - 1; w >= 0; --w) { const unsigned long long o = OCC[w]; if (o) { srcT = w * 64 + 63 - __clzll((long long)o); break; } }
+                if (srcT >= 0) cprev = LASTIN[srcT];
+            }
+            {
+                int srcT = -1;
+                const unsigned long long above = (l == 63) ? 0ull : (mine >> (l + 1));
+                if (above) srcT = wv * 64 + l + __ffsll((long long)above);
+                else
+                    for (int w = wv + 1; w < 4; ++w) { const unsigned long long o = OCC[w]; if (o) { srcT = w * 64 + __ffsll((long long)o) - 1; break; } }
+                if (srcT >= 0) cnext = FIRSTIN[srcT];
+            }
+            for (int w = 3; w >= 0; --w) {
+                const unsigned long long o = OCC[w];
+                if (o) { const int lp = LASTIN[w * 64 + 63 - __clzll((long long)o)]; last_peak = lp >> 16; last_shift = (int)(short)(lp & 0xFFFF); break; }
+            }
+        }
+        {
+            unsigned rt[16];
+            unsigned rtM = NOROUTE;
+            bool bad = false;
+            if (last_peak < 0) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) rt[i] = NOROUTE;
+            } else {
+                auto route_of = [&](int b, int pp, int pn) -> unsigned {
+                    const int own = (b - (pp >> 16) < (pn >> 16) - b) ? pp : pn;     // owner rule (pv:132-141)
+                    const int delta = __builtin_amdgcn_sbfe(own, 0, 16);
+                    return __builtin_amdgcn_perm((unsigned)__mul24(delta, tmod), (unsigned)(b + delta), 0x05040100u);
+                };
+#pragma unroll
+                for (int i = 0; i < 16; i++) rt[i] = route_of(16 * tq + i, max(lastown[i], cprev), min(firstown[i], cnext));
+                if (tq == T - 1) rtM = route_of(M, max(last_in, cprev), POSPD);
+                if (!(pf >= 1.0)) {
+                    rtM &= 0x7FFFFFFFu;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int pp = max(lastown[i], cprev), pn = min(firstown[i], cnext), b = 16 * tq + i;
+                        const bool rising = !(b - (pp >> 16) < (pn >> 16) - b);
+                        rt[i] = (rt[i] & 0x7FFFFFFFu) | (rising ? 0x80000000u : 0u);
+                    }
+                    if (!(pfm >= PV_PAIRWISE_SURE)) {                       // (f >= 2/3: the test cannot fail, see pv_device_common.h)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const int pp = max(lastown[i], cprev), pn = min(firstown[i], cnext);
+                            const int gap = (pn >> 16) - (pp >> 16), ov = __builtin_amdgcn_sbfe(pp, 0, 16) - __builtin_amdgcn_sbfe(pn, 0, 16);
+                            bad |= ov > (gap >> 1);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) *reinterpret_cast<uint4 *>(&ROUTE[C::MAG0 + 20 * tq + 4 * j]) = uint4{rt[4 * j], rt[4 * j + 1], rt[4 * j + 2], rt[4 * j + 3]};
+            if (tq == T - 1) ROUTE[C::MAG0 + 5120] = rtM;
+            if (!(pf >= 1.0)) { const bool wbad = __any(bad); if (l == 0) BADW[wv] = wbad ? 1u : 0u; }
+        }
+        int upper_end = H;
+        if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
+        // ---- zero Y (pv:121) ----
+#pragma unroll
+        for (int r = 0; r < 8; r++) *reinterpret_cast<v4f *>(&Y[2 * tq + 2 * T * r]) = v4f{0.f, 0.f, 0.f, 0.f};
+        if (tq == 0) Y[M] = float2{0.f, 0.f};
+        const bool need_res = upper_end > H;
+        __syncthreads();
+        // ---- shiftPeaks (pv:119-173) ----
+        {
+            if (pf >= 1.0) {
+                auto scatter = [&](auto mode_tag) {
+                    constexpr int MODE = decltype(mode_tag)::value;
+                    auto rot = [&](unsigned rt, float2 v) -> float2 {
+                        if (MODE == 0) return v;
+                        if (MODE == 2) {
+                            const unsigned sg = (rt << (16 - LOG2N)) & 0x80000000u;
+                            return float2{__uint_as_float(__float_as_uint(v.x) ^ sg), __uint_as_float(__float_as_uint(v.y) ^ sg)};
+                        }
+                        return rotate_route<R, LOG2N>(rt, v, p.tw32);
+                    };
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const unsigned ra = ROUTE[C::MAG0 + pl + 320 * r], ta = ra & 0xFFFFu;
+                        const unsigned rb = ROUTE[C::MAG0 + 5120 - ql - 320 * r], tb = rb & 0xFFFFu;
+                        if (ta < (unsigned)H) Y[ta] = rot(ra, XA[r]);
+                        if (tb < (unsigned)H) Y[tb] = rot(rb, XB[r]);
+                    }
+                    if (tq == 0) { const unsigned rt = ROUTE[C::MAG0 + 2560], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, xHf); }
+                };
+                if (tmod == 0) scatter(std::integral_constant<int, 0>{});
+                else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
+                else scatter(std::integral_constant<int, 1>{});
+            } else {
+                // f < 1 (and NaN): regions compress, `+=` collisions (pv:169-170).  The sources go in TWO batches -- bins below M/2 (XA), then M/2 and the bins above
+                // (XB) -- so that the route / value / key arrays are half as long (the 17-wide form spills the f >= 1 path of the loop); ascending source order, the
+                // reference's order of accumulation (pv:122,146), is kept by finishing batch 0 before batch 1 starts.
+                bool pairwise = PV_PAIRWISE != 0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) pairwise = pairwise && (BADW[w] == 0u);        // uniform in the workgroup
+                auto gather = [&](auto half_tag, unsigned (&rt)[9], float2 (&ys)[9], int (&id)[9]) {
+                    constexpr int HALF = decltype(half_tag)::value;
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        if (HALF == 0) { id[r] = tq + T * r; rt[r] = ROUTE[C::MAG0 + pl + 320 * r]; ys[r] = rotate_route<R, LOG2N>(rt[r], XA[r], p.tw32); }
+                        else { id[r] = M - tq - T * r; rt[r] = ROUTE[C::MAG0 + 5120 - ql - 320 * r]; ys[r] = rotate_route<R, LOG2N>(rt[r], XB[r], p.tw32); }
+                    }
+                    if (HALF == 0) { id[8] = 0; rt[8] = NOROUTE; ys[8] = float2{0.f, 0.f}; }
+                    else { id[8] = M / 2; rt[8] = (tq == 0) ? ROUTE[C::MAG0 + 2560] : NOROUTE; ys[8] = rotate_route<R, LOG2N>(rt[8], xHf, p.tw32); }
+                };
+                if (pairwise) {
+                    // every collision is one falling-side source against one rising-side source: the falling side (and the residue, which continues the falling side of
+                    // the last peak) stores into the zeroed Y, one barrier, the rising side adds
+                    auto store_half = [&](auto half_tag) {
+                        unsigned rt[9]; float2 ys[9]; int id[9];
+                        gather(half_tag, rt, ys, id);
+#pragma unroll
+                        for (int r = 0; r < 9; r++) { const unsigned key = rt[r] & 0x8000FFFFu; if (key < (unsigned)H) Y[key] = ys[r]; }
+                    };
+                    store_half(std::integral_constant<int, 0>{});
+                    store_half(std::integral_constant<int, 1>{});
+                    const int up_delta = need_res ? last_shift : 0;
+                    const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+                    if (need_res && upper_end <= H + N / 8) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int b = H + tq + T * j, tgt = b + up_delta;
+                            const unsigned rtj = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+                            if (rtj != NOROUTE) Y[tgt] = rotate_route<R, LOG2N>(rtj, s2v[j], p.tw32);
+                            if (dbg && b < upper_end) { p.dbg_X[2 * b] = s2v[j].x; p.dbg_X[2 * b + 1] = s2v[j].y; }
+                        }
+                    }
+                    __syncthreads();
+                    auto add_half = [&](auto half_tag) {
+                        unsigned rt[9]; float2 ys[9]; int id[9];
+                        gather(half_tag, rt, ys, id);
+                        float2 o[9];
+#pragma unroll
+                        for (int r = 0; r < 9; r++) o[r] = Y[min(rt[r] & 0xFFFFu, (unsigned)M)];
+#pragma unroll
+                        for (int r = 0; r < 9; r++) { const unsigned key = rt[r] & 0x8000FFFFu; if (key - 0x80000000u < (unsigned)H) Y[key - 0x80000000u] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y}; }
+                    };
+                    add_half(std::integral_constant<int, 0>{});      // (a target takes at most one rising-side source: the two batches do not meet)
+                    add_half(std::integral_constant<int, 1>{});
+                } else {
+                    unsigned rt0[9], rt1[9]; float2 ys0[9], ys1[9]; int id0[9], id1[9];
+                    gather(std::integral_constant<int, 0>{}, rt0, ys0, id0);
+                    gather(std::integral_constant<int, 1>{}, rt1, ys1, id1);
+                    __syncthreads();                                        // every ROUTE read is done: the region becomes the claim words
+#pragma unroll
+                    for (int r = 0; r < 16; r++) CLAIM[tq + T * r] = 0xFFFFFFFFu;
+                    if (tq == 0) CLAIM[M] = 0xFFFFFFFFu;
+                    claim_rounds_wg16<9>(rt0, ys0, id0, Y, CLAIM);            // (its first barrier orders the fill before the first claims)
+                    claim_rounds_wg16<9>(rt1, ys1, id1, Y, CLAIM);
+                    if (need_res) {
+                        __syncthreads();
+                        const int up_delta = last_shift;
+                        const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
+                        if (upper_end <= H + N / 8) {
+                            unsigned rt2[4];
+                            float2 ys2[4];
+                            int id2[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int b = H + tq + T * j, tgt = b + up_delta;
+                                rt2[j] = (b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+                                ys2[j] = rotate_route<R, LOG2N>(rt2[j], s2v[j], p.tw32);
+                                id2[j] = b - N / 2;
+                                if (dbg && b < upper_end) { p.dbg_X[2 * b] = s2v[j].x; p.dbg_X[2 * b + 1] = s2v[j].y; }
+                            }
+                            claim_rounds_wg16<4>(rt2, ys2, id2, Y, CLAIM);
+                        }
+                    }
+                }
+                if (need_res && upper_end > H + N / 8) {
+                    __syncthreads();
+                    const int up_delta = last_shift;
+                    residue_scatter_wg16<R>(src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw32, tq, upper_end, up_delta,
+                                            (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1), dbg ? p.dbg_X : nullptr, pairwise);
+                }
+            }
+        }
+        if (nonfinite && l == 0) Y[1 + wv] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};   // the reference's frame is NaN: so is this one
+        __syncthreads();
+        if (dbg) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const int k = tq + T * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
+            if (tq == 0) { p.dbg_Y[2 * M] = Y[M].x; p.dbg_Y[2 * M + 1] = Y[M].y; }
+        }
+        // ---- c2r pre-pass in conjugate pairs, packed fp32 (see pv_wg_kernel.hip): thread tq computes k = tq + 256 r, r < 8, and hands Z[M - k] over through LDS ----
+        pk::c32 zi[16];
+        {
+            constexpr float sc = 2.0f / ((float)N * (float)R);                // 1/N of the inverse, 1/R of the overlap-add, 2 for the 0.5 * Hann table (exact)
+            const float2 wlf = cconj(p.tw32[tq]);
+            const pk::c32 wlfs{wlf.x * sc, wlf.y * sc};                       // c2r twiddle with the scale folded in
+            const pk::c32 scsc{sc, sc};
+            const pk::c32 *Yc = reinterpret_cast<const pk::c32 *>(Y);
+            pk::c32 zb[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = tq + T * r;
+                pk::c32 yk = Yc[k], ym = Yc[M - k];
+                if (k == 0) { yk.y = 0.f; ym.y = 0.f; }
+                const pk::c32 E = pk::add_conj(yk, ym), O = pk::sub_conj(yk, ym);
+                const pk::c32 c = pk::cmul(mul_w32_inv_pk16(O, r), wlfs);
+                zi[r] = pk::fma_addj(E, scsc, c);
+                zb[r] = pk::fma_conj_subj(E, scsc, c);
+            }
+            const pk::c32 yH = Yc[M / 2];
+            pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem + C::OFF_RESQ);   // hand-over buffer = the residue quarter buffer: element m = M - k, m in (8T, 16T), at m - 8T
+#pragma unroll
+            for (int r = 0; r < 8; r++) if (r > 0 || tq > 0) XCH[8 * T - tq - T * r] = zb[r];   // (tq = 0, r = 0) would be Z[M]: does not exist
+            __syncthreads();
+#pragma unroll
+            for (int r = 8; r < 16; r++) zi[r] = XCH[tq + T * (r - 8)];
+            if (tq == 0) zi[8] = pk::c32{2.0f * yH.x * sc, -2.0f * yH.y * sc};   // the self-paired bin M/2
+        }
+        // the inverse's cross-wave exchange writes [0, 32 KB) -- Y, whose reads all sit in front of the hand-over's barrier --, its in-wave exchange [32 KB, 64 KB) -- dead
+        // routes / claim words and the hand-over buffer, whose reads sit in front of the cross-wave exchange's barrier: no barrier here
+        int tqi = tq;
+        asm volatile("" : "+v"(tqi));                                      // a fresh copy: the addresses of this phase are not kept alive from the top of the frame
+        const int tsi = (tqi >> 4) + 16 * (tqi & 15);
+        {
+            // the window of the overlap-add below AND of the next frame's analysis (see the top of the loop): live from here to the next frame's first lines only
+#pragma unroll
+            for (int r = 0; r < 16; r++) hw[r] = *reinterpret_cast<const float2 *>(p.hann + N + 2 * (tsi + T * r));
+        }
+        const float2 f1 = cconj(p.tw32[(2 * tsi) & (N - 1)]), f2 = cconj(p.tw32[(4 * tsi) & (N - 1)]), f4 = cconj(p.tw32[(8 * tsi) & (N - 1)]), f8 = cconj(p.tw32[(16 * tsi) & (N - 1)]);
+        const TwAf twaf{pk::c32{f1.x, f1.y}, pk::c32{f2.x, f2.y}, pk::c32{f4.x, f4.y}, pk::c32{f8.x, f8.y}};
+        fft_wg16_inv_pk(zi, reinterpret_cast<pk::c32 *>(smem), twaf, TWBF, tqi);
+        // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
+        {
+            const bool emit_out = (m >= emit_v);
+            float2 fr[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)                                   // rounded to fp32 BEFORE the accumulation like the reference's Float32Array (pv:67)
+                fr[r] = float2{__fmul_rn(zi[r].x, hw[r].x), __fmul_rn(zi[r].y, hw[r].y)};
+#pragma unroll
+            for (int r = 0; r < S_ROWS; r++) {
+                const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
+                if (emit_out) {
+                    float *dst = outp + (long)m * HOP + 2 * tsi + 2 * T * r;
+                    if (vec_out) __builtin_nontemporal_store(v2f{o.x, o.y}, reinterpret_cast<v2f *>(dst));
+                    else { dst[0] = o.x; dst[1] = o.y; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < LROWS; r++) {
+                const int s = r + S_ROWS;
+                acc[r] = (s < LROWS) ? float2{acc[s].x + fr[s].x, acc[s].y + fr[s].y} : fr[s];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (chunk == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int r = 0; r < LROWS; r++) {
+            float *a = acc_out + (long)ch * L + 2 * ts + 2 * T * r;
+            a[0] = acc[r].x; a[1] = acc[r].y;
+            // the next call's history = rows S_ROWS..15 of the last frame's window = raw[0 .. 16 - S_ROWS) after the slide: from registers
+            float *hs = hist_out + (long)ch * L + 2 * ts + 2 * T * r;
+            hs[0] = raw[r].x; hs[1] = raw[r].y;
+        }
+    }
+    pv_signal_done<true>(p.done, done_seq, (long)ch * gridDim.x + chunk);
+    if (RESIDENT) goto resident_top;
+}
+
+template <int S_ROWS, bool AUX>
+hipError_t launch_wg16(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+{
+    static std::atomic<bool> attr_done[16];
+    auto k = pv_wg16_kernel<S_ROWS, AUX>;
+    {
+        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), QC::LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(nchunks, nch, 1), dim3(QC::T, 1, 1), QC::LDS_BYTES, st, p);
+    return hipGetLastError();
+}
+
+template <int S_ROWS>
+hipError_t launch_wg16_resident(const PvKernelParams &p, int nslots, hipStream_t st)
+{
+    static std::atomic<bool> attr_done[16];
+    auto k = pv_wg16_kernel<S_ROWS, false, true>;
+    {
+        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), QC::LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    PvKernelParams q = p;
+    q.nchunks = 1; q.nch = nslots; q.nhops = 1; q.frames_per_chunk = 1;
+    hipLaunchKernelGGL(k, dim3(1, nslots, 1), dim3(QC::T, 1, 1), QC::LDS_BYTES, st, q);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool pv_wg16_supported(int log2n, int hop) { return log2n == 13 && (hop == 1024 || hop == 2048 || hop == 4096 || hop == 8192); }
+size_t pv_wg16_lds_bytes() { return QC::LDS_BYTES; }
+int pv_wg16_threads() { return QC::T; }
+
+hipError_t pv_launch_wg16(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+{
+    const bool aux = (p.dbg_mag != nullptr);
+    switch (p.hop) {
+    case 1024: return aux ? launch_wg16<2, true>(p, nch, nchunks, st) : launch_wg16<2, false>(p, nch, nchunks, st);
+    case 2048: return aux ? launch_wg16<4, true>(p, nch, nchunks, st) : launch_wg16<4, false>(p, nch, nchunks, st);
+    case 4096: return aux ? launch_wg16<8, true>(p, nch, nchunks, st) : launch_wg16<8, false>(p, nch, nchunks, st);
+    case 8192: return aux ? launch_wg16<16, true>(p, nch, nchunks, st) : launch_wg16<16, false>(p, nch, nchunks, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t pv_launch_wg16_resident(const PvKernelParams &p, int nslots, hipStream_t st)
+{
+    switch (p.hop) {
+    case 1024: return launch_wg16_resident<2>(p, nslots, st);
+    case 2048: return launch_wg16_resident<4>(p, nslots, st);
+    case 4096: return launch_wg16_resident<8>(p, nslots, st);
+    case 8192: return launch_wg16_resident<16>(p, nslots, st);
+    default: return hipErrorInvalidValue;
+    }
+}
