@@ -31,6 +31,18 @@
 
 namespace {
 
+// wave priority per phase (pv_wave_fft.h has the story): the SIMD's two waves belong to DIFFERENT workgroups; the latency chains between the transforms (short LDS
+// round trips behind barriers) run above the arithmetic of the transforms, whose exchanges are lowest.  PV_WG16_PT = fwd arithmetic, fwd exchanges, middle, inverse
+// arithmetic, inverse exchanges, overlap-add; 9 = leave unchanged.
+#ifndef PV_WG16_PT
+#define PV_WG16_PT 2, 0, 3, 1, 0, 3
+#endif
+template <int PH> __device__ __forceinline__ void wg16_prio()
+{
+    constexpr int t[] = {PV_WG16_PT};
+    if constexpr (t[PH] <= 3) __builtin_amdgcn_s_setprio(t[PH]);
+}
+
 struct QC {
     static constexpr int T = 256, M = 4096, N = 8192, H = 4097, LOG2N = 13;
     // inside the scratch, between the two FFTs:
@@ -147,14 +159,17 @@ __device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA
     // exchange inside the groups of 16 lanes: [reg k0][lane n1] -> [reg n1][lane k0]; element (k0, n1) of group g at 256 g + 16 k0 + (n1 ^ k0)
     const int c = t & 15, g = t >> 4;
     double2 *Sg = S + 256 * g;
+    wg16_prio<1>();
 #pragma unroll
     for (int k = 0; k < 16; k++) Sg[16 * k + (c ^ k)] = a[k];
     wave_sync();                                                        // the 16 lanes of a group sit in one wave: LDS traffic of a wave executes in order
 #pragma unroll
     for (int n = 0; n < 16; n++) a[n] = Sg[16 * c + (n ^ c)];
+    wg16_prio<0>();
     radix16_fwd(a);
 #pragma unroll
     for (int k = 1; k < 16; k++) a[k] = dmul(a[k], TWB[(k - 1) * 16 + g]);
+    wg16_prio<1>();
     __syncthreads();                                                    // every wave is done with its in-wave exchange: the rows below overwrite other waves' groups
 #pragma unroll
     for (int k = 0; k < 16; k++) S[256 * k + t] = a[k];                 // [reg k1][thread (n0, k0)]
@@ -162,6 +177,7 @@ __device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA
 #pragma unroll
     for (int n = 0; n < 16; n++) a[n] = S[256 * g + 16 * n + c];        // thread t = k0 + 16 k1 takes (k1 = g, n0 = n, k0 = c)
     __syncthreads();                                                    // the scratch is free again
+    wg16_prio<0>();
     radix16_fwd(a);
 }
 
@@ -172,21 +188,26 @@ struct TwAf { pk::c32 w1, w2, w4, w8; };
 __device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, const TwAf &tw, const pk::c32 *TWBF, int t)
 {
     const int c = t & 15, g = t >> 4;
+    wg16_prio<3>();
     radix16_inv_pk(a);
+    wg16_prio<4>();
 #pragma unroll
     for (int n = 0; n < 16; n++) S[256 * g + 16 * n + c] = a[n];        // thread (k1 = g, k0 = c), reg n0 = n
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) a[k] = S[256 * k + t];                 // thread (n0 = g, k0 = c), reg k1
+    wg16_prio<3>();
 #pragma unroll
     for (int k = 1; k < 16; k++) a[k] = pk::cmul(a[k], TWBF[(k - 1) * 16 + g]);
     radix16_inv_pk(a);
     pk::c32 *Sg = S + 4096 + 256 * g;                                   // second half of the scratch (fp32 elements are half the size)
+    wg16_prio<4>();
 #pragma unroll
     for (int n = 0; n < 16; n++) Sg[16 * c + (n ^ c)] = a[n];           // thread (n0, k0 = c), reg n1 = n
     wave_sync();
 #pragma unroll
     for (int k = 0; k < 16; k++) a[k] = Sg[16 * k + (c ^ k)];           // thread (n0, n1 = c), reg k0
+    wg16_prio<3>();
     {
         const pk::c32 w3 = pk::cmul(tw.w1, tw.w2), w5 = pk::cmul(tw.w4, tw.w1), w6 = pk::cmul(tw.w4, tw.w2), w7 = pk::cmul(tw.w4, w3);
         a[1] = pk::cmul(a[1], tw.w1); a[2] = pk::cmul(a[2], tw.w2); a[3] = pk::cmul(a[3], w3); a[4] = pk::cmul(a[4], tw.w4);
@@ -463,6 +484,7 @@ resident_top:
         const TwA twa{p.tw64[(2 * tsq) & (N - 1)], p.tw64[(4 * tsq) & (N - 1)], p.tw64[(8 * tsq) & (N - 1)], p.tw64[(16 * tsq) & (N - 1)]};   // W_4096^{ts k}, k = 1, 2, 4, 8
         const double2 wl = p.tw64[tq];                                      // split pass: W_N^{tq + 256 r} = wl * W_32^r
         // ---- Hann (pv:55), pack, forward FFT in fp64 (the split pass's 1/2 is folded into the window, exact) ----
+        wg16_prio<0>();
         double2 z[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) z[r] = double2{(double)(raw[r].x * hw[r].x), (double)(raw[r].y * hw[r].y)};
@@ -478,6 +500,7 @@ resident_top:
         // ---- split pass in conjugate pairs: thread tq owns the pairs k = tq + 256 r, r < 8: XA[r] = X[k], XB[r] = X[M - k]; thread 0 also the self-paired bin M/2.
         //      The partner values Z[M - k] are rows 8..15 of other threads -> LDS ----
         float2 XA[8], XB[8], xHf{0.f, 0.f};
+        wg16_prio<2>();
         {
 #pragma unroll
             for (int r = 8; r < 16; r++) S64[tq + T * (r - 8)] = z[r];
@@ -689,6 +712,7 @@ resident_top:
         }
         int upper_end = H;
         if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
+        const float2 wlf = cconj(p.tw32[tq]);                               // c2r twiddle e^{+2 pi j tq / N}: loaded a phase ahead of its use
         // ---- zero Y (pv:121) ----
 #pragma unroll
         for (int r = 0; r < 8; r++) *reinterpret_cast<v4f *>(&Y[2 * tq + 2 * T * r]) = v4f{0.f, 0.f, 0.f, 0.f};
@@ -820,7 +844,6 @@ resident_top:
         pk::c32 zi[16];
         {
             constexpr float sc = 2.0f / ((float)N * (float)R);                // 1/N of the inverse, 1/R of the overlap-add, 2 for the 0.5 * Hann table (exact)
-            const float2 wlf = cconj(p.tw32[tq]);
             const pk::c32 wlfs{wlf.x * sc, wlf.y * sc};                       // c2r twiddle with the scale folded in
             const pk::c32 scsc{sc, sc};
             const pk::c32 *Yc = reinterpret_cast<const pk::c32 *>(Y);
@@ -858,6 +881,7 @@ resident_top:
         const TwAf twaf{pk::c32{f1.x, f1.y}, pk::c32{f2.x, f2.y}, pk::c32{f4.x, f4.y}, pk::c32{f8.x, f8.y}};
         fft_wg16_inv_pk(zi, reinterpret_cast<pk::c32 *>(smem), twaf, TWBF, tqi);
         // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
+        wg16_prio<5>();
         {
             const bool emit_out = (m >= emit_v);
             float2 fr[16];
