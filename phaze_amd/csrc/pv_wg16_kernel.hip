@@ -35,7 +35,7 @@ namespace {
 // round trips behind barriers) run above the arithmetic of the transforms, whose exchanges are lowest.  PV_WG16_PT = fwd arithmetic, fwd exchanges, middle, inverse
 // arithmetic, inverse exchanges, overlap-add; 9 = leave unchanged.
 #ifndef PV_WG16_PT
-#define PV_WG16_PT 2, 0, 3, 1, 0, 3
+#define PV_WG16_PT 2, 0, 3, 1, 0, 2
 #endif
 template <int PH> __device__ __forceinline__ void wg16_prio()
 {
@@ -353,7 +353,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(co
 // S_ROWS = hop / 512 in {2, 4, 8, 16}: the frame advances by whole register rows (512 samples), overlap-add accumulator and input window live in registers.
 // AUX: test-tap instance.  RESIDENT: streaming instance that stays on the GPU (see pv_wg_kernel.hip).
 template <int S_ROWS, bool AUX, bool RESIDENT = false>
-__global__ __launch_bounds__(256, 2) PV_NO_DS_MERGE void pv_wg16_kernel(const PvKernelParams p)
+__global__ __launch_bounds__(256, RESIDENT ? 1 : 2) PV_NO_DS_MERGE void pv_wg16_kernel(const PvKernelParams p)
 {
     using C = QC;
     constexpr int N = C::N, M = C::M, H = C::H, T = C::T, LOG2N = C::LOG2N;
@@ -764,14 +764,12 @@ resident_top:
                 if (pairwise) {
                     // every collision is one falling-side source against one rising-side source: the falling side (and the residue, which continues the falling side of
                     // the last peak) stores into the zeroed Y, one barrier, the rising side adds
-                    auto store_half = [&](auto half_tag) {
-                        unsigned rt[9]; float2 ys[9]; int id[9];
-                        gather(half_tag, rt, ys, id);
+                    unsigned rt0[9], rt1[9]; float2 ys0[9], ys1[9];
+                    { int id[9]; gather(std::integral_constant<int, 0>{}, rt0, ys0, id); gather(std::integral_constant<int, 1>{}, rt1, ys1, id); }
 #pragma unroll
-                        for (int r = 0; r < 9; r++) { const unsigned key = rt[r] & 0x8000FFFFu; if (key < (unsigned)H) Y[key] = ys[r]; }
-                    };
-                    store_half(std::integral_constant<int, 0>{});
-                    store_half(std::integral_constant<int, 1>{});
+                    for (int r = 0; r < 8; r++) { const unsigned key = rt0[r] & 0x8000FFFFu; if (key < (unsigned)H) Y[key] = ys0[r]; }
+#pragma unroll
+                    for (int r = 0; r < 9; r++) { const unsigned key = rt1[r] & 0x8000FFFFu; if (key < (unsigned)H) Y[key] = ys1[r]; }
                     const int up_delta = need_res ? last_shift : 0;
                     const unsigned up_ridx = (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1);
                     if (need_res && upper_end <= H + N / 8) {
@@ -784,17 +782,15 @@ resident_top:
                         }
                     }
                     __syncthreads();
-                    auto add_half = [&](auto half_tag) {
-                        unsigned rt[9]; float2 ys[9]; int id[9];
-                        gather(half_tag, rt, ys, id);
+                    auto add_half = [&](const unsigned (&rt)[9], const float2 (&ys)[9]) {     // (two batches of reads: the 17-wide form spills the f >= 1 path of the loop)
                         float2 o[9];
 #pragma unroll
                         for (int r = 0; r < 9; r++) o[r] = Y[min(rt[r] & 0xFFFFu, (unsigned)M)];
 #pragma unroll
                         for (int r = 0; r < 9; r++) { const unsigned key = rt[r] & 0x8000FFFFu; if (key - 0x80000000u < (unsigned)H) Y[key - 0x80000000u] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y}; }
                     };
-                    add_half(std::integral_constant<int, 0>{});      // (a target takes at most one rising-side source: the two batches do not meet)
-                    add_half(std::integral_constant<int, 1>{});
+                    add_half(rt0, ys0);                                  // (a target takes at most one rising-side source: the two batches do not meet)
+                    add_half(rt1, ys1);
                 } else {
                     unsigned rt0[9], rt1[9]; float2 ys0[9], ys1[9]; int id0[9], id1[9];
                     gather(std::integral_constant<int, 0>{}, rt0, ys0, id0);
