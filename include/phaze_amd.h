@@ -73,8 +73,8 @@ enum {
     PV_FLAG_GENERIC_KERNEL = 1, /* always launch the LDS-staged fallback kernel (pv_chain_kernel)        */
     PV_FLAG_STREAM_COPY = 2,    /* streaming quantum through H2D + kernel + D2H copies instead of the
                                  * zero-copy mapping of the pinned staging buffer                         */
-    PV_FLAG_WORKGROUP_KERNEL = 4, /* N = 2048 / 4096: the workgroup-per-frame kernel (pv_wg_kernel) instead of the
-                                  * one-wave (pv_wave2k_kernel) / wave-pair (pv_pair_kernel) kernels      */
+    PV_FLAG_WORKGROUP_KERNEL = 4, /* N = 2048 / 4096 / 8192: the eight-element workgroup kernel (pv_wg_kernel) instead of the
+                                  * one-wave (pv_wave2k_kernel) / sixteen-element (pv_wg16_kernel) kernels */
     PV_FLAG_STREAM_EVENT_WAIT = 8, /* streaming quantum: wait through hipStreamSynchronize (round-2 behaviour).  Default since round 3: every
                                   * frame chain stores a sequence number into pinned host memory when its output is written and pv_process /
                                   * pv_process_end spin on those words (bounded; falls back to the stream wait) -- the runtime's completion
@@ -109,9 +109,10 @@ typedef struct pv_info {
     int32_t compute_units, device_id;
     char device_name[64];
     char kernel_name[32];    /* "pv_wave_kernel_1024" (N = 1024, hop in {128,256,512,1024}), "pv_wave2k_kernel" (N = 2048, hop in
-                              * {128,256,512,1024,2048}: one wave per frame), "pv_pair_kernel" (N = 4096, hop in {512,1024,2048,
-                              * 4096}: a pair of waves per frame), "pv_wg_kernel" (N = 8192, and N >= 2048 with smaller even hops
-                              * that fit LDS: a workgroup per frame) or "pv_chain_kernel" (everything else / PV_FLAG_GENERIC_KERNEL) */
+                              * {128,256,512,1024,2048}: one wave per frame), "pv_wg16_kernel" (N = 4096 / 8192, hop in {N/8, N/4, N/2,
+                              * N}: two / four waves per frame, sixteen elements per thread), "pv_wg_kernel" (N >= 2048 with smaller even
+                              * hops that fit LDS, and PV_FLAG_WORKGROUP_KERNEL: a workgroup per frame, eight elements per thread) or
+                              * "pv_chain_kernel" (everything else / PV_FLAG_GENERIC_KERNEL) */
 } pv_info;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */

@@ -76,7 +76,7 @@ struct pv_handle {
     bool use_wave;                               // N = 1024: wave-per-frame kernel (pv_wave_kernel.hip)
     bool use_wg;                                 // N = 2048..8192, R <= 8: register-resident workgroup kernel (pv_wg_kernel.hip)
     bool use_wave2k;                             // N = 2048, hop 128..2048: one wave per frame (pv_wave2k_kernel.hip)
-    bool use_pair;                               // N = 4096, hop 512..4096: a pair of waves per frame (pv_pair_kernel.hip)
+    bool use_wg16;                               // N = 4096 / 8192, hop N/8..N: sixteen elements per thread, N/32 threads per frame chain (pv_wg16_kernel.hip); implies use_wg
     char devname[64];
     char err[256];
 };
@@ -117,9 +117,8 @@ int pick_frames_per_chunk(const pv_handle *h, int nch, int nhops)
     // resident = chains the GPU runs concurrently (wave kernels: one per wave; others: LDS-limited workgroups per CU).
     long per_cu;
     if (h->use_wave2k) per_cu = pv_wave2k_threads() / 64;
-    else if (h->use_pair) per_cu = (160 * 1024) / (long)pv_pair_lds_bytes();
     else if (h->use_wave) per_cu = pv_wave_threads() / 64;
-    else if (h->use_wg) { per_cu = (160 * 1024) / (long)pv_wg_lds_bytes(h->log2n, h->hop); if (per_cu < 1) per_cu = 1; }
+    else if (h->use_wg) { per_cu = (160 * 1024) / (long)(pv_wg_lds_bytes(h->log2n, h->hop, !h->use_wg16) + 256); if (per_cu < 1) per_cu = 1; }   // (+ 256 static bytes: __syncthreads_or)
     else { per_cu = (160 * 1024) / (long)pv_kernel_lds_bytes(h->log2n, h->hop); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1; }
     const long resident = per_cu * h->cus;
     const int R = h->R;
@@ -177,8 +176,6 @@ int launch_chain(pv_handle *h, const float *d_in, float *d_out, int ch0, int nch
     hipError_t e = hipSuccess;
     if (h->use_wave2k) {                                         // (pv_debug_frame runs the tap instance of the kernel the handle uses)
         e = pv_launch_wave2k(p, nch, nchunks, h->stream);
-    } else if (h->use_pair) {
-        e = pv_launch_pair(p, nch, nchunks, h->stream);
     } else {
         if (!h->use_wave && nch > 65535) return fail(h, PV_ERR_CAPACITY, "more than 65535 channel slots in one launch (grid.y limit): split the call");
         unsigned *list = nullptr;
@@ -196,7 +193,7 @@ int launch_chain(pv_handle *h, const float *d_in, float *d_out, int ch0, int nch
             list = h->d_chain_list;
         }
         e = h->use_wave ? pv_launch_wave(p, nch, nchunks, h->stream, spread, list)
-          : h->use_wg ? pv_launch_wg(h->log2n, p, nch, nchunks, h->stream)
+          : h->use_wg ? pv_launch_wg(h->log2n, p, nch, nchunks, h->stream, !h->use_wg16)
                       : pv_launch_chain(h->log2n, p, nch, nchunks, h->stream);
     }
     if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
@@ -286,7 +283,7 @@ int resident_start(pv_handle *h, unsigned last_seq)
     resident_publish(h, h->h_ctl + 4, 0u);
     // stale completion words must not match a future 16-bit sequence number (a slot unused for exactly 65535 quanta)
     for (int c = 0; c < h->max_channels; c++) h->h_done[c] = 0u;
-    const hipError_t e = h->resident_wg ? pv_launch_wg_resident(h->log2n, p, h->max_channels, h->stream)
+    const hipError_t e = h->resident_wg ? pv_launch_wg_resident(h->log2n, p, h->max_channels, h->stream, !h->use_wg16)
                        : h->use_wave2k ? pv_launch_wave2k_resident(p, h->max_channels, h->stream) : pv_launch_wave_resident(p, h->max_channels, h->stream);
     if (e != hipSuccess) return fail_hip(h, e, "resident kernel launch");
     h->resident_on = true;
@@ -368,9 +365,9 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         const bool generic = (cfg->flags & PV_FLAG_GENERIC_KERNEL) != 0;      // explicit A/B switch (tests, measurements); no environment is read
         h->use_wave = pv_wave_supported(log2n, hop) && !generic;
         h->use_wg = pv_wg_supported(log2n, hop) && !generic;
-        const bool wg_only = (cfg->flags & PV_FLAG_WORKGROUP_KERNEL) != 0;    // A/B: the workgroup kernel where a one-wave / wave-pair kernel exists
+        const bool wg_only = (cfg->flags & PV_FLAG_WORKGROUP_KERNEL) != 0;    // A/B: the eight-element workgroup kernel where a one-wave / sixteen-element kernel exists
         h->use_wave2k = h->use_wg && !wg_only && pv_wave2k_supported(log2n, hop);
-        h->use_pair = h->use_wg && !wg_only && pv_pair_supported(log2n, hop);
+        h->use_wg16 = h->use_wg && !wg_only && pv_wg16_supported(log2n, hop);
     }
 
 #define CHK(call)                                                          \
@@ -461,7 +458,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         if (hipHostGetDevicePointer(&dd, hd, 0) == hipSuccess) h->d_done = (unsigned *)dd;
         (void)hipGetLastError();
         if (h->d_done && (cfg->flags & PV_FLAG_PERSISTENT_STREAM) && maxch <= 64 &&
-            (h->use_wave || h->use_wave2k || (h->use_wg && !h->use_pair && pv_wg_resident_supported(log2n, hop)))) {
+            (h->use_wave || h->use_wave2k || (h->use_wg && pv_wg_resident_supported(log2n, hop)))) {
             // Control block: in DEVICE memory when the host can write it through the BAR and the largest quantum is small enough to travel the same
             // way -- the waves then poll their own HBM and find the input there too, the only PCIe traffic of a quantum being posted writes in both
             // directions (tools/bar_probe.hip: 1 KB handed over and acknowledged in 3.5 us, 7.2 us with the block and the input in pinned host memory)
@@ -533,11 +530,11 @@ int pv_get_info(const pv_handle *h, pv_info *out)
     memset(out, 0, sizeof *out);
     out->fft_size = h->N; out->hop_size = h->hop; out->overlaps = h->R;
     out->max_channels = h->max_channels; out->max_hops = h->max_hops;
-    out->threads_per_workgroup = h->use_wave ? pv_wave_threads() : h->use_wave2k ? pv_wave2k_threads() : h->use_pair ? pv_pair_threads() : h->use_wg ? pv_wg_threads(h->log2n) : pv_kernel_threads(h->log2n);
+    out->threads_per_workgroup = h->use_wave ? pv_wave_threads() : h->use_wave2k ? pv_wave2k_threads() : h->use_wg ? pv_wg_threads(h->log2n, h->hop, !h->use_wg16) : pv_kernel_threads(h->log2n);
     snprintf(out->kernel_name, sizeof out->kernel_name, "%s",
-             h->use_wave ? "pv_wave_kernel_1024" : h->use_wave2k ? "pv_wave2k_kernel" : h->use_pair ? "pv_pair_kernel" : h->use_wg ? "pv_wg_kernel" : "pv_chain_kernel");
-    out->lds_bytes_per_workgroup = (int32_t)(h->use_wave ? pv_wave_lds_bytes() : h->use_wave2k ? pv_wave2k_lds_bytes() : h->use_pair ? pv_pair_lds_bytes()
-                                             : h->use_wg ? pv_wg_lds_bytes(h->log2n, h->hop) : pv_kernel_lds_bytes(h->log2n, h->hop));
+             h->use_wave ? "pv_wave_kernel_1024" : h->use_wave2k ? "pv_wave2k_kernel" : h->use_wg16 ? "pv_wg16_kernel" : h->use_wg ? "pv_wg_kernel" : "pv_chain_kernel");
+    out->lds_bytes_per_workgroup = (int32_t)(h->use_wave ? pv_wave_lds_bytes() : h->use_wave2k ? pv_wave2k_lds_bytes()
+                                             : h->use_wg ? pv_wg_lds_bytes(h->log2n, h->hop, !h->use_wg16) : pv_kernel_lds_bytes(h->log2n, h->hop));
     out->frames_per_chunk = h->last_frames_per_chunk;
     out->compute_units = h->cus; out->device_id = h->device;
     snprintf(out->device_name, sizeof out->device_name, "%s", h->devname);

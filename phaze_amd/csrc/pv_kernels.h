@@ -76,7 +76,7 @@ hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStre
 hipError_t pv_launch_wave_resident(const PvKernelParams &p, int nslots, hipStream_t st);
 hipError_t pv_launch_wave2k_resident(const PvKernelParams &p, int nslots, hipStream_t st);
 bool pv_wg_resident_supported(int log2n, int hop);
-hipError_t pv_launch_wg_resident(int log2n, const PvKernelParams &p, int nslots, hipStream_t st);
+hipError_t pv_launch_wg_resident(int log2n, const PvKernelParams &p, int nslots, hipStream_t st, bool wg8);
 
 // one wavefront per 2048-point frame (pv_wave2k_kernel.hip): N = 2048, hop in {128, 256, 512, 1024, 2048}, every pitchFactor
 bool pv_wave2k_supported(int log2n, int hop);
@@ -86,19 +86,15 @@ hipError_t pv_launch_wave2k(const PvKernelParams &p, int nch, int nchunks, hipSt
 
 // register-resident workgroup kernel for N = 2048..8192, hop in {N/8, N/4, N/2, N} (pv_wg_kernel.hip)
 bool pv_wg_supported(int log2n, int hop);
-size_t pv_wg_lds_bytes(int log2n, int hop);
-int pv_wg_threads(int log2n);
-hipError_t pv_launch_wg(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
+size_t pv_wg_lds_bytes(int log2n, int hop, bool wg8);
+int pv_wg_threads(int log2n, int hop, bool wg8);
+hipError_t pv_launch_wg(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st, bool wg8);   // wg8: the eight-element kernel also where pv_wg16_kernel exists
 
-// four waves, sixteen elements per thread, two workgroups per CU: N = 8192, hop in {N/8, N/4, N/2, N} (pv_wg16_kernel.hip); dispatched by pv_launch_wg / pv_launch_wg_resident
+// sixteen elements per thread, N / 32 threads: N = 8192 (four waves, two workgroups per CU) and N = 4096 (two waves, four workgroups per CU), hop in {N/8, N/4, N/2, N}
+// (pv_wg16_kernel.hip); dispatched by pv_launch_wg / pv_launch_wg_resident
 bool pv_wg16_supported(int log2n, int hop);
-size_t pv_wg16_lds_bytes();
-int pv_wg16_threads();
-hipError_t pv_launch_wg16(const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
+size_t pv_wg16_lds_bytes(int log2n);
+int pv_wg16_threads(int log2n);
+hipError_t pv_launch_wg16(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
 hipError_t pv_launch_wg16_resident(const PvKernelParams &p, int nslots, hipStream_t st);
 
-// wave-pair-per-frame kernel for N = 4096 (pv_pair_kernel.hip)
-bool pv_pair_supported(int log2n, int hop);
-size_t pv_pair_lds_bytes();
-int pv_pair_threads();
-hipError_t pv_launch_pair(const PvKernelParams &p, int nch, int nchunks, hipStream_t st);

@@ -43,26 +43,34 @@ template <int PH> __device__ __forceinline__ void wg16_prio()
     if constexpr (t[PH] <= 3) __builtin_amdgcn_s_setprio(t[PH]);
 }
 
+template <int LOG2N_>
 struct QC {
-    static constexpr int T = 256, M = 4096, N = 8192, H = 4097, LOG2N = 13;
+    static constexpr int LOG2N = LOG2N_, N = 1 << LOG2N_, M = N / 2, H = M + 1, T = M / 16;    // T = 256 (N = 8192) or 128 (N = 4096) threads, 16 elements each
+    static constexpr int K2 = T / 16;                     // radix of pass C: M = 16 * 16 * K2
+    static constexpr int NW = T / 64;                     // waves
+    static constexpr int PR = 5 * T / 4, PM = 5 * M / 4;  // padded layout P(bin) = bin + 4 (bin >> 4): P(t + T r) = pl + PR r, P(M - t - T r) = PM - ql - PR r, P(M) = PM, P(M/2) = PM / 2
     // inside the scratch, between the two FFTs:
     static constexpr int OFF_Y = 0;                       // float2[H]                 | fp32 spectrum stash (f < 1) before Y is zeroed
     static constexpr int MAG0 = 8;                        // magnitudes / routes start 8 words in (bins -2, -1 of thread 0's window stay inside)
-    static constexpr int OFF_ROUTE = 32784;               // u32 routes | f32 mags, both in the padded layout P(bin) = bin + 4 (bin >> 4) (pv_wave2k_kernel.hip) | u32 claim words [H] (plain)
-    static constexpr int ROUTE_WORDS = MAG0 + 5120 + 8;   // P(4096) = 5120
-    static constexpr int OFF_RESQ = 49184;                // float2[N / 4] one residue quarter | c2r hand-over
-    static constexpr int SCRATCH = OFF_RESQ + 16384;      // 65568
-    static_assert(8 * H <= OFF_ROUTE, "Y runs into the routes");
-    static_assert(OFF_ROUTE + 4 * ROUTE_WORDS <= SCRATCH && OFF_ROUTE + 4 * H <= OFF_RESQ, "routes / claim words");
+    static constexpr int OFF_ROUTE = ((8 * H + 15) / 16) * 16;   // u32 routes | f32 mags, both padded (pv_wave2k_kernel.hip) | u32 claim words [H] (plain)
+    static constexpr int ROUTE_WORDS = MAG0 + PM + 8;
+    static constexpr int OFF_RESQ = ((OFF_ROUTE + 4 * H + 15) / 16) * 16;   // float2[N / 4] one residue quarter | c2r hand-over
+    static constexpr int SCRATCH = OFF_RESQ + 2 * N;      // 65568 / 32800
+    static_assert(OFF_ROUTE + 4 * ROUTE_WORDS <= SCRATCH && 16 * M <= SCRATCH, "routes / the fp64 exchange");
     static_assert(OFF_ROUTE >= 16 * 8 * T, "MAG must not alias the partner rows of the split pass");
+    // i32 LASTIN[T], FIRSTIN[T].  N = 4096: inside the quarter buffer, behind the tail of the padded magnitudes (free between the end of the previous frame's inverse and
+    // this frame's scatter / c2r hand-over) -- behind the scratch they are the 1 KB that costs the fourth workgroup of the CU; N = 8192 keeps them behind the scratch
+    // (measured: the pitch sweep 2 % faster that way)
+    static constexpr bool NEAR_IN = (LOG2N_ == 12);
+    static constexpr int OFF_NEAR = NEAR_IN ? OFF_RESQ + N : SCRATCH;
+    static_assert(!NEAR_IN || (OFF_NEAR >= OFF_ROUTE + 4 * ROUTE_WORDS && OFF_NEAR + 8 * T <= SCRATCH), "LASTIN / FIRSTIN");
     // after the scratch:
-    static constexpr int OFF_NEAR = SCRATCH;              // i32 LASTIN[T], FIRSTIN[T]
-    static constexpr int OFF_OCC = OFF_NEAR + 8 * T;      // u64[4] occupancy | u32[4] "a gap fails the pairwise test" | broadcast word (resident)
-    static constexpr int OFF_TWB = OFF_OCC + 64;          // double2[15][16]  W_256^{n0 k1}, k1 = 1..15
-    static constexpr int OFF_TWBF = OFF_TWB + 16 * 15 * 16;   // float2[15][16] conj, fp32
-    static constexpr int OFF_XQ = OFF_TWBF + 8 * 15 * 16; // f32[N / 4] windowed samples xw[4n + 2] of the frame (f < 0.75): base stage of the general residue
-    static constexpr int LDS_BYTES = OFF_XQ + N;          // 81632: two workgroups per CU
-    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    static constexpr int OFF_OCC = SCRATCH + (NEAR_IN ? 0 : 8 * T);               // u64[4] occupancy | u32[4] "a gap fails the pairwise test" | broadcast word (resident)
+    static constexpr int OFF_TWB = OFF_OCC + 64;          // double2[15][K2]  W_{M/16}^{n0 k1}, k1 = 1..15
+    static constexpr int OFF_TWBF = OFF_TWB + 16 * 15 * K2;   // float2[15][K2] conj, fp32
+    static constexpr int OFF_XQ = OFF_TWBF + 8 * 15 * K2;   // f32[N / 4] windowed samples xw[4n + 2] of the frame (f < 0.75): base stage of the general residue
+    static constexpr int LDS_BYTES = OFF_XQ + N;          // 81632 (two workgroups per CU) / 39840 (four)
+    static_assert((LDS_BYTES + 256 + 511) / 512 * 512 * (512 / T) <= 160 * 1024, "workgroups per CU (256 static bytes: __syncthreads_or)");
 };
 
 // ---- radix-16 butterflies, natural order in and out: X[q + 4 p] = sum_j W4^{j p} ( W16^{j q} sum_m a[j + 4 m] W4^{m q} ) ----
@@ -146,6 +154,7 @@ struct TwA { double2 w1, w2, w4, w8; };
 
 // M = 4096-point complex FFT across the workgroup: in  thread t, reg r <-> element ts + 256 r (ts = (t >> 4) + 16 (t & 15)),
 //                                                     out thread t, reg r <-> bin t + 256 r.  S: the 64 KB scratch.
+template <int T_>
 __device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA &tw, const double2 *TWB, int t)
 {
     radix16_fwd(a);
@@ -167,40 +176,68 @@ __device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA
     for (int n = 0; n < 16; n++) a[n] = Sg[16 * c + (n ^ c)];
     wg16_prio<0>();
     radix16_fwd(a);
+    constexpr int K2 = T_ / 16;
 #pragma unroll
-    for (int k = 1; k < 16; k++) a[k] = dmul(a[k], TWB[(k - 1) * 16 + g]);
+    for (int k = 1; k < 16; k++) a[k] = dmul(a[k], TWB[(k - 1) * K2 + g]);
     wg16_prio<1>();
     __syncthreads();                                                    // every wave is done with its in-wave exchange: the rows below overwrite other waves' groups
 #pragma unroll
-    for (int k = 0; k < 16; k++) S[256 * k + t] = a[k];                 // [reg k1][thread (n0, k0)]
+    for (int k = 0; k < 16; k++) S[T_ * k + t] = a[k];                  // [reg k1][thread (n0, k0)]
     __syncthreads();
+    // thread t = k0 + 16 (k1 mod K2) takes (k1 = g + K2 h, n0 = n, k0 = c) into register K2 h + n (K2 = 16: h = 0)
 #pragma unroll
-    for (int n = 0; n < 16; n++) a[n] = S[256 * g + 16 * n + c];        // thread t = k0 + 16 k1 takes (k1 = g, n0 = n, k0 = c)
+    for (int h = 0; h < 16 / K2; h++)
+#pragma unroll
+        for (int n = 0; n < K2; n++) a[K2 * h + n] = S[T_ * (g + K2 * h) + 16 * n + c];
     __syncthreads();                                                    // the scratch is free again
     wg16_prio<0>();
-    radix16_fwd(a);
+    if (K2 == 16) {
+        radix16_fwd(a);
+    } else {                                                            // two radix-8 DFTs over n0; bin t + T (h + 2 k2) <- register 8 h + k2
+        double2 lo[8], hi[8];
+#pragma unroll
+        for (int n = 0; n < 8; n++) { lo[n] = a[n]; hi[n] = a[8 + n]; }
+        radix8<double, false>(lo);
+        radix8<double, false>(hi);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a[2 * k] = lo[k]; a[2 * k + 1] = hi[k]; }
+    }
 }
 
 // The inverse in packed fp32, the same passes backwards: in thread t, reg r <-> bin t + 256 r, out thread t, reg r <-> element ts + 256 r.
 // The caller guarantees that nobody still reads the first 32 KB of the scratch; the data of the cross-wave exchange is consumed before the function returns its
 // in-wave exchange, which lives in the SECOND 32 KB (no barrier between the two).
 struct TwAf { pk::c32 w1, w2, w4, w8; };
+template <int T_>
 __device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, const TwAf &tw, const pk::c32 *TWBF, int t)
 {
     const int c = t & 15, g = t >> 4;
+    constexpr int K2 = T_ / 16;
     wg16_prio<3>();
-    radix16_inv_pk(a);
+    if (K2 == 16) {
+        radix16_inv_pk(a);
+    } else {                                                            // register 8 h + k2 <- bin t + T (h + 2 k2); two radix-8 inverse DFTs over k2 -> n0
+        pk::c32 lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { lo[k] = a[2 * k]; hi[k] = a[2 * k + 1]; }
+        pk::radix8_inv(lo);
+        pk::radix8_inv(hi);
+#pragma unroll
+        for (int n = 0; n < 8; n++) { a[n] = lo[n]; a[8 + n] = hi[n]; }
+    }
     wg16_prio<4>();
 #pragma unroll
-    for (int n = 0; n < 16; n++) S[256 * g + 16 * n + c] = a[n];        // thread (k1 = g, k0 = c), reg n0 = n
+    for (int h = 0; h < 16 / K2; h++)
+#pragma unroll
+        for (int n = 0; n < K2; n++) S[T_ * (g + K2 * h) + 16 * n + c] = a[K2 * h + n];   // thread (k1 = g + K2 h, k0 = c), reg n0 = n
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; k++) a[k] = S[256 * k + t];                 // thread (n0 = g, k0 = c), reg k1
+    for (int k = 0; k < 16; k++) a[k] = S[T_ * k + t];                  // thread (n0 = g, k0 = c), reg k1
     wg16_prio<3>();
 #pragma unroll
-    for (int k = 1; k < 16; k++) a[k] = pk::cmul(a[k], TWBF[(k - 1) * 16 + g]);
+    for (int k = 1; k < 16; k++) a[k] = pk::cmul(a[k], TWBF[(k - 1) * K2 + g]);
     radix16_inv_pk(a);
-    pk::c32 *Sg = S + 4096 + 256 * g;                                   // second half of the scratch (fp32 elements are half the size)
+    pk::c32 *Sg = S + 16 * T_ + 256 * g;                                // second half of the scratch (fp32 elements are half the size)
     wg16_prio<4>();
 #pragma unroll
     for (int n = 0; n < 16; n++) Sg[16 * c + (n ^ c)] = a[n];           // thread (n0, k0 = c), reg n1 = n
@@ -236,7 +273,7 @@ __device__ __forceinline__ pk::c32 mul_w32_inv_pk16(pk::c32 o, int r)
 }
 
 // Workgroup-wide claim rounds (pv_wg_kernel.hip): atomic MIN on the claim word, the smallest pending source bin wins the round.  CLAIM[0..H) all-ones on entry and exit.
-template <int NS>
+template <int NS, int H_>
 __device__ __forceinline__ void claim_rounds_wg16(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned *CLAIM)
 {
     unsigned pend = 0;
@@ -244,7 +281,7 @@ __device__ __forceinline__ void claim_rounds_wg16(const unsigned (&rt)[NS], cons
 #pragma unroll
     for (int r = 0; r < NS; r++) {
         const unsigned t = rt[r] & 0xFFFFu;
-        const bool ok = t < (unsigned)QC::H;
+        const bool ok = t < (unsigned)H_;
         pend |= ok ? (1u << r) : 0u;
         tg[r] = ok ? t : 0u;
     }
@@ -277,32 +314,57 @@ __device__ __forceinline__ int digitrev4_16(int v, int nd)
 
 // Rare path: above-Nyquist residue of fft.js's in-place real DIT, one quarter of the buffer at a time (log2 N odd: radix-2 base blocks, bundle:447-463,
 // then the radix-4 stages with their predicated stores, bundle:329-441), then its sources are added into Y.  See residue_scatter_wg.
-template <int R_>
+template <int LOG2N, int R_>
 __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(const float *in, const float *hist, int hist_len, bool sys, long s0, const float *__restrict__ hann,
                                                                                const float2 *__restrict__ tw32, int t, int upper_end, int up_delta, unsigned up_ridx,
                                                                                double *dbg_X, bool plain)
 {
-    constexpr int N = QC::N, H = QC::H, T = QC::T, QN = N / 4, LOG2N = QC::LOG2N;
+    using C = QC<LOG2N>;
+    constexpr int N = C::N, H = C::H, T = C::T, QN = N / 4;
+    constexpr bool BASE4 = (LOG2N % 2) == 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2 *Y = reinterpret_cast<float2 *>(smem + QC::OFF_Y);
-    unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + QC::OFF_ROUTE);
-    float2 *Q = reinterpret_cast<float2 *>(smem + QC::OFF_RESQ);
-    const float *XQ = reinterpret_cast<const float *>(smem + QC::OFF_XQ);
+    float2 *Y = reinterpret_cast<float2 *>(smem + C::OFF_Y);
+    unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);
+    float2 *Q = reinterpret_cast<float2 *>(smem + C::OFF_RESQ);
+    const float *XQ = reinterpret_cast<const float *>(smem + C::OFF_XQ);
     const WaveSrc src{in, hist, hist_len, sys};
     for (int base = N / 2; base < N && base < upper_end; base += QN) {
-        constexpr int nd = (LOG2N - 1) / 2;
+        if (BASE4) {
+            constexpr int nd = (LOG2N - 2) / 2;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {                                      // QN / 2 = 1024 radix-2 blocks per quarter
-            const int lb = t + T * i;
-            const int off = digitrev4_16((base == N / 2 ? N / 4 : base / 2) + lb, nd);
-            float a, b;
-            if (base == N / 2) { a = XQ[(off - 2) >> 2]; b = XQ[((off - 2) >> 2) + N / 8]; }     // quarter 2: sub-FFT of xw[4n + 2], from the frame's stash
-            else { a = src.at(s0 + off) * hann[off]; b = src.at(s0 + off + N / 2) * hann[off + N / 2]; }
-            Q[2 * lb] = float2{a + b, 0.f};
-            Q[2 * lb + 1] = float2{a - b, 0.f};
+            for (int i = 0; i < 2; i++) {                                  // QN / 4 = 2T radix-4 blocks per quarter (bundle:468-508)
+                const int lb = t + T * i;
+                float a, b, c, d;
+                if (base == N / 2) {                                       // quarter 2: sub-FFT of xw[4n + 2], from the frame's stash
+                    const int off = digitrev4_16(N / 8 + lb, nd);          // = 2 (mod 4): sample off + q N/4 is XQ[(off - 2) / 4 + q N/16]
+                    a = XQ[(off - 2) >> 2]; b = XQ[((off - 2) >> 2) + N / 16]; c = XQ[((off - 2) >> 2) + N / 8]; d = XQ[((off - 2) >> 2) + 3 * N / 16];
+                } else {
+                    const int off = digitrev4_16(base / 4 + lb, nd);
+                    a = src.at(s0 + off) * hann[off]; b = src.at(s0 + off + N / 4) * hann[off + N / 4];
+                    c = src.at(s0 + off + N / 2) * hann[off + N / 2]; d = src.at(s0 + off + 3 * N / 4) * hann[off + 3 * N / 4];
+                }
+                const float t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+                Q[4 * lb] = float2{t0 + t2, 0.f};
+                Q[4 * lb + 1] = float2{t1, -t3};
+                Q[4 * lb + 2] = float2{t0 - t2, 0.f};
+                Q[4 * lb + 3] = float2{t1, t3};
+            }
+        } else {
+            constexpr int nd = (LOG2N - 1) / 2;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {                                  // QN / 2 = 4T radix-2 blocks per quarter (bundle:447-463)
+                const int lb = t + T * i;
+                const int off = digitrev4_16((base == N / 2 ? N / 4 : base / 2) + lb, nd);
+                float a, b;
+                if (base == N / 2) { a = XQ[(off - 2) >> 2]; b = XQ[((off - 2) >> 2) + N / 8]; }     // quarter 2: sub-FFT of xw[4n + 2], from the frame's stash
+                else { a = src.at(s0 + off) * hann[off]; b = src.at(s0 + off + N / 2) * hann[off + N / 2]; }
+                Q[2 * lb] = float2{a + b, 0.f};
+                Q[2 * lb + 1] = float2{a - b, 0.f};
+            }
         }
         __syncthreads();
-        for (int log2m = 3; log2m <= LOG2N - 2; log2m += 2) {              // block sizes 8, 32, 128, 512, 2048 inside the quarter
+        constexpr int LOG2BASE = BASE4 ? 2 : 1;
+        for (int log2m = LOG2BASE + 2; log2m <= LOG2N - 2; log2m += 2) {  // block sizes 4 * base .. N/4 inside the quarter
             const int q = (1 << log2m) >> 2, hq = q >> 1;
             const int nblocks = QN >> log2m;
             const int tws = LOG2N - log2m;
@@ -312,7 +374,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(co
                 const int o = blk << log2m;
                 const float2 A = Q[o + i];
                 const float2 w1 = tw32[i << tws];
-                const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);          // (the same forms as pv_wg_kernel: results agree bit for bit)
+                const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
                 const float2 Bv = cmul(Q[o + q + i], w1);
                 const float2 Cc = cmul(Q[o + 2 * q + i], w2);
                 const float2 D = cmul(Q[o + 3 * q + i], w3);
@@ -344,20 +406,20 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(co
 #pragma unroll
             for (int j = 0; j < 8; j++) if (rt[j] != NOROUTE) Y[rt[j] & 0xFFFFu] = ys[j];
         } else {
-            claim_rounds_wg16<8>(rt, ys, id, Y, CLAIM);
+            claim_rounds_wg16<8, H>(rt, ys, id, Y, CLAIM);
         }
         __syncthreads();
     }
 }
 
-// S_ROWS = hop / 512 in {2, 4, 8, 16}: the frame advances by whole register rows (512 samples), overlap-add accumulator and input window live in registers.
+// S_ROWS = hop / (N / 16) in {2, 4, 8, 16}: the frame advances by whole register rows (N / 16 samples), overlap-add accumulator and input window live in registers.
 // AUX: test-tap instance.  RESIDENT: streaming instance that stays on the GPU (see pv_wg_kernel.hip).
-template <int S_ROWS, bool AUX, bool RESIDENT = false>
-__global__ __launch_bounds__(256, RESIDENT ? 1 : 2) PV_NO_DS_MERGE void pv_wg16_kernel(const PvKernelParams p)
+template <int LOG2N, int S_ROWS, bool AUX, bool RESIDENT = false>
+__global__ __launch_bounds__(QC<LOG2N>::T, RESIDENT ? 1 : 2) PV_NO_DS_MERGE void pv_wg16_kernel(const PvKernelParams p)
 {
-    using C = QC;
-    constexpr int N = C::N, M = C::M, H = C::H, T = C::T, LOG2N = C::LOG2N;
-    constexpr int HOP = 512 * S_ROWS, R = N / HOP, LROWS = 16 - S_ROWS, L = N - HOP;
+    using C = QC<LOG2N>;
+    constexpr int N = C::N, M = C::M, H = C::H, T = C::T, K2 = C::K2, NW = C::NW, PR = C::PR, PM = C::PM;
+    constexpr int HOP = 2 * T * S_ROWS, R = N / HOP, LROWS = 16 - S_ROWS, L = N - HOP;
     constexpr int NEGPD = -(1 << 30), POSPD = 1 << 30;                    // packed (bin << 16 | shift) sentinels: no peak on this side
     constexpr int DROP = 0x4000;
     const int t = threadIdx.x;
@@ -376,13 +438,13 @@ __global__ __launch_bounds__(256, RESIDENT ? 1 : 2) PV_NO_DS_MERGE void pv_wg16_
     pk::c32 *TWBF = reinterpret_cast<pk::c32 *>(smem + C::OFF_TWBF);
 
     // ---- table: W_256^{n0 k1} = tw[32 n0 k1] (tw[i] = exp(-2 pi j i / N)), and its conjugate in fp32 ----
-    if (t < 240) {
-        const int k1 = t / 16 + 1, n0 = t % 16;
+    if (t < 15 * K2) {
+        const int k1 = t / K2 + 1, n0 = t % K2;
         const double2 w = p.tw64[(32 * n0 * k1) & (N - 1)];
         TWB[t] = w;
         TWBF[t] = pk::c32{(float)w.x, -(float)w.y};
     }
-    const int ts = (t >> 4) + 16 * (t & 15);                              // this thread's complex elements: ts + 256 r
+    const int ts = (t >> 4) + K2 * (t & 15);                              // this thread's complex elements: ts + T r
 
     unsigned psh_key = 0u;
     bool psh_valid = false;
@@ -480,7 +542,7 @@ resident_top:
         // Loop-invariant per-thread values that are only needed in ONE phase of the frame are re-loaded per frame (L1 / L2 hits, issued ahead of their use) through
         // addresses derived from the opaque thread id, instead of occupying registers across the phases that need every one of them: the pass-A twiddles here,
         // the Hann values and the inverse's twiddles in front of the inverse FFT.
-        const int tsq = (tq >> 4) + 16 * (tq & 15);
+        const int tsq = (tq >> 4) + K2 * (tq & 15);
         const TwA twa{p.tw64[(2 * tsq) & (N - 1)], p.tw64[(4 * tsq) & (N - 1)], p.tw64[(8 * tsq) & (N - 1)], p.tw64[(16 * tsq) & (N - 1)]};   // W_4096^{ts k}, k = 1, 2, 4, 8
         const double2 wl = p.tw64[tq];                                      // split pass: W_N^{tq + 256 r} = wl * W_32^r
         // ---- Hann (pv:55), pack, forward FFT in fp64 (the split pass's 1/2 is folded into the window, exact) ----
@@ -495,7 +557,7 @@ resident_top:
 #pragma unroll
             for (int r = 0; r < 16; r++) XQ[(tsq + T * r - 1) >> 1] = raw[r].x * (2.0f * hw[r].x);
         }
-        fft_wg16(z, S64, twa, TWB, tq);
+        fft_wg16<T>(z, S64, twa, TWB, tq);
 
         // ---- split pass in conjugate pairs: thread tq owns the pairs k = tq + 256 r, r < 8: XA[r] = X[k], XB[r] = X[M - k]; thread 0 also the self-paired bin M/2.
         //      The partner values Z[M - k] are rows 8..15 of other threads -> LDS ----
@@ -520,8 +582,8 @@ resident_top:
                     xb = double2{2.0 * (z[0].x - z[0].y), 0.0};
                 }
                 // (the magnitudes sit behind the partner rows: they may be written while other threads still read theirs; fp32 values at once: 16 doubles less to hold)
-                MAG[C::MAG0 + pl + 320 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
-                MAG[C::MAG0 + 5120 - ql - 320 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                MAG[C::MAG0 + pl + PR * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                MAG[C::MAG0 + PM - ql - PR * r] = (float)(xb.x * xb.x + xb.y * xb.y);
                 XA[r] = float2{(float)xa.x, (float)xa.y};
                 XB[r] = float2{(float)xb.x, (float)xb.y};
                 if (dbg) {
@@ -532,7 +594,7 @@ resident_top:
             }
             if (tq == 0) {
                 xH = double2{2.0 * z[8].x, -2.0 * z[8].y};                    // k = M/2 pairs with itself: X = 2 conj(Z)
-                MAG[C::MAG0 + 2560] = (float)(xH.x * xH.x + xH.y * xH.y);
+                MAG[C::MAG0 + PM / 2] = (float)(xH.x * xH.x + xH.y * xH.y);
                 if (dbg) { p.dbg_X[M] = xH.x; p.dbg_X[M + 1] = xH.y; }
             }
             xHf = float2{(float)xH.x, (float)xH.y};
@@ -663,10 +725,10 @@ resident_top:
                 const unsigned long long above = (l == 63) ? 0ull : (mine >> (l + 1));
                 if (above) srcT = wv * 64 + l + __ffsll((long long)above);
                 else
-                    for (int w = wv + 1; w < 4; ++w) { const unsigned long long o = OCC[w]; if (o) { srcT = w * 64 + __ffsll((long long)o) - 1; break; } }
+                    for (int w = wv + 1; w < NW; ++w) { const unsigned long long o = OCC[w]; if (o) { srcT = w * 64 + __ffsll((long long)o) - 1; break; } }
                 if (srcT >= 0) cnext = FIRSTIN[srcT];
             }
-            for (int w = 3; w >= 0; --w) {
+            for (int w = NW - 1; w >= 0; --w) {
                 const unsigned long long o = OCC[w];
                 if (o) { const int lp = LASTIN[w * 64 + 63 - __clzll((long long)o)]; last_peak = lp >> 16; last_shift = (int)(short)(lp & 0xFFFF); break; }
             }
@@ -707,7 +769,7 @@ resident_top:
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) *reinterpret_cast<uint4 *>(&ROUTE[C::MAG0 + 20 * tq + 4 * j]) = uint4{rt[4 * j], rt[4 * j + 1], rt[4 * j + 2], rt[4 * j + 3]};
-            if (tq == T - 1) ROUTE[C::MAG0 + 5120] = rtM;
+            if (tq == T - 1) ROUTE[C::MAG0 + PM] = rtM;
             if (!(pf >= 1.0)) { const bool wbad = __any(bad); if (l == 0) BADW[wv] = wbad ? 1u : 0u; }
         }
         int upper_end = H;
@@ -734,12 +796,12 @@ resident_top:
                     };
 #pragma unroll
                     for (int r = 0; r < 8; r++) {
-                        const unsigned ra = ROUTE[C::MAG0 + pl + 320 * r], ta = ra & 0xFFFFu;
-                        const unsigned rb = ROUTE[C::MAG0 + 5120 - ql - 320 * r], tb = rb & 0xFFFFu;
+                        const unsigned ra = ROUTE[C::MAG0 + pl + PR * r], ta = ra & 0xFFFFu;
+                        const unsigned rb = ROUTE[C::MAG0 + PM - ql - PR * r], tb = rb & 0xFFFFu;
                         if (ta < (unsigned)H) Y[ta] = rot(ra, XA[r]);
                         if (tb < (unsigned)H) Y[tb] = rot(rb, XB[r]);
                     }
-                    if (tq == 0) { const unsigned rt = ROUTE[C::MAG0 + 2560], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, xHf); }
+                    if (tq == 0) { const unsigned rt = ROUTE[C::MAG0 + PM / 2], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Y[tg] = rot(rt, xHf); }
                 };
                 if (tmod == 0) scatter(std::integral_constant<int, 0>{});
                 else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
@@ -750,16 +812,16 @@ resident_top:
                 // reference's order of accumulation (pv:122,146), is kept by finishing batch 0 before batch 1 starts.
                 bool pairwise = PV_PAIRWISE != 0;
 #pragma unroll
-                for (int w = 0; w < 4; w++) pairwise = pairwise && (BADW[w] == 0u);        // uniform in the workgroup
+                for (int w = 0; w < NW; w++) pairwise = pairwise && (BADW[w] == 0u);       // uniform in the workgroup
                 auto gather = [&](auto half_tag, unsigned (&rt)[9], float2 (&ys)[9], int (&id)[9]) {
                     constexpr int HALF = decltype(half_tag)::value;
 #pragma unroll
                     for (int r = 0; r < 8; r++) {
-                        if (HALF == 0) { id[r] = tq + T * r; rt[r] = ROUTE[C::MAG0 + pl + 320 * r]; ys[r] = rotate_route<R, LOG2N>(rt[r], XA[r], p.tw32); }
-                        else { id[r] = M - tq - T * r; rt[r] = ROUTE[C::MAG0 + 5120 - ql - 320 * r]; ys[r] = rotate_route<R, LOG2N>(rt[r], XB[r], p.tw32); }
+                        if (HALF == 0) { id[r] = tq + T * r; rt[r] = ROUTE[C::MAG0 + pl + PR * r]; ys[r] = rotate_route<R, LOG2N>(rt[r], XA[r], p.tw32); }
+                        else { id[r] = M - tq - T * r; rt[r] = ROUTE[C::MAG0 + PM - ql - PR * r]; ys[r] = rotate_route<R, LOG2N>(rt[r], XB[r], p.tw32); }
                     }
                     if (HALF == 0) { id[8] = 0; rt[8] = NOROUTE; ys[8] = float2{0.f, 0.f}; }
-                    else { id[8] = M / 2; rt[8] = (tq == 0) ? ROUTE[C::MAG0 + 2560] : NOROUTE; ys[8] = rotate_route<R, LOG2N>(rt[8], xHf, p.tw32); }
+                    else { id[8] = M / 2; rt[8] = (tq == 0) ? ROUTE[C::MAG0 + PM / 2] : NOROUTE; ys[8] = rotate_route<R, LOG2N>(rt[8], xHf, p.tw32); }
                 };
                 if (pairwise) {
                     // every collision is one falling-side source against one rising-side source: the falling side (and the residue, which continues the falling side of
@@ -799,8 +861,8 @@ resident_top:
 #pragma unroll
                     for (int r = 0; r < 16; r++) CLAIM[tq + T * r] = 0xFFFFFFFFu;
                     if (tq == 0) CLAIM[M] = 0xFFFFFFFFu;
-                    claim_rounds_wg16<9>(rt0, ys0, id0, Y, CLAIM);            // (its first barrier orders the fill before the first claims)
-                    claim_rounds_wg16<9>(rt1, ys1, id1, Y, CLAIM);
+                    claim_rounds_wg16<9, H>(rt0, ys0, id0, Y, CLAIM);            // (its first barrier orders the fill before the first claims)
+                    claim_rounds_wg16<9, H>(rt1, ys1, id1, Y, CLAIM);
                     if (need_res) {
                         __syncthreads();
                         const int up_delta = last_shift;
@@ -817,14 +879,14 @@ resident_top:
                                 id2[j] = b - N / 2;
                                 if (dbg && b < upper_end) { p.dbg_X[2 * b] = s2v[j].x; p.dbg_X[2 * b + 1] = s2v[j].y; }
                             }
-                            claim_rounds_wg16<4>(rt2, ys2, id2, Y, CLAIM);
+                            claim_rounds_wg16<4, H>(rt2, ys2, id2, Y, CLAIM);
                         }
                     }
                 }
                 if (need_res && upper_end > H + N / 8) {
                     __syncthreads();
                     const int up_delta = last_shift;
-                    residue_scatter_wg16<R>(src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw32, tq, upper_end, up_delta,
+                    residue_scatter_wg16<LOG2N, R>(src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw32, tq, upper_end, up_delta,
                                             (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1), dbg ? p.dbg_X : nullptr, pairwise);
                 }
             }
@@ -867,7 +929,7 @@ resident_top:
         // routes / claim words and the hand-over buffer, whose reads sit in front of the cross-wave exchange's barrier: no barrier here
         int tqi = tq;
         asm volatile("" : "+v"(tqi));                                      // a fresh copy: the addresses of this phase are not kept alive from the top of the frame
-        const int tsi = (tqi >> 4) + 16 * (tqi & 15);
+        const int tsi = (tqi >> 4) + K2 * (tqi & 15);
         {
             // the window of the overlap-add below AND of the next frame's analysis (see the top of the loop): live from here to the next frame's first lines only
 #pragma unroll
@@ -875,7 +937,7 @@ resident_top:
         }
         const float2 f1 = cconj(p.tw32[(2 * tsi) & (N - 1)]), f2 = cconj(p.tw32[(4 * tsi) & (N - 1)]), f4 = cconj(p.tw32[(8 * tsi) & (N - 1)]), f8 = cconj(p.tw32[(16 * tsi) & (N - 1)]);
         const TwAf twaf{pk::c32{f1.x, f1.y}, pk::c32{f2.x, f2.y}, pk::c32{f4.x, f4.y}, pk::c32{f8.x, f8.y}};
-        fft_wg16_inv_pk(zi, reinterpret_cast<pk::c32 *>(smem), twaf, TWBF, tqi);
+        fft_wg16_inv_pk<T>(zi, reinterpret_cast<pk::c32 *>(smem), twaf, TWBF, tqi);
         // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
         wg16_prio<5>();
         {
@@ -916,59 +978,72 @@ resident_top:
     if (RESIDENT) goto resident_top;
 }
 
-template <int S_ROWS, bool AUX>
+template <int LOG2N, int S_ROWS, bool AUX>
 hipError_t launch_wg16(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
+    using C = QC<LOG2N>;
     static std::atomic<bool> attr_done[16];
-    auto k = pv_wg16_kernel<S_ROWS, AUX>;
+    auto k = pv_wg16_kernel<LOG2N, S_ROWS, AUX>;
     {
-        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), QC::LDS_BYTES);
+        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), C::LDS_BYTES);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(nchunks, nch, 1), dim3(QC::T, 1, 1), QC::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(k, dim3(nchunks, nch, 1), dim3(C::T, 1, 1), C::LDS_BYTES, st, p);
     return hipGetLastError();
 }
 
 template <int S_ROWS>
 hipError_t launch_wg16_resident(const PvKernelParams &p, int nslots, hipStream_t st)
 {
+    using C = QC<13>;
     static std::atomic<bool> attr_done[16];
-    auto k = pv_wg16_kernel<S_ROWS, false, true>;
+    auto k = pv_wg16_kernel<13, S_ROWS, false, true>;
     {
-        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), QC::LDS_BYTES);
+        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), C::LDS_BYTES);
         if (e != hipSuccess) return e;
     }
     PvKernelParams q = p;
     q.nchunks = 1; q.nch = nslots; q.nhops = 1; q.frames_per_chunk = 1;
-    hipLaunchKernelGGL(k, dim3(1, nslots, 1), dim3(QC::T, 1, 1), QC::LDS_BYTES, st, q);
+    hipLaunchKernelGGL(k, dim3(1, nslots, 1), dim3(C::T, 1, 1), C::LDS_BYTES, st, q);
     return hipGetLastError();
 }
 
-}  // namespace
-
-bool pv_wg16_supported(int log2n, int hop) { return log2n == 13 && (hop == 1024 || hop == 2048 || hop == 4096 || hop == 8192); }
-size_t pv_wg16_lds_bytes() { return QC::LDS_BYTES; }
-int pv_wg16_threads() { return QC::T; }
-
-hipError_t pv_launch_wg16(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+template <int LOG2N>
+hipError_t launch_wg16_n(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
     const bool aux = (p.dbg_mag != nullptr);
-    switch (p.hop) {
-    case 1024: return aux ? launch_wg16<2, true>(p, nch, nchunks, st) : launch_wg16<2, false>(p, nch, nchunks, st);
-    case 2048: return aux ? launch_wg16<4, true>(p, nch, nchunks, st) : launch_wg16<4, false>(p, nch, nchunks, st);
-    case 4096: return aux ? launch_wg16<8, true>(p, nch, nchunks, st) : launch_wg16<8, false>(p, nch, nchunks, st);
-    case 8192: return aux ? launch_wg16<16, true>(p, nch, nchunks, st) : launch_wg16<16, false>(p, nch, nchunks, st);
+    switch (16 * p.hop >> LOG2N) {
+    case 2: return aux ? launch_wg16<LOG2N, 2, true>(p, nch, nchunks, st) : launch_wg16<LOG2N, 2, false>(p, nch, nchunks, st);
+    case 4: return aux ? launch_wg16<LOG2N, 4, true>(p, nch, nchunks, st) : launch_wg16<LOG2N, 4, false>(p, nch, nchunks, st);
+    case 8: return aux ? launch_wg16<LOG2N, 8, true>(p, nch, nchunks, st) : launch_wg16<LOG2N, 8, false>(p, nch, nchunks, st);
+    case 16: return aux ? launch_wg16<LOG2N, 16, true>(p, nch, nchunks, st) : launch_wg16<LOG2N, 16, false>(p, nch, nchunks, st);
     default: return hipErrorInvalidValue;
     }
 }
 
+}  // namespace
+
+bool pv_wg16_supported(int log2n, int hop)
+{
+    if (log2n != 12 && log2n != 13) return false;
+    const int N = 1 << log2n;
+    return hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N;
+}
+size_t pv_wg16_lds_bytes(int log2n) { return log2n == 12 ? QC<12>::LDS_BYTES : QC<13>::LDS_BYTES; }
+int pv_wg16_threads(int log2n) { return log2n == 12 ? QC<12>::T : QC<13>::T; }
+
+hipError_t pv_launch_wg16(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+{
+    return log2n == 12 ? launch_wg16_n<12>(p, nch, nchunks, st) : launch_wg16_n<13>(p, nch, nchunks, st);
+}
+
 hipError_t pv_launch_wg16_resident(const PvKernelParams &p, int nslots, hipStream_t st)
 {
-    switch (p.hop) {
-    case 1024: return launch_wg16_resident<2>(p, nslots, st);
-    case 2048: return launch_wg16_resident<4>(p, nslots, st);
-    case 4096: return launch_wg16_resident<8>(p, nslots, st);
-    case 8192: return launch_wg16_resident<16>(p, nslots, st);
+    switch (16 * p.hop >> 13) {
+    case 2: return launch_wg16_resident<2>(p, nslots, st);
+    case 4: return launch_wg16_resident<4>(p, nslots, st);
+    case 8: return launch_wg16_resident<8>(p, nslots, st);
+    case 16: return launch_wg16_resident<16>(p, nslots, st);
     default: return hipErrorInvalidValue;
     }
 }

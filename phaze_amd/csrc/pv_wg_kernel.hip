@@ -1103,19 +1103,16 @@ bool pv_wg_supported(int log2n, int hop)
     if (log2n < 11 || log2n > 13) return false;
     const int N = 1 << log2n;
     if (hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N) return true;      // register-resident overlap-add
-    return hop >= 2 && hop % 2 == 0 && N % hop == 0 && pv_wg_lds_bytes(log2n, hop) <= 160 * 1024;   // LDS ring (e.g. native 2048/128)
+    return hop >= 2 && hop % 2 == 0 && N % hop == 0 && pv_wg_lds_bytes(log2n, hop, true) <= 160 * 1024;   // LDS ring (e.g. native 2048/128)
 }
 
-// N = 8192 with the register-resident overlap-add runs on pv_wg16_kernel.hip (four waves, sixteen elements per thread, two workgroups per CU): PV_WG16 = 0 keeps the
-// eight-wave kernel of this file (A/B builds)
-#ifndef PV_WG16
-#define PV_WG16 1
-#endif
-static bool use_wg16(int log2n, int hop) { return PV_WG16 && pv_wg16_supported(log2n, hop); }
+// N = 4096 / 8192 with the register-resident overlap-add run on pv_wg16_kernel.hip (sixteen elements per thread, N/32 threads per frame chain) unless the caller asks
+// for the eight-element kernel of this file (wg8: PV_FLAG_WORKGROUP_KERNEL, the second implementation the tests compare with)
+static bool use_wg16(int log2n, int hop, bool wg8) { return !wg8 && pv_wg16_supported(log2n, hop); }
 
-size_t pv_wg_lds_bytes(int log2n, int hop)
+size_t pv_wg_lds_bytes(int log2n, int hop, bool wg8)
 {
-    if (use_wg16(log2n, hop)) return pv_wg16_lds_bytes();
+    if (use_wg16(log2n, hop, wg8)) return pv_wg16_lds_bytes(log2n);
     const int N = 1 << log2n;
     const bool ring = !(hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N);
     switch (log2n) {
@@ -1126,15 +1123,15 @@ size_t pv_wg_lds_bytes(int log2n, int hop)
     }
 }
 
-int pv_wg_threads(int log2n) { return (PV_WG16 && log2n == 13) ? pv_wg16_threads() : 64 << (log2n - 10); }
+int pv_wg_threads(int log2n, int hop, bool wg8) { return use_wg16(log2n, hop, wg8) ? pv_wg16_threads(log2n) : 64 << (log2n - 10); }
 
 // resident streaming form: N = 8192 with the register-resident overlap-add (hop = N/8 .. N)
 bool pv_wg_resident_supported(int log2n, int hop) { const int N = 1 << log2n; return log2n == 13 && (hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N); }
 
-hipError_t pv_launch_wg_resident(int log2n, const PvKernelParams &p, int nslots, hipStream_t st)
+hipError_t pv_launch_wg_resident(int log2n, const PvKernelParams &p, int nslots, hipStream_t st, bool wg8)
 {
     if (log2n != 13) return hipErrorInvalidValue;
-    if (use_wg16(log2n, p.hop)) return pv_launch_wg16_resident(p, nslots, st);
+    if (use_wg16(log2n, p.hop, wg8)) return pv_launch_wg16_resident(p, nslots, st);
     switch (8 * p.hop / (1 << log2n)) {
     case 1: return launch_wg_resident<13, 1>(p, nslots, st);
     case 2: return launch_wg_resident<13, 2>(p, nslots, st);
@@ -1144,9 +1141,9 @@ hipError_t pv_launch_wg_resident(int log2n, const PvKernelParams &p, int nslots,
     }
 }
 
-hipError_t pv_launch_wg(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
+hipError_t pv_launch_wg(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st, bool wg8)
 {
-    if (use_wg16(log2n, p.hop)) return pv_launch_wg16(p, nch, nchunks, st);
+    if (use_wg16(log2n, p.hop, wg8)) return pv_launch_wg16(log2n, p, nch, nchunks, st);
     switch (log2n) {
     case 11: return launch_wg_n<11>(p, nch, nchunks, st);
     case 12: return launch_wg_n<12>(p, nch, nchunks, st);

@@ -96,13 +96,13 @@ def test_streaming_process_matches_reference_golden(name, flags):
 @pytest.mark.parametrize("name", sorted(n for n, c in CASES.items() if c.get("dumps")))
 def test_intermediates_match_reference(name):
     """freqComplexBuffer (incl. the above-Nyquist residue when read), magnitudes, peaks, shifted spectrum -- tapped from the kernel the handle
-    actually runs (round 3: pv_wave2k_kernel for the c3m_* / native_* dumps, pv_pair_kernel for c4m_*, each through its AUX instance)."""
+    actually runs (pv_wave2k_kernel for the c3m_* / native_* dumps, pv_wg16_kernel for c4m_* and the 8192-point cases, each through its AUX instance)."""
     case = CASES[name]
     sig, pitch = _inputs(case)
     N, h = case["fft"], case["hop"]
     H = N // 2 + 1
     pv = _pv(fft_size=N, hop_size=h, max_channels=1, max_hops=1)
-    expect = {1024: "pv_wave_kernel_1024", 2048: "pv_wave2k_kernel", 4096: "pv_pair_kernel", 8192: "pv_wg_kernel"}
+    expect = {1024: "pv_wave_kernel_1024", 2048: "pv_wave2k_kernel", 4096: "pv_wg16_kernel", 8192: "pv_wg16_kernel"}
     if N in expect and (N, h) != (1024, 64):
         assert pv.info()["kernel_name"] == expect[N]
     want = {d["hop"]: S.load_dump(case, d) for d in case["dumps"]}
@@ -298,15 +298,16 @@ def test_wave2k_kernel(hop):
     pv.close()
 
 
-@pytest.mark.parametrize("hop", [512, 1024, 2048, 4096])
-def test_pair_kernel(hop):
-    """N = 4096: a pair of waves per frame (pv_pair_kernel).  f >= 1 (plain stores), f < 1 (atomic-MIN claim rounds across the two waves + the fast
-    residue), f < 0.75 (the residue rebuilt quarter by quarter by both waves), 0, negative, NaN and Inf, chunking, call splitting, and the same
-    stream through the workgroup kernel (PV_FLAG_WORKGROUP_KERNEL) as a second implementation of the path."""
-    fft, T, nch = 4096, 28, 3
+@pytest.mark.parametrize("fft,hop", [(4096, 512), (4096, 1024), (4096, 2048), (4096, 4096), (8192, 1024), (8192, 2048), (8192, 4096), (8192, 8192)])
+def test_wg16_kernel(fft, hop):
+    """N = 4096 / 8192: sixteen elements per thread, N/32 threads per frame chain (pv_wg16_kernel).  f >= 1 (plain stores), f < 1 (store / add on pairwise
+    frames, atomic-MIN claim rounds across the waves otherwise, + the fast residue), f < 0.75 (the residue rebuilt quarter by quarter), 0, negative, NaN
+    and Inf, chunking, call splitting, and the same stream through the eight-element workgroup kernel (PV_FLAG_WORKGROUP_KERNEL) as a second
+    implementation of the path."""
+    T, nch = (28, 3) if fft == 4096 else (20, 2)
     x = np.stack([S.make_signal("tonal" if c != 1 else "noise", c, T * hop, stream=4) for c in range(nch)])
     pv = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T)
-    assert pv.info()["kernel_name"] == "pv_pair_kernel"
+    assert pv.info()["kernel_name"] == "pv_wg16_kernel"
     wg = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T, flags=4)
     assert wg.info()["kernel_name"] == "pv_wg_kernel"
     ar = np.arange(T)
@@ -333,7 +334,7 @@ def test_pair_kernel(hop):
             ref = y if ref is None else ref
             assert np.array_equal(y, ref)
         pv.reset()
-        cuts = [0, 9, 20, T]
+        cuts = [0, 9, T - 8, T]
         parts = [pv.process_batch(x[:, a * hop:b * hop], p[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
         assert np.array_equal(np.concatenate(parts, axis=1), ref)
     pv.close()
