@@ -458,7 +458,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         if (hipHostGetDevicePointer(&dd, hd, 0) == hipSuccess) h->d_done = (unsigned *)dd;
         (void)hipGetLastError();
         if (h->d_done && (cfg->flags & PV_FLAG_PERSISTENT_STREAM) && maxch <= 64 &&
-            (h->use_wave || h->use_wave2k || (h->use_wg && pv_wg_resident_supported(log2n, hop)))) {
+            (h->use_wave || h->use_wave2k || (h->use_wg && pv_wg_resident_supported(log2n, hop, !h->use_wg16)))) {
             // Control block: in DEVICE memory when the host can write it through the BAR and the largest quantum is small enough to travel the same
             // way -- the waves then poll their own HBM and find the input there too, the only PCIe traffic of a quantum being posted writes in both
             // directions (tools/bar_probe.hip: 1 KB handed over and acknowledged in 3.5 us, 7.2 us with the block and the input in pinned host memory)

@@ -75,7 +75,7 @@ hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStre
 // resident form of the same kernel for streaming quanta (p.ctl != null): one wave per channel slot, nslots of them, polling p.ctl until ctl[4] (stop) or ~50 ms idle
 hipError_t pv_launch_wave_resident(const PvKernelParams &p, int nslots, hipStream_t st);
 hipError_t pv_launch_wave2k_resident(const PvKernelParams &p, int nslots, hipStream_t st);
-bool pv_wg_resident_supported(int log2n, int hop);
+bool pv_wg_resident_supported(int log2n, int hop, bool wg8);
 hipError_t pv_launch_wg_resident(int log2n, const PvKernelParams &p, int nslots, hipStream_t st, bool wg8);
 
 // one wavefront per 2048-point frame (pv_wave2k_kernel.hip): N = 2048, hop in {128, 256, 512, 1024, 2048}, every pitchFactor
@@ -96,5 +96,5 @@ bool pv_wg16_supported(int log2n, int hop);
 size_t pv_wg16_lds_bytes(int log2n);
 int pv_wg16_threads(int log2n);
 hipError_t pv_launch_wg16(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
-hipError_t pv_launch_wg16_resident(const PvKernelParams &p, int nslots, hipStream_t st);
+hipError_t pv_launch_wg16_resident(int log2n, const PvKernelParams &p, int nslots, hipStream_t st);
 

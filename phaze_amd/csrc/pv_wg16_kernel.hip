@@ -992,12 +992,12 @@ hipError_t launch_wg16(const PvKernelParams &p, int nch, int nchunks, hipStream_
     return hipGetLastError();
 }
 
-template <int S_ROWS>
+template <int LOG2N, int S_ROWS>
 hipError_t launch_wg16_resident(const PvKernelParams &p, int nslots, hipStream_t st)
 {
-    using C = QC<13>;
+    using C = QC<LOG2N>;
     static std::atomic<bool> attr_done[16];
-    auto k = pv_wg16_kernel<13, S_ROWS, false, true>;
+    auto k = pv_wg16_kernel<LOG2N, S_ROWS, false, true>;
     {
         const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), C::LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -1037,13 +1037,19 @@ hipError_t pv_launch_wg16(int log2n, const PvKernelParams &p, int nch, int nchun
     return log2n == 12 ? launch_wg16_n<12>(p, nch, nchunks, st) : launch_wg16_n<13>(p, nch, nchunks, st);
 }
 
-hipError_t pv_launch_wg16_resident(const PvKernelParams &p, int nslots, hipStream_t st)
+template <int LOG2N>
+hipError_t launch_wg16_resident_n(const PvKernelParams &p, int nslots, hipStream_t st)
 {
-    switch (16 * p.hop >> 13) {
-    case 2: return launch_wg16_resident<2>(p, nslots, st);
-    case 4: return launch_wg16_resident<4>(p, nslots, st);
-    case 8: return launch_wg16_resident<8>(p, nslots, st);
-    case 16: return launch_wg16_resident<16>(p, nslots, st);
+    switch (16 * p.hop >> LOG2N) {
+    case 2: return launch_wg16_resident<LOG2N, 2>(p, nslots, st);
+    case 4: return launch_wg16_resident<LOG2N, 4>(p, nslots, st);
+    case 8: return launch_wg16_resident<LOG2N, 8>(p, nslots, st);
+    case 16: return launch_wg16_resident<LOG2N, 16>(p, nslots, st);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t pv_launch_wg16_resident(int log2n, const PvKernelParams &p, int nslots, hipStream_t st)
+{
+    return log2n == 12 ? launch_wg16_resident_n<12>(p, nslots, st) : launch_wg16_resident_n<13>(p, nslots, st);
 }

@@ -1125,13 +1125,17 @@ size_t pv_wg_lds_bytes(int log2n, int hop, bool wg8)
 
 int pv_wg_threads(int log2n, int hop, bool wg8) { return use_wg16(log2n, hop, wg8) ? pv_wg16_threads(log2n) : 64 << (log2n - 10); }
 
-// resident streaming form: N = 8192 with the register-resident overlap-add (hop = N/8 .. N)
-bool pv_wg_resident_supported(int log2n, int hop) { const int N = 1 << log2n; return log2n == 13 && (hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N); }
+// resident streaming form: N = 8192 (and N = 4096 on pv_wg16_kernel) with the register-resident overlap-add (hop = N/8 .. N)
+bool pv_wg_resident_supported(int log2n, int hop, bool wg8)
+{
+    const int N = 1 << log2n;
+    return (log2n == 13 || (log2n == 12 && use_wg16(log2n, hop, wg8))) && (hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N);
+}
 
 hipError_t pv_launch_wg_resident(int log2n, const PvKernelParams &p, int nslots, hipStream_t st, bool wg8)
 {
+    if (use_wg16(log2n, p.hop, wg8)) return pv_launch_wg16_resident(log2n, p, nslots, st);
     if (log2n != 13) return hipErrorInvalidValue;
-    if (use_wg16(log2n, p.hop, wg8)) return pv_launch_wg16_resident(p, nslots, st);
     switch (8 * p.hop / (1 << log2n)) {
     case 1: return launch_wg_resident<13, 1>(p, nslots, st);
     case 2: return launch_wg_resident<13, 2>(p, nslots, st);

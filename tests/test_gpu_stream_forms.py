@@ -37,7 +37,7 @@ def _stream(fft, hop, nch, flags, x, pitch, pauses=()):
     return y, info
 
 
-@pytest.mark.parametrize("fft,hop,nch", [(1024, 256, 1), (1024, 256, 2), (1024, 128, 2), (1024, 512, 1), (2048, 128, 2), (8192, 2048, 8), (8192, 1024, 3)])
+@pytest.mark.parametrize("fft,hop,nch", [(1024, 256, 1), (1024, 256, 2), (1024, 128, 2), (1024, 512, 1), (2048, 128, 2), (4096, 1024, 8), (4096, 512, 2), (8192, 2048, 8), (8192, 1024, 3)])
 def test_every_hand_over_form_gives_the_same_bits(fft, hop, nch):
     T = 6000 if fft <= 2048 else 500
     rng = np.random.default_rng(fft + hop + nch)
