@@ -951,7 +951,7 @@ resident_top:
                 const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};
                 if (emit_out) {
                     float *dst = outp + (long)m * HOP + 2 * tsi + 2 * T * r;
-                    if (vec_out) __builtin_nontemporal_store(v2f{o.x, o.y}, reinterpret_cast<v2f *>(dst));
+                    if (vec_out) *reinterpret_cast<v2f *>(dst) = v2f{o.x, o.y};                // plain, not non-temporal: the waves' 32-byte pieces of a line merge in L2
                     else { dst[0] = o.x; dst[1] = o.y; }
                 }
             }
