@@ -32,15 +32,21 @@
 namespace {
 
 // wave priority per phase (pv_wave_fft.h has the story): the SIMD's two waves belong to DIFFERENT workgroups; the latency chains between the transforms (short LDS
-// round trips behind barriers) run above the arithmetic of the transforms, whose exchanges are lowest.  PV_WG16_PT = fwd arithmetic, fwd exchanges, middle, inverse
-// arithmetic, inverse exchanges, overlap-add; 9 = leave unchanged.
-#ifndef PV_WG16_PT
-#define PV_WG16_PT 2, 0, 3, 1, 0, 2
+// round trips behind barriers) run above the arithmetic of the transforms, whose exchanges are lowest.  One table per size, phases in this order: forward arithmetic, forward
+// exchanges, split pass, inverse arithmetic, inverse exchanges, overlap-add, peak search + routes, scatter, c2r pass; 9 = leave unchanged.  Measured (gpurun_out/r04wg16d, e, s, t:
+// 25 tables): without priorities C5 at f = 1.5 takes 3.71 instead of 3.09 ms; peak search and scatter must stay on top (3.5 ms at level 2); the c2r pass at level 1 is worth
+// 3 % on C4 and 1.6 % on C5's sweep, the split pass at level 2 another 2.5 % on the sweep (and costs C4 what the c2r level gave: N = 4096 keeps it at 3).
+#ifndef PV_WG16_PT13
+#define PV_WG16_PT13 2, 0, 2, 1, 0, 2, 3, 3, 1
 #endif
-template <int PH> __device__ __forceinline__ void wg16_prio()
+#ifndef PV_WG16_PT12
+#define PV_WG16_PT12 2, 0, 3, 1, 0, 2, 3, 3, 1
+#endif
+template <int PH, int T_> __device__ __forceinline__ void wg16_prio()
 {
-    constexpr int t[] = {PV_WG16_PT};
-    if constexpr (t[PH] <= 3) __builtin_amdgcn_s_setprio(t[PH]);
+    constexpr int t13[] = {PV_WG16_PT13}, t12[] = {PV_WG16_PT12};
+    constexpr int lvl = (T_ == 256) ? t13[PH] : t12[PH];
+    if constexpr (lvl <= 3) __builtin_amdgcn_s_setprio(lvl);
 }
 
 template <int LOG2N_>
@@ -168,18 +174,18 @@ __device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA
     // exchange inside the groups of 16 lanes: [reg k0][lane n1] -> [reg n1][lane k0]; element (k0, n1) of group g at 256 g + 16 k0 + (n1 ^ k0)
     const int c = t & 15, g = t >> 4;
     double2 *Sg = S + 256 * g;
-    wg16_prio<1>();
+    wg16_prio<1, T_>();
 #pragma unroll
     for (int k = 0; k < 16; k++) Sg[16 * k + (c ^ k)] = a[k];
     wave_sync();                                                        // the 16 lanes of a group sit in one wave: LDS traffic of a wave executes in order
 #pragma unroll
     for (int n = 0; n < 16; n++) a[n] = Sg[16 * c + (n ^ c)];
-    wg16_prio<0>();
+    wg16_prio<0, T_>();
     radix16_fwd(a);
     constexpr int K2 = T_ / 16;
 #pragma unroll
     for (int k = 1; k < 16; k++) a[k] = dmul(a[k], TWB[(k - 1) * K2 + g]);
-    wg16_prio<1>();
+    wg16_prio<1, T_>();
     __syncthreads();                                                    // every wave is done with its in-wave exchange: the rows below overwrite other waves' groups
 #pragma unroll
     for (int k = 0; k < 16; k++) S[T_ * k + t] = a[k];                  // [reg k1][thread (n0, k0)]
@@ -190,7 +196,7 @@ __device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA
 #pragma unroll
         for (int n = 0; n < K2; n++) a[K2 * h + n] = S[T_ * (g + K2 * h) + 16 * n + c];
     __syncthreads();                                                    // the scratch is free again
-    wg16_prio<0>();
+    wg16_prio<0, T_>();
     if (K2 == 16) {
         radix16_fwd(a);
     } else {                                                            // two radix-8 DFTs over n0; bin t + T (h + 2 k2) <- register 8 h + k2
@@ -213,7 +219,7 @@ __device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, co
 {
     const int c = t & 15, g = t >> 4;
     constexpr int K2 = T_ / 16;
-    wg16_prio<3>();
+    wg16_prio<3, T_>();
     if (K2 == 16) {
         radix16_inv_pk(a);
     } else {                                                            // register 8 h + k2 <- bin t + T (h + 2 k2); two radix-8 inverse DFTs over k2 -> n0
@@ -225,7 +231,7 @@ __device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, co
 #pragma unroll
         for (int n = 0; n < 8; n++) { a[n] = lo[n]; a[8 + n] = hi[n]; }
     }
-    wg16_prio<4>();
+    wg16_prio<4, T_>();
 #pragma unroll
     for (int h = 0; h < 16 / K2; h++)
 #pragma unroll
@@ -233,18 +239,18 @@ __device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, co
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) a[k] = S[T_ * k + t];                  // thread (n0 = g, k0 = c), reg k1
-    wg16_prio<3>();
+    wg16_prio<3, T_>();
 #pragma unroll
     for (int k = 1; k < 16; k++) a[k] = pk::cmul(a[k], TWBF[(k - 1) * K2 + g]);
     radix16_inv_pk(a);
     pk::c32 *Sg = S + 16 * T_ + 256 * g;                                // second half of the scratch (fp32 elements are half the size)
-    wg16_prio<4>();
+    wg16_prio<4, T_>();
 #pragma unroll
     for (int n = 0; n < 16; n++) Sg[16 * c + (n ^ c)] = a[n];           // thread (n0, k0 = c), reg n1 = n
     wave_sync();
 #pragma unroll
     for (int k = 0; k < 16; k++) a[k] = Sg[16 * k + (c ^ k)];           // thread (n0, n1 = c), reg k0
-    wg16_prio<3>();
+    wg16_prio<3, T_>();
     {
         const pk::c32 w3 = pk::cmul(tw.w1, tw.w2), w5 = pk::cmul(tw.w4, tw.w1), w6 = pk::cmul(tw.w4, tw.w2), w7 = pk::cmul(tw.w4, w3);
         a[1] = pk::cmul(a[1], tw.w1); a[2] = pk::cmul(a[2], tw.w2); a[3] = pk::cmul(a[3], w3); a[4] = pk::cmul(a[4], tw.w4);
@@ -546,7 +552,7 @@ resident_top:
         const TwA twa{p.tw64[(2 * tsq) & (N - 1)], p.tw64[(4 * tsq) & (N - 1)], p.tw64[(8 * tsq) & (N - 1)], p.tw64[(16 * tsq) & (N - 1)]};   // W_4096^{ts k}, k = 1, 2, 4, 8
         const double2 wl = p.tw64[tq];                                      // split pass: W_N^{tq + 256 r} = wl * W_32^r
         // ---- Hann (pv:55), pack, forward FFT in fp64 (the split pass's 1/2 is folded into the window, exact) ----
-        wg16_prio<0>();
+        wg16_prio<0, T>();
         double2 z[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) z[r] = double2{(double)(raw[r].x * hw[r].x), (double)(raw[r].y * hw[r].y)};
@@ -562,7 +568,7 @@ resident_top:
         // ---- split pass in conjugate pairs: thread tq owns the pairs k = tq + 256 r, r < 8: XA[r] = X[k], XB[r] = X[M - k]; thread 0 also the self-paired bin M/2.
         //      The partner values Z[M - k] are rows 8..15 of other threads -> LDS ----
         float2 XA[8], XB[8], xHf{0.f, 0.f};
-        wg16_prio<2>();
+        wg16_prio<2, T>();
         {
 #pragma unroll
             for (int r = 8; r < 16; r++) S64[tq + T * (r - 8)] = z[r];
@@ -649,6 +655,7 @@ resident_top:
             }
         }
         bool nonfinite = false;
+        wg16_prio<6, T>();
         // ---- peak flags on bins 16 tq .. 16 tq + 15 (pv:95-116) ----
         int lastown[16], firstown[16];
         int last_in, first_in;
@@ -781,6 +788,7 @@ resident_top:
         if (tq == 0) Y[M] = float2{0.f, 0.f};
         const bool need_res = upper_end > H;
         __syncthreads();
+        wg16_prio<7, T>();
         // ---- shiftPeaks (pv:119-173) ----
         {
             if (pf >= 1.0) {
@@ -898,6 +906,7 @@ resident_top:
             for (int r = 0; r < 16; r++) { const int k = tq + T * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
             if (tq == 0) { p.dbg_Y[2 * M] = Y[M].x; p.dbg_Y[2 * M + 1] = Y[M].y; }
         }
+        wg16_prio<8, T>();
         // ---- c2r pre-pass in conjugate pairs, packed fp32 (see pv_wg_kernel.hip): thread tq computes k = tq + 256 r, r < 8, and hands Z[M - k] over through LDS ----
         pk::c32 zi[16];
         {
@@ -939,7 +948,7 @@ resident_top:
         const TwAf twaf{pk::c32{f1.x, f1.y}, pk::c32{f2.x, f2.y}, pk::c32{f4.x, f4.y}, pk::c32{f8.x, f8.y}};
         fft_wg16_inv_pk<T>(zi, reinterpret_cast<pk::c32 *>(smem), twaf, TWBF, tqi);
         // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
-        wg16_prio<5>();
+        wg16_prio<5, T>();
         {
             const bool emit_out = (m >= emit_v);
             float2 fr[16];
