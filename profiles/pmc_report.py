@@ -55,6 +55,11 @@ def kernel_stats(d):
 
 def main():
     d, tag = sys.argv[1], sys.argv[2]
+    # a directory that is not the output of profiles/run_profile_r0N.sh must not overwrite the committed summaries (it happened: a stale scratch directory of the same name)
+    need = ["trace", "pmc_1", "hbm_c2_FETCH_SIZE", "hbm_c5_WRITE_SIZE", "hbm_calib_FETCH_SIZE", "wg_c5_1"]
+    missing = [n for n in need if not os.path.isdir(os.path.join(d, n))]
+    if missing:
+        sys.exit(f"{d}: not a run_profile directory (missing {', '.join(missing)}); nothing written")
     out = []
     # ---- kernel trace ----
     st = kernel_stats(os.path.join(d, "trace"))
