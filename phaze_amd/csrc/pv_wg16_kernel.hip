@@ -99,24 +99,39 @@ __device__ __forceinline__ void radix16_fwd(double2 (&a)[16])
         b[4 * j + 2] = csub(s02, s13);
         b[4 * j + 3] = double2{d02.x - d13.y, d02.y + d13.x};          // d02 + j d13
     }
-    // W16^{j q} = exp(-2 pi j (j q) / 16)
+    // W16^{j q} = exp(-2 pi j (j q) / 16); the four eighth-root twiddles (e = 2, 6) keep their factor h for the second stage, which folds it into its additions (u = b W / h)
     b[5] = dmul(b[5], double2{c, -s});                                  // e = 1
-    b[6] = double2{(b[6].x + b[6].y) * h, (b[6].y - b[6].x) * h};      // e = 2: (h, -h)
+    const double2 u6{b[6].x + b[6].y, b[6].y - b[6].x};                 // e = 2: (1 - j) b
     b[7] = dmul(b[7], double2{s, -c});                                  // e = 3
-    b[9] = double2{(b[9].x + b[9].y) * h, (b[9].y - b[9].x) * h};      // e = 2
+    const double2 u9{b[9].x + b[9].y, b[9].y - b[9].x};                 // e = 2
     b[10] = double2{b[10].y, -b[10].x};                                 // e = 4: -j
-    b[11] = double2{(b[11].y - b[11].x) * h, -(b[11].x + b[11].y) * h}; // e = 6: (-h, -h)
+    const double2 u11{b[11].y - b[11].x, -(b[11].x + b[11].y)};         // e = 6: (-1 - j) b
     b[13] = dmul(b[13], double2{s, -c});                                // e = 3
-    b[14] = double2{(b[14].y - b[14].x) * h, -(b[14].x + b[14].y) * h}; // e = 6
+    const double2 u14{b[14].y - b[14].x, -(b[14].x + b[14].y)};         // e = 6
     b[15] = dmul(b[15], double2{-c, s});                                // e = 9
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const double2 x0 = b[q], x1 = b[4 + q], x2 = b[8 + q], x3 = b[12 + q];
-        const double2 s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = csub(x1, x3);
-        a[q] = cadd(s02, s13);
-        a[q + 4] = double2{d02.x + d13.y, d02.y - d13.x};
-        a[q + 8] = csub(s02, s13);
-        a[q + 12] = double2{d02.x - d13.y, d02.y + d13.x};
+    {   // q = 0: no twiddles
+        const double2 s02 = cadd(b[0], b[8]), d02 = csub(b[0], b[8]), s13 = cadd(b[4], b[12]), d13 = csub(b[4], b[12]);
+        a[0] = cadd(s02, s13); a[4] = double2{d02.x + d13.y, d02.y - d13.x}; a[8] = csub(s02, s13); a[12] = double2{d02.x - d13.y, d02.y + d13.x};
+    }
+    {   // q = 1: x2 = h u9
+        const double2 x0 = b[1], x1 = b[5], x3 = b[13];
+        const double2 s02{__fma_rn(h, u9.x, x0.x), __fma_rn(h, u9.y, x0.y)}, d02{__fma_rn(-h, u9.x, x0.x), __fma_rn(-h, u9.y, x0.y)};
+        const double2 s13 = cadd(x1, x3), d13 = csub(x1, x3);
+        a[1] = cadd(s02, s13); a[5] = double2{d02.x + d13.y, d02.y - d13.x}; a[9] = csub(s02, s13); a[13] = double2{d02.x - d13.y, d02.y + d13.x};
+    }
+    {   // q = 2: x1 = h u6, x3 = h u14
+        const double2 s02 = cadd(b[2], b[10]), d02 = csub(b[2], b[10]);
+        const double2 S{u6.x + u14.x, u6.y + u14.y}, D{u6.x - u14.x, u6.y - u14.y};
+        a[2] = double2{__fma_rn(h, S.x, s02.x), __fma_rn(h, S.y, s02.y)};
+        a[10] = double2{__fma_rn(-h, S.x, s02.x), __fma_rn(-h, S.y, s02.y)};
+        a[6] = double2{__fma_rn(h, D.y, d02.x), __fma_rn(-h, D.x, d02.y)};    // d02 - j h D
+        a[14] = double2{__fma_rn(-h, D.y, d02.x), __fma_rn(h, D.x, d02.y)};   // d02 + j h D
+    }
+    {   // q = 3: x2 = h u11
+        const double2 x0 = b[3], x1 = b[7], x3 = b[15];
+        const double2 s02{__fma_rn(h, u11.x, x0.x), __fma_rn(h, u11.y, x0.y)}, d02{__fma_rn(-h, u11.x, x0.x), __fma_rn(-h, u11.y, x0.y)};
+        const double2 s13 = cadd(x1, x3), d13 = csub(x1, x3);
+        a[3] = cadd(s02, s13); a[7] = double2{d02.x + d13.y, d02.y - d13.x}; a[11] = csub(s02, s13); a[15] = double2{d02.x - d13.y, d02.y + d13.x};
     }
 }
 
