@@ -18,7 +18,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   "cpu_baseline": the CPU oracle (a C port of the reference JS, kind "port") timed on ONE host core on a bounded sample of the same
                   workload, plus the estimate for the reference's own Node.js path (ratio measured by tools/time_reference.js)
   "configs":      one short measured line per other BASELINE config (C3, a C4 share, C5 with its pitch sweep, the 8-channel form of the
-                  headline shape) and "latency_us": the streaming-quantum histogram of C5, "latency_us_headline_shape": mono 1024/256 per quantum (launch form / resident kernel) -- N = 1 only, skipped with --no-extras
+                  headline shape) and "latency_us": the streaming-quantum histogram of C5 (one launch per quantum; "latency_us_resident": the same on the resident kernel), "latency_us_headline_shape": mono 1024/256 per quantum (launch form / resident kernel) -- N = 1 only, skipped with --no-extras
 """
 import argparse
 import hashlib
@@ -644,6 +644,7 @@ def main():
             hb.append(nl)
         out["host_buffer_configs"] = hb
         out["latency_us"] = latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True)
+        out["latency_us_resident"] = latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True, flags=32)   # the same stream on the resident kernel (PV_FLAG_PERSISTENT_STREAM)
         # the headline shape as a stream: launch per quantum, and on the resident kernel (opt-in flag of the C ABI / `processorOptions.flags` in Node)
         out["latency_us_headline_shape"] = {"launch": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, fs=48000.0),
                                             "resident": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, flags=32, fs=48000.0)}
