@@ -1,23 +1,24 @@
-// pv_wg16_kernel.hip -- N = 8192 (BASELINE configs[4]), hop in {N/8, N/4, N/2, N}: a workgroup of FOUR wavefronts per frame chain, 16 packed complex elements per
-// thread, TWO workgroups per CU.
+// pv_wg16_kernel.hip -- N = 8192 and N = 4096 (BASELINE configs[4] and [3]), hop in {N/8, N/4, N/2, N}: N/32 threads per frame chain (four / two wavefronts), 16 packed
+// complex elements per thread, two / four workgroups per CU.
 //
 // pv_wg_kernel.hip holds an 8192-point frame in eight waves of eight elements: 157 KB of LDS and 250 VGPRs, i.e. ONE workgroup per CU whose waves move in lock-step
-// between ~13 barriers -- LDS phases idle the VALUs and arithmetic phases idle the LDS (VALU 53 % busy).  Here the same pipeline runs with
-//   * 16 elements per thread, T = 256 threads: M = N/2 = 4096 = 16 * 16 * 16 -- three radix-16 passes with ONE cross-wave exchange and one exchange inside a wave
-//     per transform (the eight-wave kernel: four passes, two cross-wave exchanges and a register transpose), no LDS twiddle table for the per-thread pass
+// between 13 barriers -- LDS phases idle the VALUs and arithmetic phases idle the LDS (VALU 53 % busy).  Here the same pipeline runs with
+//   * 16 elements per thread, T = N/32 threads: M = N/2 = 16 * 16 * K2 (K2 = T/16 = 16 or 8) -- three in-register passes with ONE cross-wave exchange and one exchange
+//     inside a wave per transform (the eight-wave kernel: four passes, two cross-wave exchanges and a register transpose), no LDS twiddle table for the per-thread pass
 //     (W^{ts k} = products of four loaded powers), no shift table in LDS (a thread computes the shifts of its own 16 candidate bins);
-//   * 80 KB of LDS and <= 256 VGPRs: two workgroups per CU, each SIMD holds one wave of either, and the parked time of one workgroup (barriers, exchanges) is the
-//     other's issue time.
+//   * 80 KB (40 KB at N = 4096) of LDS and <= 256 VGPRs without spills: two (four) workgroups per CU, each SIMD holds one wave of either, and the parked time of one
+//     workgroup (barriers, exchanges) is another's issue time -- given the phase priorities below.
 //
-// Layout.  z[n] = xw[2n] + j xw[2n+1], n = n0 + 16 n1 + 256 n2.  Thread t = n1 + 16 n0 (n1 in the low four LANE bits, n0 = wave and lane bits 5..4), register r = n2:
-// thread t holds the complex elements ts + 256 r with ts = (t >> 4) + 16 (t & 15) -- the float2 at samples 2 ts + 512 r, i.e. the lanes of a load are 128 bytes
-// apart and the four waves together use every byte of a line (L2 merges; measured traffic in profiles/).  With k = k0 + 16 k1 + 256 k2:
-//   pass A over r = n2 -> k0, twiddle W_4096^{ts k0};  exchange inside groups of 16 lanes (register <-> low lane bits, XOR-swizzled, no barrier): registers n1
-//   pass B over n1 -> k1, twiddle W_256^{n0 k1};       cross-wave exchange (register <-> wave and lane bits 5..4): thread t' = k0 + 16 k1, registers n0
-//   pass C over n0 -> k2:  thread t', register r' <-> bin t' + 256 r'  -- the NATURAL bin order every stage between the transforms wants.
+// Layout.  z[n] = xw[2n] + j xw[2n+1], n = n0 + K2 n1 + 16 K2 n2.  Thread t = n1 + 16 n0 (n1 in the low four LANE bits, n0 = wave and lane bits 5..4), register r = n2:
+// thread t holds the complex elements ts + T r with ts = (t >> 4) + K2 (t & 15) -- the float2 at samples 2 ts + 2 T r, i.e. the lanes of a load are 128 (64) bytes apart
+// and the waves together use every byte of a line (plain loads and stores: L2 merges; measured traffic in profiles/hbm_traffic.json).  With k = k0 + 16 k1 + 256 k2:
+//   pass A over r = n2 -> k0, twiddle W_M^{ts k0};     exchange inside groups of 16 lanes (register <-> low lane bits, XOR-swizzled, no barrier): registers n1
+//   pass B over n1 -> k1, twiddle W_{M/16}^{n0 k1};    cross-wave exchange (register <-> wave and lane bits 5..4): thread t' = k0 + 16 (k1 mod K2), registers (k1 / K2, n0)
+//   pass C over n0 -> k2 (radix 16, or two radix-8 DFTs per thread at N = 4096):  thread t', register r' <-> bin t' + T r'  -- the NATURAL bin order every stage
+//   between the transforms wants.
 // The inverse runs the same passes backwards (C, cross-wave, twiddle, B, in-wave, twiddle, A) in packed fp32 and lands in the sample layout it started from.
 // Everything between the transforms is pv_wg_kernel's / pv_wave2k_kernel's pipeline (16 consecutive bins per thread in the padded magnitude / route layout);
-// reference citations are those of pv_kernels.hip / pv_wave_kernel.hip.
+// reference citations are those of pv_kernels.hip / pv_wave_kernel.hip.  DESIGN.md 3c has the measurements and the register story.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
