@@ -56,12 +56,17 @@ def synth_input(torch, nch, nsamples, device, seed):
 
 
 def csrc_sha16():
-    """Identity of the kernel sources: profiles/hbm_traffic.json entries are only reported for the build they were measured on."""
+    """Identity of the kernel sources: profiles/hbm_traffic.json entries are only reported for the build they were measured on.  Comments and blank lines do not count
+    (a reworded comment is not another build)."""
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "phaze_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
+            src = open(os.path.join(d, f), "r", encoding="utf-8", errors="replace").read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            code = [re.sub(r"//.*$", "", line).rstrip() for line in src.split("\n")]
+            h.update(f.encode() + b"\0" + "\n".join(l for l in code if l.strip()).encode())
     return h.hexdigest()[:16]
 
 
