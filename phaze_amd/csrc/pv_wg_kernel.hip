@@ -1,4 +1,8 @@
-// pv_wg_kernel.hip -- register-resident frame pipeline for N = 2048, 4096, 8192 (BASELINE configs[2..4]).
+// pv_wg_kernel.hip -- register-resident frame pipeline for N = 2048, 4096, 8192 with EIGHT elements per thread.
+//
+// Its role since round 4: the hops below N/8 that go through an overlap-add ring in LDS (the reference's 2048/128 when the one-wave kernel is switched off, 4096/256 ...),
+// and -- under PV_FLAG_WORKGROUP_KERNEL -- the second implementation of the path the tests run every stream of N = 2048 / 4096 / 8192 through.  BASELINE's shapes run on
+// pv_wave2k_kernel.hip (N = 2048) and pv_wg16_kernel.hip (N = 4096, 8192: sixteen elements per thread, two / four workgroups per CU); this kernel ran N = 8192 until then.
 //
 // Generalisation of pv_wave_kernel_1024: one frame is held by G = N/1024 wavefronts (T = 64 G threads = one workgroup = one
 // frame chain), 8 packed complex elements per thread:
