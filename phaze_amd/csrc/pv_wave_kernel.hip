@@ -1042,8 +1042,8 @@ resident_top:
                 // (a frame with f >= 1 in a chain that also has frames below 1: disjoint regions, plain stores, each lane its own 8 bins)
                 auto scatter = [&](auto mode_tag) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) { const unsigned t = rt[i] & 0xFFFFu; ystore_if(t < (unsigned)H, t, rot_mode(mode_tag, rt[i], xs[i])); }
-                    { const unsigned t = rt512 & 0xFFFFu; ystore_if(t < (unsigned)H, t, rot_mode(mode_tag, rt512, xs512)); }
+                    for (int i = 0; i < 8; i++) { const unsigned t = rt[i] & 0xFFFFu; if (t < (unsigned)H) ystore(t, rot_mode(mode_tag, rt[i], xs[i])); }
+                    { const unsigned t = rt512 & 0xFFFFu; if (t < (unsigned)H) ystore(t, rot_mode(mode_tag, rt512, xs512)); }
                 };
                 if (tmod == 0) scatter(std::integral_constant<int, 0>{});
                 else if (tmod == N / 2) scatter(std::integral_constant<int, 2>{});
