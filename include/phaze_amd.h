@@ -46,8 +46,9 @@ typedef struct pv_handle pv_handle;
 /* Version of this header's binary interface (struct layouts + semantics).  pv_abi_version() returns the value the LIBRARY was built with;
  * 2 = round 3: pv_config carries its own size, unknown pv_config.flags bits are rejected, PV_FLAG_PERSISTENT_STREAM;
  * 3 = round 4: pv_host_alloc / pv_host_free (page-locked host buffers: pv_process_batch pipelines them), PV_FLAG_TEST_NO_HDP_FLUSH,
- *     pv_reset_channels_part + PV_FLAG_HOST_CHANNEL_BOOKKEEPING. */
-#define PV_ABI_VERSION 3
+ *     pv_reset_channels_part + PV_FLAG_HOST_CHANNEL_BOOKKEEPING;
+ * 4 = round 5: PV_FLAG_FP64_FORWARD, pv_forward_stats. */
+#define PV_ABI_VERSION 4
 
 /* Construction options.  Replaces `new PhaseVocoderProcessor(options)` (phase-vocoder.js:24-43,
  * ola-processor.js:7-34).  The reference hard-codes fft_size 2048 (phase-vocoder.js:6) and hop 128
@@ -100,7 +101,14 @@ enum {
     PV_FLAG_HOST_CHANNEL_BOOKKEEPING = 128, /* pv_process / pv_process_begin do NOT reset the channel state when nch differs from the previous call: the host does the
                                   * reference's bookkeeping itself with pv_reset_channels_part -- input and output buffers separately, ola-processor.js:38-52 -- as
                                   * phaze_amd/node/phase-vocoder.js does for hosts whose outputs do not mirror their inputs */
-    PV_FLAG_ALL = 255            /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
+    PV_FLAG_FP64_FORWARD = 256,  /* every frame's forward transform in fp64, as the reference computes it (realTransform on JS doubles, bundle:306-508) and as every
+                                  * round-4 kernel did.  Default since round 5: the forward transform runs in packed fp32 FIRST and the peak decisions
+                                  * (phase-vocoder.js:95-116) are taken on its magnitudes wherever every comparison they rest on lies outside a guard band around the fp32
+                                  * transform's error; a frame with a comparison inside the band re-runs its forward transform in fp64 (pv_forward_stats counts them).
+                                  * Decisions are the reference's either way; the source spectrum of a guarded frame carries the fp32 transform's rounding
+                                  * (~1e-7 of the frame's rms instead of a correctly rounded fp64 value).  Which frames fall back depends on their own samples only:
+                                  * chunked, call-split, streaming and batch runs of one stream still agree bit for bit */
+    PV_FLAG_ALL = 511            /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
 };
 
 typedef struct pv_info {
@@ -130,6 +138,11 @@ PV_API int pv_get_info(const pv_handle *h, pv_info *out);
 /* Number of HIP devices this process can create handles on (pv_config.device_id in [0, count)): what a host needs to shard streams over the
  * GPUs of a node (stream s -> device s mod count; streams are independent processors, nothing is exchanged). */
 PV_API int pv_device_count(int32_t *out);
+
+/* Forward-transform statistics since the handle was created (or last reset): frames whose forward transform an fp32-first kernel instance computed, and how many
+ * of them re-ran it in fp64 because a peak decision (phase-vocoder.js:95-116) was within the fp32 transform's error (PV_FLAG_FP64_FORWARD).  Frames that run on
+ * instances without the fp32-first path are not counted.  Synchronizes the handle's stream.  Either pointer may be NULL; reset != 0 zeroes the counters. */
+PV_API int pv_forward_stats(pv_handle *h, uint64_t *frames, uint64_t *fallbacks, int32_t reset);
 
 /* ---- state ------------------------------------------------------------------------------------- */
 /* Zero history + accumulators of ALL channels and set timeCursor = 0 (a freshly constructed processor). */

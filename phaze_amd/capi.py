@@ -22,6 +22,7 @@ EXPORTS = [
     "pv_get_time_cursor", "pv_set_time_cursor", "pv_process", "pv_process_batch", "pv_process_batch_device",
     "pv_set_stream", "pv_synchronize", "pv_debug_frame", "pv_export_state", "pv_import_state", "pv_abi_version",
     "pv_process_begin", "pv_process_end", "pv_device_count", "pv_host_alloc", "pv_host_free", "pv_reset_channels_part",
+    "pv_forward_stats",
 ]
 
 
@@ -40,13 +41,14 @@ def make_config(fft_size, hop_size, max_channels=1, max_hops=1, device_id=0, fra
     return _Config(C.sizeof(_Config), fft_size, hop_size, max_channels, max_hops, device_id, frames_per_chunk, flags)
 
 
-ABI_VERSION = 3          # PV_ABI_VERSION of include/phaze_amd.h this binding was written against (checked at load time)
+ABI_VERSION = 4          # PV_ABI_VERSION of include/phaze_amd.h this binding was written against (checked at load time)
 
 
 # pv_config.flags (include/phaze_amd.h): explicit A/B switches; the library reads no environment variables
 FLAG_GENERIC_KERNEL, FLAG_STREAM_COPY, FLAG_WORKGROUP_KERNEL, FLAG_STREAM_EVENT_WAIT, FLAG_STREAM_PINNED_INPUT, FLAG_PERSISTENT_STREAM = 1, 2, 4, 8, 16, 32
 FLAG_TEST_NO_HDP_FLUSH = 64      # test hook (tests/test_gpu_stream_forms.py)
 FLAG_HOST_CHANNEL_BOOKKEEPING = 128
+FLAG_FP64_FORWARD = 256          # every forward transform in fp64 (the round-4 kernels); default: fp32 first, fp64 only where a peak decision is in doubt
 STATE_HISTORY, STATE_ACCUMULATOR = 1, 2
 
 
@@ -116,6 +118,7 @@ def load_library():
     L.pv_device_count.argtypes = [C.POINTER(C.c_int32)]
     L.pv_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.pv_host_free.argtypes = [vp]
+    L.pv_forward_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
     L.pv_abi_version.argtypes = []
     if L.pv_abi_version() != ABI_VERSION:
         raise PvError(PV_ERR_ARGUMENT, f"{_LIB_PATH} has PV_ABI_VERSION {L.pv_abi_version()}, this binding expects {ABI_VERSION}: rebuild the library")
@@ -301,6 +304,12 @@ class PhaseVocoder:
 
     def synchronize(self):
         self._check(self._L.pv_synchronize(self._h))
+
+    def forward_stats(self, reset=False):
+        """(frames whose forward transform an fp32-first instance computed, frames of those that re-ran it in fp64) since creation / the last reset."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._L.pv_forward_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return int(a.value), int(b.value)
 
     # -- test tap --
     def debug_frame(self, ch, block, pitch):

@@ -42,6 +42,8 @@ struct pv_handle {
     float *d_stage_in, *d_stage_out, *d_pitch;   // host-buffer batch staging
     unsigned *d_chain_list;                      // N = 1024 batch launches: chain classes (pv_launch_wave), 2 + 2 * chain_list_cap words
     long chain_list_cap;
+    bool fwd64;                                  // PV_FLAG_FP64_FORWARD: every frame's forward transform in fp64 (the round-4 kernels)
+    unsigned long long *d_fwd_stats;             // 128 x {frames computed by an fp32-first instance, frames of those that fell back to fp64} (pv_forward_stats)
     hipStream_t s_in, s_out;                     // pipelined host-buffer batch: H2D of piece k+1 || kernel of piece k || D2H of piece k-1 (created on first use)
     hipEvent_t ev_in[kMaxPieces], ev_k[kMaxPieces];
     bool pipe_ready;
@@ -166,6 +168,7 @@ int launch_chain(pv_handle *h, const float *d_in, float *d_out, int ch0, int nch
     p.t0_mod_n = (int)(h->time_cursor & (int64_t)(h->N - 1));
     p.tw64 = h->d_tw64; p.tw32 = h->d_tw32; p.hann = h->d_hann;
     p.dbg_ch = -1; p.dbg_frame = -1;
+    p.fwd64 = h->fwd64 ? 1 : 0; p.fwd_stats = h->d_fwd_stats;
     if (done_seq) { p.done = h->d_done; p.done_seq = done_seq; }
 #ifdef PV_STAMPS
     p.stamps = h->d_stamps;
@@ -361,6 +364,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     h->frames_per_chunk_cfg = cfg->frames_per_chunk;
     h->active_nch = -1;
     h->host_channels = (cfg->flags & PV_FLAG_HOST_CHANNEL_BOOKKEEPING) != 0;
+    h->fwd64 = (cfg->flags & PV_FLAG_FP64_FORWARD) != 0;
     {
         const bool generic = (cfg->flags & PV_FLAG_GENERIC_KERNEL) != 0;      // explicit A/B switch (tests, measurements); no environment is read
         h->use_wave = pv_wave_supported(log2n, hop) && !generic;
@@ -410,6 +414,8 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     for (int k = 0; k < N; k++) hann[k] *= 0.5f;
     CHK(hipMemcpy(h->d_hann + N, hann.data(), sizeof(float) * N, hipMemcpyHostToDevice));
 
+    CHK(hipMalloc(&h->d_fwd_stats, sizeof(unsigned long long) * 256));
+    CHK(hipMemset(h->d_fwd_stats, 0, sizeof(unsigned long long) * 256));
     const size_t state = sizeof(float) * (size_t)maxch * (size_t)(h->L > 0 ? h->L : 1);
     for (int i = 0; i < 2; i++) {
         CHK(hipMalloc(&h->d_hist[i], state));
@@ -512,6 +518,7 @@ int pv_destroy(pv_handle *h)
     for (int i = 0; i < 2; i++) { (void)hipFree(h->d_hist[i]); (void)hipFree(h->d_acc[i]); }
     (void)hipFree(h->d_stage_in); (void)hipFree(h->d_stage_out); (void)hipFree(h->d_pitch);
     if (h->d_chain_list) (void)hipFree(h->d_chain_list);
+    (void)hipFree(h->d_fwd_stats);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_done) (void)hipHostFree((void *)h->h_done);
     if (h->h_ctl) { if (h->resident_bar) (void)hipFree((void *)h->h_ctl); else (void)hipHostFree((void *)h->h_ctl); }
@@ -638,6 +645,22 @@ int pv_synchronize(pv_handle *h)
     { const int rs_ = resident_stop(h); if (rs_ != PV_OK) return rs_; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PV_OK;
+}
+
+int pv_forward_stats(pv_handle *h, uint64_t *frames, uint64_t *fallbacks, int32_t reset)
+{
+    if (!live(h)) return PV_ERR_DESTROYED;
+    { const int rs_ = resident_stop(h); if (rs_ != PV_OK) return rs_; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    unsigned long long st[256];
+    HIPCHK(h, hipMemcpy(st, h->d_fwd_stats, sizeof st, hipMemcpyDeviceToHost));
+    uint64_t a = 0, b = 0;
+    for (int i = 0; i < 128; i++) { a += st[2 * i]; b += st[2 * i + 1]; }
+    if (frames) *frames = a;
+    if (fallbacks) *fallbacks = b;
+    if (reset) HIPCHK(h, hipMemset(h->d_fwd_stats, 0, sizeof st));
     return PV_OK;
 }
 

@@ -45,6 +45,10 @@ struct PvKernelParams {
     // its own instance of the kernel.  Null: chains are numbered directly (streaming quantum, test tap)
     const unsigned *chain_list;
     const unsigned *chain_count;
+    // round 5: the one-wave kernels take the peak decisions on a packed-fp32 forward transform behind a guard band and re-run a frame's forward transform in fp64
+    // only when a decision is in doubt (pv_wave_kernel.hip: F32).  fwd64 != 0: every frame at the reference's width (PV_FLAG_FP64_FORWARD: the round-4 kernels).
+    int fwd64;
+    unsigned long long *fwd_stats;   // 128 x {frames computed by an F32 instance, frames of those that fell back}; null: not counted
     unsigned *stamps;         // measurement builds only (-DPV_STAMPS, tools/exp_headline.sh): [chain][16] accumulated s_memtime deltas per phase
 };
 

@@ -25,12 +25,16 @@ PV_PK2(add_conj, "v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]")                        
 PV_PK2(sub_conj, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]")                                             // a - conj(b)
 PV_PK2(neg_add_j, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]")  // -a + j b = (-ax - by, -ay + bx)
 PV_PK2(mul, "v_pk_mul_f32 %0, %1, %2")                                                               // component-wise
+PV_PK2(mul_conj, "v_pk_mul_f32 %0, %1, %2 neg_hi:[0,1]")                                             // conj of the component-wise product: (ax bx, -ay by)
+PV_PK2(conj_add_j, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]") // conj(a + j b) = (ax - by, -ay - bx)
 PV_PK2(mul_ay, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]")                  // (-ay by, ay bx)
 PV_PK3(fma_ax, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]")                       // (ax bx + cx, ax by + cy)
 PV_PK3(fma, "v_pk_fma_f32 %0, %1, %2, %3")                                                           // a * b + c component-wise
 PV_PK3(fnma, "v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]")                            // -a * b + c
 PV_PK3(fma_j, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]")         // c + j (a * b)  (b = (s, s))
 PV_PK3(fnma_j, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]")        // c - j (a * b)  (b = (s, s))
+PV_PK3(conj_fma_j, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,1]")   // conj(c + j (a * b)) = (cx - ay s, -cy - ax s)  (b = (s, s))
+PV_PK3(fms, "v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]")                             // a * b - c component-wise
 PV_PK3(fma_addj, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_lo:[0,0,1]")      // a * b + j c
 PV_PK3(fma_conj_subj, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_hi:[1,0,0]") // conj(a * b - j c) = (ax bx + cy, -ay by + cx)  (b = (s, s))
 

@@ -135,9 +135,12 @@ __device__ __forceinline__ void fft512_wave(typename v2t<T>::type (&a)[8], typen
 // the minimum for 512 bytes (checked with tools/lds_layout_check.py pairs).
 constexpr int TPP = 72;
 // REGT1 = false keeps transpose 1 in LDS: needed when `l` is NOT the physical lane id (pv_wave2k_kernel relabels the lanes of odd frames at hop 128).
-template <bool REGT1 = true, typename ST = NoStamp>
+// FWDPH = true: the instance that serves as the fp32 FORWARD transform (round 5: FFT(z) = conj(IFFT(conj z)), the conjugations folded into the window product
+// and the split pass) -- same arithmetic, the forward phases' priorities.
+template <bool REGT1 = true, typename ST = NoStamp, bool FWDPH = false>
 __device__ __forceinline__ void fft512_wave_inv_pk(pk::c32 (&a)[8], pk::c32 *S, const v4f *TW1F4, const v4f *TW2F4, int l, ST st = ST{})
 {
+    constexpr int PHX = FWDPH ? PH_FX : PH_IX, PHA = FWDPH ? PH_FA : PH_IA, PHP3 = FWDPH ? PH_FP3 : PH_IP3;
     constexpr bool MATH = !(PV_ABL & 4), XPOSE = !(PV_ABL & 8);
     const int lh = l >> 3, ll = l & 7;
     v4f *S4 = reinterpret_cast<v4f *>(S);
@@ -160,14 +163,14 @@ __device__ __forceinline__ void fft512_wave_inv_pk(pk::c32 (&a)[8], pk::c32 *S, 
 #pragma unroll
         for (int k = 0; k < 8; k++) a[k] = pk::c32{__uint_as_float(w[k][0]), __uint_as_float(w[k][1])};
     } else if (XPOSE) {
-        pv_prio(PH_IX);
+        pv_prio(PHX);
 #pragma unroll
         for (int j = 0; j < 4; j++) S4[j * TPP + l] = v4f{a[2 * j].x, a[2 * j].y, a[2 * j + 1].x, a[2 * j + 1].y};
         wave_sync();
 #pragma unroll
         for (int n = 0; n < 8; n++) a[n] = S[2 * ((lh >> 1) * TPP + 8 * n + ll) + (lh & 1)];
         wave_sync();
-        pv_prio(PH_IA);
+        pv_prio(PHA);
     }
     st(1);
     if (MATH) {
@@ -182,14 +185,14 @@ __device__ __forceinline__ void fft512_wave_inv_pk(pk::c32 (&a)[8], pk::c32 *S, 
     st(2);
     // transpose 2: [reg k1][lane (k0,n0)] -> [reg n0][lane (k1,k0)], skewed columns
     if (XPOSE) {
-        pv_prio(PH_IX);
+        pv_prio(PHX);
 #pragma unroll
         for (int j = 0; j < 4; j++) S4[j * TPP + lh * 8 + ((ll + lh) & 7)] = v4f{a[2 * j].x, a[2 * j].y, a[2 * j + 1].x, a[2 * j + 1].y};
         wave_sync();
 #pragma unroll
         for (int n = 0; n < 8; n++) a[n] = S[2 * ((lh >> 1) * TPP + ll * 8 + ((n + ll) & 7)) + (lh & 1)];
         wave_sync();
-        pv_prio(PH_IP3);
+        pv_prio(PHP3);
     }
     st(3);
     if (MATH) pk::radix8_inv(a);

@@ -502,6 +502,43 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void scatter_claims_1024(Rou
     }
 }
 
+// ---- fp32-first forward transform: the guard band (round 5) ----
+// An F32 instance takes the peak decisions (pv:95-116) on the |X|^2 of a PACKED-fp32 forward transform wherever that is provably the same decision the
+// reference's fp64 transform gives.  Error model of the fp32 path, in the amplitude A = |X| of a bin: |A32 - A64| <= E_abs + r A, E_abs = kappa eps rms|X|
+// (rounding of the early passes, spread over the spectrum) and r = a few eps (the last pass and the magnitude itself, proportional to the bin).  A comparison
+// c > n of two magnitudes is safe while |A_c - A_n| > G + rho eps (A_c + A_n) / 2... -- evaluated without square roots on the magnitudes themselves:
+//     ambiguous  <=>  (c - n)^2 <= (c + n) (K + R (c + n)),     K = 2 G^2 = 8 g^2 eps^2 S  (G = g eps rms|X|, rms|X|^2 = 4 S, S = sum |z|^2 of the pre-halved samples),
+//                                                              R = rho^2 eps^2
+// which is the exact condition when A_c = A_n (the only place it matters) and errs on the ambiguous side elsewhere.  Only the comparison of a bin with the LARGEST
+// of its four neighbours decides whether it is a peak, so one test per bin.  A frame with one ambiguous bin re-runs its forward transform in fp64.
+// g = 32: sixteen times the rms error of the transform per compared bin (measured 1.0e-7 rms|X| = 1.7 eps; tools/study_fp32_decisions.py), rho = 64.
+#ifndef PV_F32_REGT1
+#define PV_F32_REGT1 true       // transpose 1 of the fp32 forward FFT in registers (false: through LDS; A/B builds)
+#endif
+#ifndef PV_GUARD_G
+#define PV_GUARD_G 32.0f
+#endif
+#ifndef PV_GUARD_RHO
+#define PV_GUARD_RHO 64.0f
+#endif
+constexpr float GUARD_EPS = 5.9604644775390625e-8f;                       // 2^-24
+constexpr float GUARD_CK = 8.0f * PV_GUARD_G * PV_GUARD_G * GUARD_EPS * GUARD_EPS;
+constexpr float GUARD_R = PV_GUARD_RHO * PV_GUARD_RHO * GUARD_EPS * GUARD_EPS;
+
+// sum of v over the 64 lanes, the same bits in every lane (one fixed order of additions: the class of a frame must not depend on who computes it)
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+#define PV_DPP_ADD(ctrl, rowmask) v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), ctrl, rowmask, 0xF, false))
+    PV_DPP_ADD(0x111, 0xF);       // row_shr:1
+    PV_DPP_ADD(0x112, 0xF);       // row_shr:2
+    PV_DPP_ADD(0x114, 0xF);       // row_shr:4
+    PV_DPP_ADD(0x118, 0xF);       // row_shr:8: lane 15 of every row holds the row's sum
+    PV_DPP_ADD(0x142, 0xA);       // row_bcast:15 into rows 1 and 3
+    PV_DPP_ADD(0x143, 0xC);       // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+#undef PV_DPP_ADD
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
 // AUX = true: test-tap instance (pv_debug_frame); the production instance carries no tap code.
 // RESIDENT = true: streaming instance that stays on the GPU (PV_FLAG_PERSISTENT_STREAM): after its quantum a wave polls the control block in pinned host memory
@@ -514,9 +551,10 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void scatter_claims_1024(Rou
 // no route table, and the stash is what the above-Nyquist residue is computed from anyway: an f < 1 frame makes three dependent LDS round trips in
 // its scatter where round 3 made five.  (One instance that chooses per frame was tried first: the register allocator does not keep the two flows
 // apart, at 168 VGPRs the f >= 1 flow then reloads its source bins from scratch memory.)
-template <int S_ROWS, bool AUX, bool RESIDENT = false, bool SPREAD = false>
+template <int S_ROWS, bool AUX, bool RESIDENT = false, bool SPREAD = false, bool F32 = false>
 __global__ __launch_bounds__(64 * (RESIDENT ? RES_WAVES : WAVES), RESIDENT ? 1 : PV_WAVES_PER_SIMD) PV_NO_DS_MERGE void pv_wave_kernel_1024(const PvKernelParams p)
 {
+    static_assert(!F32 || (!FP64 && !AUX), "the fp32-first forward transform is a product path: neither the reference-width flavour nor the tap instance");
     constexpr int WGW = RESIDENT ? RES_WAVES : WAVES;                    // waves per workgroup of this instance
     constexpr int N = 1024, M = 512, H = 513;
     constexpr int HOP = 128 * S_ROWS, R = N / HOP, LROWS = 8 - S_ROWS;    // LROWS rows of carried accumulator
@@ -681,103 +719,185 @@ resident_top:
     stamps.start();
     const unsigned stamp_t0 = stamps.prev;
 #endif
+    [[maybe_unused]] unsigned n_fallback = 0;                            // F32: frames of this chain that re-ran their forward transform in fp64
     for (int m = first_frame; m < last_out; ++m) {
         const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));   // k-rate pitchFactor (pv:47), wave-uniform
         const double pf = (double)pfm;
         const int tmod = (int)(((long)t0_mod_n + (long)m * HOP) & (N - 1));
         const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
 
-        pv_prio(PH_FA);
-        // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded into the table (exact) ----
-        double2 z[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) { const v2f xw = v2f{raw[r].x, raw[r].y} * hw[r]; z[r] = double2{(double)xw.x, (double)xw.y}; }
-
-#ifdef PV_STAMPS
-        fft512_wave<double, false>(z, S64, TW1, TW2, l, [&](int id) { if (id & 1) stamps.mark(id); else stamps.mark(id, true); });
-#else
-        fft512_wave<double, false>(z, S64, TW1, TW2, l);
-#endif
-
-        // ---- split pass in conjugate pairs: with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved),
-        //      X[k] = E - j W^k O and X[512-k] = conj(E + j W^k O).  Lane l owns the pairs k = l + 64 r, r < 4 (partner value from lane
-        //      64-l, register 7-r), i.e. bins XA[r] = X[l + 64 r] and XB[r] = X[512 - l - 64 r]; lane 0 also owns the self-paired bin 256.
-        pv_prio(PH_SPLITX);
         float2 XA[4], XB[4], x256f{0.f, 0.f};                              // fp32 copy of the spectrum: the only thing the shift needs after the decisions
         [[maybe_unused]] double2 XAd[4], XBd[4], x256d{0.0, 0.0};         // (fp64 flavour: the spectrum itself)
-        {
-            // partner values through the (now free) transpose scratch: rows 4..7 written lane-contiguous, read back reversed.  Element
-            // 512 - k of the pair k = l + 64 r sits at (3 - r) * 64 + (64 - l) for every lane (lane 0: 64 (8 - r), its own register
-            // 8 - r); half the LDS cycles of sixteen bpermutes.  (l = 0, r = 0) reads one element past the rows: replaced below.
+        // ---- forward transform at the reference's width: Hann, pack, 512-point complex FFT in fp64, split pass, |X|^2 -> MAG, the spectrum rounded to fp32 -> XA / XB
+        //      (and the transposed stash).  The only forward transform of the !F32 instances; what an F32 instance falls back to when a decision is in doubt ----
+        auto forward64 = [&]() {
+            pv_prio(PH_FA);
+            // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded into the table (exact) ----
+            double2 z[8];
 #pragma unroll
-            for (int r = 4; r < 8; r++) S64[(r - 4) * 64 + l] = z[r];
-            wave_sync();
-            pv_prio(PH_SPLITM);
+            for (int r = 0; r < 8; r++) { const v2f xw = v2f{raw[r].x, raw[r].y} * hw[r]; z[r] = double2{(double)xw.x, (double)xw.y}; }
+
+#ifdef PV_STAMPS
+            fft512_wave<double, false>(z, S64, TW1, TW2, l, [&](int id) { if (id & 1) stamps.mark(id); else stamps.mark(id, true); });
+#else
+            fft512_wave<double, false>(z, S64, TW1, TW2, l);
+#endif
+
+            // ---- split pass in conjugate pairs: with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved),
+            //      X[k] = E - j W^k O and X[512-k] = conj(E + j W^k O).  Lane l owns the pairs k = l + 64 r, r < 4 (partner value from lane
+            //      64-l, register 7-r), i.e. bins XA[r] = X[l + 64 r] and XB[r] = X[512 - l - 64 r]; lane 0 also owns the self-paired bin 256.
+            pv_prio(PH_SPLITX);
+            {
+                // partner values through the (now free) transpose scratch: rows 4..7 written lane-contiguous, read back reversed.  Element
+                // 512 - k of the pair k = l + 64 r sits at (3 - r) * 64 + (64 - l) for every lane (lane 0: 64 (8 - r), its own register
+                // 8 - r); half the LDS cycles of sixteen bpermutes.  (l = 0, r = 0) reads one element past the rows: replaced below.
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                double2 xa, xb;
-                {
-                    const double2 zm = S64[(3 - r) * 64 + 64 - l];
-                    const double2 E{z[r].x + zm.x, z[r].y - zm.y};
-                    const double2 O{z[r].x - zm.x, z[r].y + zm.y};
-                    const double2 WO = cmul(wl, mul_w16<double, false>(O, r));     // W_1024^{l+64r} = W^l * W_16^r
-                    xa = double2{E.x + WO.y, E.y - WO.x};
-                    xb = double2{E.x - WO.y, -(E.y + WO.x)};
-                    if (r == 0 && l == 0) {
-                        // Z[0] is pre-halved: X[0] = 2(zr + zi), X[512] = 2(zr - zi), both real (bundle:447-508 keep Im = 0)
-                        xa = double2{2.0 * (z[0].x + z[0].y), 0.0};
-                        xb = double2{2.0 * (z[0].x - z[0].y), 0.0};
-                    }
-                }
-                // ---- |X|^2 -> f32 (pv:82-92) for the neighbour tests, and the spectrum itself, rounded to fp32 (the only thing the shift needs after
-                //      the decisions), into the transposed stash: the lanes that take the decisions (8 consecutive bins each) also move the bins ----
-                MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
-                MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
-                XA[r] = float2{(float)xa.x, (float)xa.y};
-                XB[r] = float2{(float)xb.x, (float)xb.y};
-                if constexpr (FP64) { XAd[r] = xa; XBd[r] = xb; }
-                if (dbg) {
-                    const int ka = l + 64 * r, kb = 512 - ka;
-                    p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
-                    p.dbg_X[2 * kb] = xb.x; p.dbg_X[2 * kb + 1] = xb.y;
-                }
-            }
-            if (l == 0) {
-                const double2 x256{2.0 * z[4].x, -2.0 * z[4].y};              // k = 256 pairs with itself: W^256 = -j, X = 2 conj(Z)
-                MAG[4 + 256] = (float)(x256.x * x256.x + x256.y * x256.y);
-                x256f = float2{(float)x256.x, (float)x256.y};
-                if constexpr (FP64) x256d = x256;
-                if (dbg) { p.dbg_X[2 * 256] = x256.x; p.dbg_X[2 * 256 + 1] = x256.y; }
-            }
-            if constexpr (!SPREAD) {
-                // strided-order addresses of the transposed stash: bin l + 64 r at ystr + 64 r, bin 512 - l - 64 r at ystr_m + 64 (3 - r).  Formed HERE from an
-                // opaque copy of the lane id (four instructions per frame): as loop invariants they would live in registers across the forward FFT, the
-                // register peak of the kernel, and push other addresses into scratch
-                unsigned ystr, ystr_m;
-                { int lq = l; asm volatile("" : "+v"(lq)); ystr = yslot_bytes((unsigned)lq); ystr_m = yslot_bytes((unsigned)(512 - 192 - lq)); }
+                for (int r = 4; r < 8; r++) S64[(r - 4) * 64 + l] = z[r];
+                wave_sync();
+                pv_prio(PH_SPLITM);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    *reinterpret_cast<float2 *>(XSb + ystr + 64 * r) = XA[r];
-                    *reinterpret_cast<float2 *>(XSb + ystr_m + 64 * (3 - r)) = XB[r];
+                    double2 xa, xb;
+                    {
+                        const double2 zm = S64[(3 - r) * 64 + 64 - l];
+                        const double2 E{z[r].x + zm.x, z[r].y - zm.y};
+                        const double2 O{z[r].x - zm.x, z[r].y + zm.y};
+                        const double2 WO = cmul(wl, mul_w16<double, false>(O, r));     // W_1024^{l+64r} = W^l * W_16^r
+                        xa = double2{E.x + WO.y, E.y - WO.x};
+                        xb = double2{E.x - WO.y, -(E.y + WO.x)};
+                        if (r == 0 && l == 0) {
+                            // Z[0] is pre-halved: X[0] = 2(zr + zi), X[512] = 2(zr - zi), both real (bundle:447-508 keep Im = 0)
+                            xa = double2{2.0 * (z[0].x + z[0].y), 0.0};
+                            xb = double2{2.0 * (z[0].x - z[0].y), 0.0};
+                        }
+                    }
+                    // ---- |X|^2 -> f32 (pv:82-92) for the neighbour tests, and the spectrum itself, rounded to fp32 (the only thing the shift needs after
+                    //      the decisions), into the transposed stash: the lanes that take the decisions (8 consecutive bins each) also move the bins ----
+                    MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                    MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                    XA[r] = float2{(float)xa.x, (float)xa.y};
+                    XB[r] = float2{(float)xb.x, (float)xb.y};
+                    if constexpr (FP64) { XAd[r] = xa; XBd[r] = xb; }
+                    if (dbg) {
+                        const int ka = l + 64 * r, kb = 512 - ka;
+                        p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
+                        p.dbg_X[2 * kb] = xb.x; p.dbg_X[2 * kb + 1] = xb.y;
+                    }
                 }
-                if (l == 0) *reinterpret_cast<float2 *>(XSb + 256) = x256f;                           // slot(256) = 32
-            }
-        }
-        // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change.  BEFORE the prefetch is issued: the
-        //      table build is a call, a function entry waits for vmcnt(0), and with the next frame's rows in flight that is an exposed HBM round trip in
-        //      every frame whose f differs from the last one (a pitch sweep: -3 % per launch) ----
-        {
-            const unsigned pfb = __float_as_uint(pfm);
-            if (!psh_valid || pfb != psh_key) { psh_key = pfb; psh_valid = true; build_shift_table_1024(pfm, wave_off, l); }
-        }
-        // slide the window: the rows the next frame adds are issued here and land behind the shift + inverse FFT
+                if (l == 0) {
+                    const double2 x256{2.0 * z[4].x, -2.0 * z[4].y};              // k = 256 pairs with itself: W^256 = -j, X = 2 conj(Z)
+                    MAG[4 + 256] = (float)(x256.x * x256.x + x256.y * x256.y);
+                    x256f = float2{(float)x256.x, (float)x256.y};
+                    if constexpr (FP64) x256d = x256;
+                    if (dbg) { p.dbg_X[2 * 256] = x256.x; p.dbg_X[2 * 256 + 1] = x256.y; }
+                }
+                if constexpr (!SPREAD) {
+                    // strided-order addresses of the transposed stash: bin l + 64 r at ystr + 64 r, bin 512 - l - 64 r at ystr_m + 64 (3 - r).  Formed HERE from an
+                    // opaque copy of the lane id (four instructions per frame): as loop invariants they would live in registers across the forward FFT, the
+                    // register peak of the kernel, and push other addresses into scratch
+                    unsigned ystr, ystr_m;
+                    { int lq = l; asm volatile("" : "+v"(lq)); ystr = yslot_bytes((unsigned)lq); ystr_m = yslot_bytes((unsigned)(512 - 192 - lq)); }
 #pragma unroll
-        for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
-        {
-            const int mn = (m + 1 < last_out) ? m + 1 : m;                 // the last frame of a chain re-reads its own rows (unused): no branch
-            load_rows(&raw[8 - S_ROWS], S_ROWS, 8 - S_ROWS, mn);
-            pf_next = pitch_row[mn];
-        }
+                    for (int r = 0; r < 4; r++) {
+                        *reinterpret_cast<float2 *>(XSb + ystr + 64 * r) = XA[r];
+                        *reinterpret_cast<float2 *>(XSb + ystr_m + 64 * (3 - r)) = XB[r];
+                    }
+                    if (l == 0) *reinterpret_cast<float2 *>(XSb + 256) = x256f;                           // slot(256) = 32
+                }
+            }
+        };
+        // ---- fp32-first forward transform (round 5; F32 instances).  The peak decisions need the |X|^2 of an fp64 spectrum only where two magnitudes that are compared
+        //      lie within the error of an fp32 transform of each other.  So: Hann, pack, 512-point FFT and split pass in PACKED fp32 (half the issue cycles of the fp64
+        //      form), a guard band around every comparison the decisions rest on (below, at the flags), and the fp64 transform above only for frames with a comparison
+        //      inside its band -- a wave-uniform branch, one frame per wave, no divergence.  A frame's class (guarded / fallen back) is a function of its own samples
+        //      only, so chunked / call-split / resident runs still agree bit for bit.  The forward FFT is the inverse instance on conjugated data: FFT(z) = conj(IFFT(conj z)),
+        //      the first conjugation folded into the window product, the second into the split pass: with Zc = conj(Z), E' = Zc[k] + conj(Zc[512-k]), O' = Zc[k] - conj(Zc[512-k]),
+        //      T = conj(W^k) O':  X[k] = conj(E' + j T), X[512-k] = E' - j T.
+        //      Returns the absolute part K of the frame's guard band (0: the frame is outside the guarded range -- silent, denormal-small, non-finite or absurdly
+        //      large input -- and takes the fp64 transform unconditionally). ----
+        [[maybe_unused]] auto forward32 = [&]() -> float {
+            pv_prio(PH_FA);
+            pk::c32 zc[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) zc[r] = pk::mul_conj(pk::c32{raw[r].x, raw[r].y}, hw[r]);       // conj(z), z pre-halved like the fp64 form's
+            // frame energy S = sum |z|^2 over the wave: Parseval gives the mean of |X|^2 over the N bins = 4 S, the scale of the transform's rounding error
+            pk::c32 e2 = pk::mul(zc[0], zc[0]);
+#pragma unroll
+            for (int r = 1; r < 8; r++) e2 = pk::fma(zc[r], zc[r], e2);
+            const float S = wave_sum_f32(e2.x + e2.y);
+#ifdef PV_STAMPS
+            auto st_fwd = [&](int id) { if (id & 1) stamps.mark(id); else stamps.mark(id, true); };
+            fft512_wave_inv_pk<PV_F32_REGT1, decltype(st_fwd), true>(zc, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l, st_fwd);
+#else
+            fft512_wave_inv_pk<PV_F32_REGT1, NoStamp, true>(zc, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l);
+#endif
+            pv_prio(PH_SPLITX);
+            {
+                pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem);           // partner rows 4..7, read back reversed (as in the fp64 form: (l = 0, r = 0) reads one past, replaced below)
+#pragma unroll
+                for (int r = 4; r < 8; r++) XCH[(r - 4) * 64 + l] = zc[r];
+                wave_sync();
+                pv_prio(PH_SPLITM);
+                constexpr float ISC = 1.0f / SC;                            // wlfs carries the c2r scale SC (a power of two): taken out again inside the FMAs, exact
+                const pk::c32 isc{ISC, ISC};
+                pk::c32 zm[4];                                              // all four partner values first: read one by one, each read queues behind the magnitude
+                                                                            // stores of the pair before it (the compiler cannot tell the arrays apart)
+#pragma unroll
+                for (int r = 0; r < 4; r++) zm[r] = XCH[(3 - r) * 64 + 64 - l];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const pk::c32 E = pk::add_conj(zc[r], zm[r]), O = pk::sub_conj(zc[r], zm[r]);
+                    const pk::c32 T = pk::cmul(mul_w16_inv_pk(O, r), wlfs);                 // SC conj(W^{l + 64 r}) O'
+                    pk::c32 xa = pk::conj_fma_j(T, isc, E), xb = pk::fnma_j(T, isc, E);
+                    if (r == 0 && l == 0) {
+                        xa = pk::c32{2.0f * (zc[0].x - zc[0].y), 0.f};        // X[0] = 2 (Re Z0 + Im Z0), X[512] = 2 (Re Z0 - Im Z0), Z0 = conj(Zc0)
+                        xb = pk::c32{2.0f * (zc[0].x + zc[0].y), 0.f};
+                    }
+                    MAG[4 + l + 64 * r] = __fmaf_rn(xa.y, xa.y, __fmul_rn(xa.x, xa.x));
+                    MAG[4 + 512 - l - 64 * r] = __fmaf_rn(xb.y, xb.y, __fmul_rn(xb.x, xb.x));
+                    XA[r] = float2{xa.x, xa.y};
+                    XB[r] = float2{xb.x, xb.y};
+                }
+                if (l == 0) {
+                    x256f = float2{2.0f * zc[4].x, 2.0f * zc[4].y};           // X[256] = 2 conj(Z[256]) = 2 Zc[256]
+                    MAG[4 + 256] = __fmaf_rn(x256f.y, x256f.y, __fmul_rn(x256f.x, x256f.x));
+                }
+                if constexpr (!SPREAD) {
+                    unsigned ystr, ystr_m;
+                    { int lq = l; asm volatile("" : "+v"(lq)); ystr = yslot_bytes((unsigned)lq); ystr_m = yslot_bytes((unsigned)(512 - 192 - lq)); }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        *reinterpret_cast<float2 *>(XSb + ystr + 64 * r) = XA[r];
+                        *reinterpret_cast<float2 *>(XSb + ystr_m + 64 * (3 - r)) = XB[r];
+                    }
+                    if (l == 0) *reinterpret_cast<float2 *>(XSb + 256) = x256f;
+                }
+            }
+            // guarded range: 1e-20 <= S < 1e12 (NaN fails both): inside it neither the band's products underflow to zero nor its squares overflow
+            return (S >= 1e-20f && S < 1e12f) ? GUARD_CK * S : 0.f;
+        };
+        auto shift_table = [&]() {
+            // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change.  BEFORE the prefetch is issued: the
+            //      table build is a call, a function entry waits for vmcnt(0), and with the next frame's rows in flight that is an exposed HBM round trip in
+            //      every frame whose f differs from the last one (a pitch sweep: -3 % per launch) ----
+            {
+                const unsigned pfb = __float_as_uint(pfm);
+                if (!psh_valid || pfb != psh_key) { psh_key = pfb; psh_valid = true; build_shift_table_1024(pfm, wave_off, l); }
+            }
+        };
+        auto slide_prefetch = [&]() {
+            // slide the window: the rows the next frame adds are issued here and land behind the shift + inverse FFT
+#pragma unroll
+            for (int r = 0; r < 8 - S_ROWS; r++) raw[r] = raw[r + S_ROWS];
+            {
+                const int mn = (m + 1 < last_out) ? m + 1 : m;                 // the last frame of a chain re-reads its own rows (unused): no branch
+                load_rows(&raw[8 - S_ROWS], S_ROWS, 8 - S_ROWS, mn);
+                pf_next = pitch_row[mn];
+            }
+        };
+        [[maybe_unused]] float guardK = 0.f;                               // F32: the absolute part of the guard band of this frame, 0 = frame out of the guarded range
+        if constexpr (!F32) { forward64(); shift_table(); slide_prefetch(); }
+        else { guardK = forward32(); shift_table(); }
         wave_sync();
         PV_STAMP(4);
         pv_prio(PH_PEAKS);
@@ -794,31 +914,70 @@ resident_top:
             // "greater than all four neighbours" (pv:100-110, `>=` rejects) becomes c > max(neighbours) with v_max3_u32 -- two instructions per
             // bin plus eight shared pair maxima, instead of four compares and three mask ANDs.
             unsigned mg[12];
+            unsigned pm[11], nm[8];                                         // pair maxima; nm[i] = the largest of the four neighbours of bin 8 l + i
+            v4u dq;
             // volatile vector loads: otherwise the optimizer re-pairs the 12 words into five misaligned ds_read2_b32 (8 LDS cycles each)
             typedef const volatile __attribute__((address_space(3))) v2u *lds_v2u;
             typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
-            const v2u q0 = *(lds_v2u)(&MAG[4 + 8 * l - 2]);
-            const v4u q1 = *(lds_v4u)(&MAG[4 + 8 * l]);
-            const v4u q2 = *(lds_v4u)(&MAG[4 + 8 * l + 4]);
-            const v2u q3 = *(lds_v2u)(&MAG[4 + 8 * l + 8]);
-            const v4u dq = *(lds_v4u)(&DSH[8 * l]);
-            if constexpr (!SPREAD) {
-                // the lane's source bins, natural order: bin 8 l + i sits in row i of the transposed stash, lane-contiguous (conflict-free ds_read_b64)
+            auto read_mags = [&]() {
+                const v2u q0 = *(lds_v2u)(&MAG[4 + 8 * l - 2]);
+                const v4u q1 = *(lds_v4u)(&MAG[4 + 8 * l]);
+                const v4u q2 = *(lds_v4u)(&MAG[4 + 8 * l + 4]);
+                const v2u q3 = *(lds_v2u)(&MAG[4 + 8 * l + 8]);
+                dq = *(lds_v4u)(&DSH[8 * l]);
+                if constexpr (!SPREAD) {
+                    // the lane's source bins, natural order: bin 8 l + i sits in row i of the transposed stash, lane-contiguous (conflict-free ds_read_b64)
 #pragma unroll
-                for (int i = 0; i < 8; i++) xs[i] = *reinterpret_cast<const float2 *>(XSb + 8 * l + 8 * YROW * i);
-                xs512 = *reinterpret_cast<const float2 *>(XSb + 512);       // slot(512) = 64; only lane 63 uses it
-            }
-            mg[0] = q0.x; mg[1] = q0.y; mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w;
-            mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w; mg[10] = q3.x; mg[11] = q3.y;
-            unsigned pm[11];
+                    for (int i = 0; i < 8; i++) xs[i] = *reinterpret_cast<const float2 *>(XSb + 8 * l + 8 * YROW * i);
+                    xs512 = *reinterpret_cast<const float2 *>(XSb + 512);   // slot(512) = 64; only lane 63 uses it
+                }
+                mg[0] = q0.x; mg[1] = q0.y; mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w;
+                mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w; mg[10] = q3.x; mg[11] = q3.y;
 #pragma unroll
-            for (int j = 3; j < 11; j++) pm[j] = max(mg[j], mg[j + 1]);
+                for (int j = 3; j < 11; j++) pm[j] = max(mg[j], mg[j + 1]);
+#pragma unroll
+                for (int i = 0; i < 8; i++) nm[i] = max(max(mg[i], mg[i + 1]), pm[i + 3]);
+            };
             bool fl[8];
+            auto take_flags = [&]() {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                // bin k = 8l + i, candidates are 2 <= k < H - 2 = 511 (pv:97-100): lane 0 drops i < 2, lane 63 drops i = 7
-                const bool in_range = (i < 2) ? (l != 0) : (i == 7) ? (l != 63) : true;
-                fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
+                for (int i = 0; i < 8; i++) {
+                    // bin k = 8l + i, candidates are 2 <= k < H - 2 = 511 (pv:97-100): lane 0 drops i < 2, lane 63 drops i = 7
+                    const bool in_range = (i < 2) ? (l != 0) : (i == 7) ? (l != 63) : true;
+                    fl[i] = in_range & (nm[i] < mg[i + 2]);
+                }
+            };
+            read_mags();
+            take_flags();
+            if constexpr (F32) {
+                // ---- the guard band (see GUARD_CK): is any candidate bin within the fp32 transform's error of the largest of its four neighbours? ----
+                bool amb = !(guardK > 0.f);                                 // frame outside the guarded range
+                {
+                    const pk::c32 KK{guardK, guardK}, RR{GUARD_R, GUARD_R};
+                    float tmin = 1.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int i = 2 * j;
+                        const pk::c32 c2{__uint_as_float(mg[i + 2]), __uint_as_float(mg[i + 3])}, n2{__uint_as_float(nm[i]), __uint_as_float(nm[i + 1])};
+                        const pk::c32 d2 = pk::sub(c2, n2), s2 = pk::add(c2, n2);
+                        pk::c32 t2 = pk::fms(d2, d2, pk::mul(pk::fma(s2, RR, KK), s2));      // (c - n)^2 - (c + n) (K + R (c + n)): <= 0 inside the band
+                        if (j == 0 && l == 0) t2 = pk::c32{1.f, 1.f};        // bins 0, 1 and 511 are no candidates (pv:97-100)
+                        if (j == 3 && l == 63) t2.y = 1.f;
+                        tmin = fminf(fminf(tmin, t2.x), t2.y);
+                    }
+                    amb |= tmin <= 0.f;
+                }
+                if (__builtin_expect(__any(amb), 0)) {
+                    // a decision of this frame is in doubt: the transform at the reference's width (raw[] and hw[] are untouched), its magnitudes, its flags
+                    // -- and its spectrum, rounded to fp32, as the frame's sources: a fallen-back frame is exactly a frame of the !F32 instances
+                    forward64();
+                    wave_sync();
+                    pv_prio(PH_PEAKS);
+                    read_mags();
+                    take_flags();
+                    n_fallback++;
+                }
+                slide_prefetch();
             }
             // Non-finite magnitudes (NaN / Inf samples in the window): the order of bit patterns is not the order of floats any more.  In the
             // reference every comparison with NaN fails to reject (pv:103,107), peaks appear at every other bin and the NaNs they move reach
@@ -1188,6 +1347,15 @@ resident_top:
     }
 #endif
 
+    if constexpr (F32) {
+        // forward-transform statistics (pv_forward_stats): {frames computed, frames that fell back to fp64}, spread over 128 slots so that the chains of a launch,
+        // which all end together, do not queue on one address
+        if (p.fwd_stats && l == 0) {
+            unsigned long long *st = p.fwd_stats + 2 * (chain & 127);
+            atomicAdd(st, (unsigned long long)(last_out - first_frame));
+            if (n_fallback) atomicAdd(st + 1, (unsigned long long)n_fallback);
+        }
+    }
     if (chunk == p.nchunks - 1) {
 #pragma unroll
         for (int r = 0; r < LROWS; r++) {
@@ -1248,11 +1416,16 @@ template <int S_ROWS, bool AUX>
 hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st, int spread, unsigned *list)
 {
     static std::atomic<bool> attr_done[16], attr_done_s[16];
-    auto k = pv_wave_kernel_1024<S_ROWS, AUX, false, false>;
-    auto ks = pv_wave_kernel_1024<S_ROWS, false, false, true>;
+    static std::atomic<bool> attr_done_f[16], attr_done_g[16];
+    // F32FWD: the product's instances take the peak decisions on an fp32 forward transform behind a guard band (F32; p.fwd64 = 0); with p.fwd64 != 0, in the tap
+    // instance and in the reference-width flavour every frame runs the fp64 forward transform (the round-4 kernels, bit for bit)
+    constexpr bool F32OK = !AUX && !FP64;
+    const bool f32 = F32OK && !p.fwd64;
+    auto k = f32 ? pv_wave_kernel_1024<S_ROWS, AUX, false, false, F32OK> : pv_wave_kernel_1024<S_ROWS, AUX, false, false, false>;
+    auto ks = f32 ? pv_wave_kernel_1024<S_ROWS, false, false, true, F32OK> : pv_wave_kernel_1024<S_ROWS, false, false, true>;
     {
-        hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_wave_lds_bytes());
-        if (e == hipSuccess && !AUX) e = pv_set_dynamic_lds_once(attr_done_s, reinterpret_cast<const void *>(ks), (int)pv_wave_lds_bytes());
+        hipError_t e = pv_set_dynamic_lds_once(f32 ? attr_done_g : attr_done, reinterpret_cast<const void *>(k), (int)pv_wave_lds_bytes());
+        if (e == hipSuccess && !AUX) e = pv_set_dynamic_lds_once(f32 ? attr_done_f : attr_done_s, reinterpret_cast<const void *>(ks), (int)pv_wave_lds_bytes());
         if (e != hipSuccess) return e;
     }
     PvKernelParams q = p;
@@ -1282,10 +1455,11 @@ hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_
 template <int S_ROWS>
 hipError_t launch_wave_resident(const PvKernelParams &p, int nslots, hipStream_t st)
 {
-    static std::atomic<bool> attr_done[16];
-    auto k = pv_wave_kernel_1024<S_ROWS, false, true>;
+    static std::atomic<bool> attr_done[16], attr_done_f[16];
+    const bool f32 = !FP64 && !p.fwd64;
+    auto k = f32 ? pv_wave_kernel_1024<S_ROWS, false, true, false, !FP64> : pv_wave_kernel_1024<S_ROWS, false, true, false, false>;
     {
-        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_wave_lds_bytes());
+        const hipError_t e = pv_set_dynamic_lds_once(f32 ? attr_done_f : attr_done, reinterpret_cast<const void *>(k), (int)pv_wave_lds_bytes());
         if (e != hipSuccess) return e;
     }
     PvKernelParams q = p;

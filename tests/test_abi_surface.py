@@ -60,7 +60,7 @@ def test_errors_without_device():
     cfg = capi.make_config(1024, 256)
     cfg.struct_size -= 4                                           # what a caller compiled against the round-2 header (no struct_size, 28 bytes) would pass
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_ARGUMENT and "struct_size" in L.pv_last_error(None).decode()
-    cfg = capi.make_config(1024, 256, flags=0x100)
+    cfg = capi.make_config(1024, 256, flags=0x200)
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_ARGUMENT and "flags" in L.pv_last_error(None).decode()
     try:
         import torch
@@ -101,9 +101,10 @@ def test_no_environment_switches_in_the_product_library():
 def test_flag_constants_match_the_header():
     """The ctypes binding's FLAG_* values are the header's PV_FLAG_* enumerators."""
     hdr = open(os.path.join(ROOT, "include", "phaze_amd.h")).read()
-    vals = dict(re.findall(r"(PV_FLAG_[A-Z_]+)\s*=\s*(\d+)", hdr))
+    vals = dict(re.findall(r"(PV_FLAG_[A-Z0-9_]+)\s*=\s*(\d+)", hdr))
     assert vals == {"PV_FLAG_GENERIC_KERNEL": "1", "PV_FLAG_STREAM_COPY": "2", "PV_FLAG_WORKGROUP_KERNEL": "4", "PV_FLAG_STREAM_EVENT_WAIT": "8", "PV_FLAG_STREAM_PINNED_INPUT": "16",
-                    "PV_FLAG_PERSISTENT_STREAM": "32", "PV_FLAG_TEST_NO_HDP_FLUSH": "64", "PV_FLAG_HOST_CHANNEL_BOOKKEEPING": "128", "PV_FLAG_ALL": "255"}
+                    "PV_FLAG_PERSISTENT_STREAM": "32", "PV_FLAG_TEST_NO_HDP_FLUSH": "64", "PV_FLAG_HOST_CHANNEL_BOOKKEEPING": "128", "PV_FLAG_FP64_FORWARD": "256", "PV_FLAG_ALL": "511"}
     import phaze_amd
     assert (phaze_amd.FLAG_GENERIC_KERNEL, phaze_amd.FLAG_STREAM_COPY, phaze_amd.FLAG_WORKGROUP_KERNEL, phaze_amd.FLAG_STREAM_EVENT_WAIT,
             phaze_amd.FLAG_STREAM_PINNED_INPUT) == (1, 2, 4, 8, 16)
+    assert phaze_amd.FLAG_FP64_FORWARD == 256
