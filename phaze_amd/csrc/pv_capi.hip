@@ -24,6 +24,8 @@ namespace {
 constexpr uint32_t kMagic = 0x50564d49u;   // 'PVMI'
 constexpr int kHdrFloats = 16;             // pinned staging header: [0] = pitchFactor
 constexpr int kMaxPieces = 16;             // pieces a pipelined host-buffer batch is cut into at most
+constexpr int kFwdStatWords = 1024;        // forward-transform statistics: [0, 256) 128 x {frames, fallbacks} (pv_forward_stats); the rest belongs to the validation
+                                           // build -DPV_FLIP_COUNT: [256, 512) 128 x {frames whose flags differ, of those not caught by the guard}, [512] largest q
 thread_local char g_create_err[256] = "";
 }  // namespace
 
@@ -414,8 +416,8 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     for (int k = 0; k < N; k++) hann[k] *= 0.5f;
     CHK(hipMemcpy(h->d_hann + N, hann.data(), sizeof(float) * N, hipMemcpyHostToDevice));
 
-    CHK(hipMalloc(&h->d_fwd_stats, sizeof(unsigned long long) * 256));
-    CHK(hipMemset(h->d_fwd_stats, 0, sizeof(unsigned long long) * 256));
+    CHK(hipMalloc(&h->d_fwd_stats, sizeof(unsigned long long) * kFwdStatWords));
+    CHK(hipMemset(h->d_fwd_stats, 0, sizeof(unsigned long long) * kFwdStatWords));
     const size_t state = sizeof(float) * (size_t)maxch * (size_t)(h->L > 0 ? h->L : 1);
     for (int i = 0; i < 2; i++) {
         CHK(hipMalloc(&h->d_hist[i], state));
@@ -660,9 +662,25 @@ int pv_forward_stats(pv_handle *h, uint64_t *frames, uint64_t *fallbacks, int32_
     for (int i = 0; i < 128; i++) { a += st[2 * i]; b += st[2 * i + 1]; }
     if (frames) *frames = a;
     if (fallbacks) *fallbacks = b;
-    if (reset) HIPCHK(h, hipMemset(h->d_fwd_stats, 0, sizeof st));
+    if (reset) HIPCHK(h, hipMemset(h->d_fwd_stats, 0, sizeof(unsigned long long) * kFwdStatWords));
     return PV_OK;
 }
+
+#ifdef PV_FLIP_COUNT
+// validation build only (tools/flip_count.py): out = {frames, guard-band fallbacks, frames whose fp32 and fp64 flags differ, of those NOT caught, largest q as float bits}
+PV_API int pv_exp_flip_stats(pv_handle *h, uint64_t *out)
+{
+    if (!live(h) || !out) return PV_ERR_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    unsigned long long st[kFwdStatWords];
+    HIPCHK(h, hipMemcpy(st, h->d_fwd_stats, sizeof st, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 10; k++) out[k] = 0;
+    for (int i = 0; i < 128; i++) { out[0] += st[2 * i]; out[1] += st[2 * i + 1]; out[2] += st[256 + 2 * i]; out[3] += st[257 + 2 * i]; }
+    for (int k = 0; k < 6; k++) out[4 + k] = st[512 + k] & 0xFFFFFFFFull;     // float bits: q_max; max over bins of (err - r eps A) / (eps rms|X|) and / (eps max|X|) for r = 8, 32; max of max|X| / rms|X|
+    return PV_OK;
+}
+#endif
 
 int pv_process_begin(pv_handle *h, const float *const *in, int32_t nch, int32_t nsamples, float pitch_factor)
 {

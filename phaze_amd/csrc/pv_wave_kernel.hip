@@ -504,39 +504,48 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void scatter_claims_1024(Rou
 
 // ---- fp32-first forward transform: the guard band (round 5) ----
 // An F32 instance takes the peak decisions (pv:95-116) on the |X|^2 of a PACKED-fp32 forward transform wherever that is provably the same decision the
-// reference's fp64 transform gives.  Error model of the fp32 path, in the amplitude A = |X| of a bin: |A32 - A64| <= E_abs + r A, E_abs = kappa eps rms|X|
-// (rounding of the early passes, spread over the spectrum) and r = a few eps (the last pass and the magnitude itself, proportional to the bin).  A comparison
-// c > n of two magnitudes is safe while |A_c - A_n| > G + rho eps (A_c + A_n) / 2... -- evaluated without square roots on the magnitudes themselves:
-//     ambiguous  <=>  (c - n)^2 <= (c + n) (K + R (c + n)),     K = 2 G^2 = 8 g^2 eps^2 S  (G = g eps rms|X|, rms|X|^2 = 4 S, S = sum |z|^2 of the pre-halved samples),
-//                                                              R = rho^2 eps^2
+// reference's fp64 transform gives.  Error law of the fp32 path, MEASURED on the GPU against the fp64 path of the same kernel (tools/flip_count.py, validation build
+// -DPV_FLIP_COUNT: 4.7e7 frames of eleven signal classes, 2.4e10 bins): in the amplitude A = |X| of a bin
+//     |A32 - A64|  <=  3.3 eps max|X|  +  (a few eps) A            (largest value seen; 1.0 ... 3.3 across the classes)
+// i.e. the absolute part scales with the LARGEST bin of the frame, not with the frame's rms: a weak bin is a cancellation of terms the size of the strong partial's,
+// and what the early passes round off at that size reaches every bin (the rms model of tools/study_fp32_decisions.py was refuted by that build: bins outside its band flipped).
+// A comparison c > n of two magnitudes is therefore safe while |A_c - A_n| > G + rho eps (A_c + A_n) / 2, G = g eps max|X| -- evaluated without square roots:
+//     ambiguous  <=>  (c - n)^2 <= (c + n) (K + R (c + n)),     K = 2 G^2 = 2 g^2 eps^2 max|X|^2,   R = rho^2 eps^2
 // which is the exact condition when A_c = A_n (the only place it matters) and errs on the ambiguous side elsewhere.  Only the comparison of a bin with the LARGEST
 // of its four neighbours decides whether it is a peak, so one test per bin.  A frame with one ambiguous bin re-runs its forward transform in fp64.
-// g = 32: sixteen times the rms error of the transform per compared bin (measured 1.0e-7 rms|X| = 1.7 eps; tools/study_fp32_decisions.py), rho = 64.
+// g = 10: three times the largest single-bin error seen, and three times the largest discrepancy that flipped a decision in that build (2.4 ... 3.2 eps max|X|
+// at g = 8, 12, 16: q_max of profiles/r05_flip_count.json); rho = 32.
 #ifndef PV_F32_REGT1
 #define PV_F32_REGT1 true       // transpose 1 of the fp32 forward FFT in registers (false: through LDS; A/B builds)
 #endif
 #ifndef PV_GUARD_G
-#define PV_GUARD_G 32.0f
+#define PV_GUARD_G 10.0f
 #endif
 #ifndef PV_GUARD_RHO
-#define PV_GUARD_RHO 64.0f
+#define PV_GUARD_RHO 32.0f
 #endif
 constexpr float GUARD_EPS = 5.9604644775390625e-8f;                       // 2^-24
-constexpr float GUARD_CK = 8.0f * PV_GUARD_G * PV_GUARD_G * GUARD_EPS * GUARD_EPS;
+constexpr float GUARD_CK = 2.0f * PV_GUARD_G * PV_GUARD_G * GUARD_EPS * GUARD_EPS;
 constexpr float GUARD_R = PV_GUARD_RHO * PV_GUARD_RHO * GUARD_EPS * GUARD_EPS;
+// The guarded range of the frame's largest magnitude M = max|X|^2.  The test works on SQUARED magnitudes -- fourth powers of amplitudes --, so a quiet frame's
+// products reach the denormal range: with d = c - n, s = c + n the last operation, fma(d, d, -(s (K + R s))), has the sign of the exact difference of its operands,
+// and for every bin with A >= G / 30 the subtrahend is >= G^4 / 225, which keeps 13 significant bits (>= 1.4e-41) once G >= 2.4e-10, i.e. max|X| >= 3.4e-4 (a
+// sine of amplitude 1.3e-6: -117 dB re full scale); bins below G / 30 come out ambiguous whatever is lost (d^2 <= s^2 <= s G^2 / 450 against s K = 2 s G^2).
+// Quieter frames, digital silence and non-finite input (whose bit pattern is the largest of all) take the fp64 transform; above 1e15 the squares could overflow.
+constexpr unsigned GUARD_M_MIN_BITS = 0x33F00000u /* 1.1e-7 */, GUARD_M_MAX_BITS = 0x58635FA9u /* 1e15 */;
 
-// sum of v over the 64 lanes, the same bits in every lane (one fixed order of additions: the class of a frame must not depend on who computes it)
-__device__ __forceinline__ float wave_sum_f32(float v)
+// largest of v over the 64 lanes (v_max_u32 with DPP: 0 is the identity), the same bits in every lane
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
-#define PV_DPP_ADD(ctrl, rowmask) v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), ctrl, rowmask, 0xF, false))
-    PV_DPP_ADD(0x111, 0xF);       // row_shr:1
-    PV_DPP_ADD(0x112, 0xF);       // row_shr:2
-    PV_DPP_ADD(0x114, 0xF);       // row_shr:4
-    PV_DPP_ADD(0x118, 0xF);       // row_shr:8: lane 15 of every row holds the row's sum
-    PV_DPP_ADD(0x142, 0xA);       // row_bcast:15 into rows 1 and 3
-    PV_DPP_ADD(0x143, 0xC);       // row_bcast:31 into rows 2 and 3: lane 63 holds the total
-#undef PV_DPP_ADD
-    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+#define PV_DPP_MAX(ctrl, rowmask) v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rowmask, 0xF, false))
+    PV_DPP_MAX(0x111, 0xF);       // row_shr:1
+    PV_DPP_MAX(0x112, 0xF);       // row_shr:2
+    PV_DPP_MAX(0x114, 0xF);       // row_shr:4
+    PV_DPP_MAX(0x118, 0xF);       // row_shr:8: lane 15 of every row holds the row's maximum
+    PV_DPP_MAX(0x142, 0xA);       // row_bcast:15 into rows 1 and 3
+    PV_DPP_MAX(0x143, 0xC);       // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+#undef PV_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
@@ -720,6 +729,9 @@ resident_top:
     const unsigned stamp_t0 = stamps.prev;
 #endif
     [[maybe_unused]] unsigned n_fallback = 0;                            // F32: frames of this chain that re-ran their forward transform in fp64
+#ifdef PV_FLIP_COUNT
+    unsigned n_flip = 0, n_uncaught = 0;
+#endif
     for (int m = first_frame; m < last_out; ++m) {
         const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));   // k-rate pitchFactor (pv:47), wave-uniform
         const double pf = (double)pfm;
@@ -813,18 +825,14 @@ resident_top:
         //      only, so chunked / call-split / resident runs still agree bit for bit.  The forward FFT is the inverse instance on conjugated data: FFT(z) = conj(IFFT(conj z)),
         //      the first conjugation folded into the window product, the second into the split pass: with Zc = conj(Z), E' = Zc[k] + conj(Zc[512-k]), O' = Zc[k] - conj(Zc[512-k]),
         //      T = conj(W^k) O':  X[k] = conj(E' + j T), X[512-k] = E' - j T.
-        //      Returns the absolute part K of the frame's guard band (0: the frame is outside the guarded range -- silent, denormal-small, non-finite or absurdly
+        //      Returns the absolute part K of the frame's guard band (0: the frame is outside the guarded range -- silent, below -117 dB, non-finite or absurdly
         //      large input -- and takes the fp64 transform unconditionally). ----
         [[maybe_unused]] auto forward32 = [&]() -> float {
+            float guard_k;
             pv_prio(PH_FA);
             pk::c32 zc[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) zc[r] = pk::mul_conj(pk::c32{raw[r].x, raw[r].y}, hw[r]);       // conj(z), z pre-halved like the fp64 form's
-            // frame energy S = sum |z|^2 over the wave: Parseval gives the mean of |X|^2 over the N bins = 4 S, the scale of the transform's rounding error
-            pk::c32 e2 = pk::mul(zc[0], zc[0]);
-#pragma unroll
-            for (int r = 1; r < 8; r++) e2 = pk::fma(zc[r], zc[r], e2);
-            const float S = wave_sum_f32(e2.x + e2.y);
 #ifdef PV_STAMPS
             auto st_fwd = [&](int id) { if (id & 1) stamps.mark(id); else stamps.mark(id, true); };
             fft512_wave_inv_pk<PV_F32_REGT1, decltype(st_fwd), true>(zc, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l, st_fwd);
@@ -840,6 +848,7 @@ resident_top:
                 pv_prio(PH_SPLITM);
                 constexpr float ISC = 1.0f / SC;                            // wlfs carries the c2r scale SC (a power of two): taken out again inside the FMAs, exact
                 const pk::c32 isc{ISC, ISC};
+                unsigned mmax = 0u;                                         // bit pattern of the largest |X|^2 this lane has seen
                 pk::c32 zm[4];                                              // all four partner values first: read one by one, each read queues behind the magnitude
                                                                             // stores of the pair before it (the compiler cannot tell the arrays apart)
 #pragma unroll
@@ -853,14 +862,18 @@ resident_top:
                         xa = pk::c32{2.0f * (zc[0].x - zc[0].y), 0.f};        // X[0] = 2 (Re Z0 + Im Z0), X[512] = 2 (Re Z0 - Im Z0), Z0 = conj(Zc0)
                         xb = pk::c32{2.0f * (zc[0].x + zc[0].y), 0.f};
                     }
-                    MAG[4 + l + 64 * r] = __fmaf_rn(xa.y, xa.y, __fmul_rn(xa.x, xa.x));
-                    MAG[4 + 512 - l - 64 * r] = __fmaf_rn(xb.y, xb.y, __fmul_rn(xb.x, xb.x));
+                    const float ma = __fmaf_rn(xa.y, xa.y, __fmul_rn(xa.x, xa.x)), mb = __fmaf_rn(xb.y, xb.y, __fmul_rn(xb.x, xb.x));
+                    MAG[4 + l + 64 * r] = ma;
+                    MAG[4 + 512 - l - 64 * r] = mb;
+                    mmax = max(max(mmax, __float_as_uint(ma)), __float_as_uint(mb));     // (|X|^2 >= 0: the order of the bit patterns; NaN / Inf come out on top)
                     XA[r] = float2{xa.x, xa.y};
                     XB[r] = float2{xb.x, xb.y};
                 }
                 if (l == 0) {
                     x256f = float2{2.0f * zc[4].x, 2.0f * zc[4].y};           // X[256] = 2 conj(Z[256]) = 2 Zc[256]
-                    MAG[4 + 256] = __fmaf_rn(x256f.y, x256f.y, __fmul_rn(x256f.x, x256f.x));
+                    const float m256 = __fmaf_rn(x256f.y, x256f.y, __fmul_rn(x256f.x, x256f.x));
+                    MAG[4 + 256] = m256;
+                    mmax = max(mmax, __float_as_uint(m256));
                 }
                 if constexpr (!SPREAD) {
                     unsigned ystr, ystr_m;
@@ -872,9 +885,12 @@ resident_top:
                     }
                     if (l == 0) *reinterpret_cast<float2 *>(XSb + 256) = x256f;
                 }
+                // the frame's largest magnitude M sets the absolute part of the guard band; outside [M_MIN, M_MAX) -- silence, very quiet, absurdly large or
+                // non-finite input -- K = 0 and the frame takes the fp64 transform unconditionally
+                const unsigned mb = wave_max_u32(mmax);
+                guard_k = (mb >= GUARD_M_MIN_BITS && mb < GUARD_M_MAX_BITS) ? GUARD_CK * __uint_as_float(mb) : 0.f;
             }
-            // guarded range: 1e-20 <= S < 1e12 (NaN fails both): inside it neither the band's products underflow to zero nor its squares overflow
-            return (S >= 1e-20f && S < 1e12f) ? GUARD_CK * S : 0.f;
+            return guard_k;
         };
         auto shift_table = [&]() {
             // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change.  BEFORE the prefetch is issued: the
@@ -967,6 +983,62 @@ resident_top:
                     }
                     amb |= tmin <= 0.f;
                 }
+#ifdef PV_FLIP_COUNT
+                // Validation build (tools/flip_count.py; never the product): EVERY frame also runs the fp64 transform, and the two flag sets are compared --
+                // frames whose flags differ at all, frames whose flags differ although the guard band did not ask for the fp64 transform (must be none), and
+                // over all candidate bins whose flag differs the largest q = (c - n)^2 / ((c + n) (K + R (c + n))): the guard calls a bin ambiguous for q <= 1,
+                // so sqrt(1 / q_max) is the factor by which the band could shrink before a flip escapes.
+                {
+                    unsigned f32bits = 0;
+                    float q[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        f32bits |= fl[i] ? (1u << i) : 0u;
+                        const float c = __uint_as_float(mg[i + 2]), n = __uint_as_float(nm[i]), d = c - n, sm = c + n;
+                        q[i] = (guardK > 0.f && sm > 0.f) ? (d * d) / (sm * (guardK + GUARD_R * sm)) : 0.f;
+                    }
+                    const bool amb_any = __any(amb);
+                    float a32[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) a32[i] = sqrtf(__uint_as_float(mg[i + 2]));
+                    forward64();
+                    wave_sync();
+                    pv_prio(PH_PEAKS);
+                    read_mags();
+                    take_flags();
+                    if (guardK > 0.f && p.fwd_stats) {
+                        // error of the fp32 transform in the amplitude of a bin beyond a relative allowance r eps A (r = 8, 32), against eps * rms|X| and eps * max|X| of the frame
+                        float e8 = 0.f, e32 = 0.f, amax = 0.f;
+                        float a64[8];
+#pragma unroll
+                        for (int i = 0; i < 8; i++) { a64[i] = sqrtf(__uint_as_float(mg[i + 2])); amax = fmaxf(amax, a64[i]); }
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const float e = fabsf(a32[i] - a64[i]);
+                            e8 = fmaxf(e8, e - 8.f * GUARD_EPS * a64[i]);
+                            e32 = fmaxf(e32, e - 32.f * GUARD_EPS * a64[i]);
+                        }
+                        for (int o = 32; o; o >>= 1) { e8 = fmaxf(e8, __shfl_xor(e8, o, 64)); e32 = fmaxf(e32, __shfl_xor(e32, o, 64)); amax = fmaxf(amax, __shfl_xor(amax, o, 64)); }
+                        if (l == 0) {
+                            atomicMax(reinterpret_cast<unsigned *>(p.fwd_stats + 514), __float_as_uint(e8 / (GUARD_EPS * amax)));
+                            atomicMax(reinterpret_cast<unsigned *>(p.fwd_stats + 516), __float_as_uint(e32 / (GUARD_EPS * amax)));
+                        }
+                    }
+                    unsigned diff = 0;
+                    float qmax = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const bool dif = (fl[i] ? 1u : 0u) != ((f32bits >> i) & 1u);
+                        diff |= dif ? 1u : 0u;
+                        if (dif) qmax = fmaxf(qmax, q[i]);
+                    }
+                    const bool flip_any = __any(diff != 0u);
+                    n_fallback += amb_any ? 1u : 0u;
+                    n_flip += flip_any ? 1u : 0u;
+                    n_uncaught += (flip_any && !amb_any) ? 1u : 0u;
+                    if (diff && p.fwd_stats) atomicMax(reinterpret_cast<unsigned *>(p.fwd_stats + 512), __float_as_uint(qmax));
+                }
+#else
                 if (__builtin_expect(__any(amb), 0)) {
                     // a decision of this frame is in doubt: the transform at the reference's width (raw[] and hw[] are untouched), its magnitudes, its flags
                     // -- and its spectrum, rounded to fp32, as the frame's sources: a fallen-back frame is exactly a frame of the !F32 instances
@@ -977,6 +1049,7 @@ resident_top:
                     take_flags();
                     n_fallback++;
                 }
+#endif
                 slide_prefetch();
             }
             // Non-finite magnitudes (NaN / Inf samples in the window): the order of bit patterns is not the order of floats any more.  In the
@@ -1354,6 +1427,10 @@ resident_top:
             unsigned long long *st = p.fwd_stats + 2 * (chain & 127);
             atomicAdd(st, (unsigned long long)(last_out - first_frame));
             if (n_fallback) atomicAdd(st + 1, (unsigned long long)n_fallback);
+#ifdef PV_FLIP_COUNT
+            if (n_flip) atomicAdd(st + 256, (unsigned long long)n_flip);
+            if (n_uncaught) atomicAdd(st + 257, (unsigned long long)n_uncaught);
+#endif
         }
     }
     if (chunk == p.nchunks - 1) {
