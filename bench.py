@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
-DTYPE = "f64+f32"           # forward FFT and peak decisions in f64 (decision parity), shift / inverse FFT / overlap-add in f32, I/O f32
+DTYPE = "f32+f64"           # forward FFT in f32 first, re-run in f64 for the frames where a peak decision is within the f32 transform's error (N = 1024; the other
+                            # sizes: f64 forward); shift / inverse FFT / overlap-add in f32, I/O f32
 
 
 def synth_input(torch, nch, nsamples, device, seed):
@@ -121,15 +122,28 @@ def cpu_baseline(fft, hop, pitch, x_prefix, what, target_seconds=12.0):
     return out
 
 
+def other_input(torch, kind, nch, nsamples, device, seed):
+    """The signal classes next to synth_input that bound the fp32-first forward transform from both sides: white noise (nothing falls back) and
+    two clean partials over a -80 dB floor (every frame falls back) -- tools/study_fp32_decisions.py's classes."""
+    g = torch.Generator(device=device)
+    g.manual_seed(4321 + seed)
+    if kind == "white":
+        return (torch.rand((nch, nsamples), device=device, generator=g) - 0.5).float()
+    i = torch.arange(nsamples, device=device, dtype=torch.float64)[None, :]
+    x = (0.5 * torch.sin(2 * 3.14159265358979 * i * 0.0123) + 0.3 * torch.sin(2 * 3.14159265358979 * i * 0.0931)).float().expand(nch, nsamples).clone()
+    x += (torch.rand((nch, nsamples), device=device, generator=g) * 2 - 1) * 1e-4
+    return x
+
+
 def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmup, label, local_rank, frames_per_chunk=0,
-            pitch_stride=0, ch_per_stream=1, parity_hops=0, seed=0, repeats=1, keep_prefix_hops=0):
+            pitch_stride=0, ch_per_stream=1, parity_hops=0, seed=0, repeats=1, keep_prefix_hops=0, flags=0, signal="bench"):
     """One workload: resident input, `warmup` + `steps` launches bracketed by HIP events on the launch stream.  Returns a dict."""
     import numpy as np
     from phaze_amd import shard
-    x = synth_input(torch, nch, T * hop, dev, seed)
+    x = synth_input(torch, nch, T * hop, dev, seed) if signal == "bench" else other_input(torch, signal, nch, T * hop, dev, seed)
     y = torch.empty_like(x)
     torch.cuda.synchronize()
-    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, device_id=local_rank, frames_per_chunk=frames_per_chunk)
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, device_id=local_rank, frames_per_chunk=frames_per_chunk, flags=flags)
     stream = torch.cuda.Stream(device=dev)        # a real (non-null) torch stream: the library launches on it, so HIP events bracket the kernels
     assert stream.cuda_stream != 0
     pv.set_stream(stream.cuda_stream)
@@ -157,6 +171,7 @@ def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmu
                 break                       # a few streams are enough for a spot check
         parity = float(np.sqrt(err2 / cnt))
     pv.reset()
+    pv.forward_stats(reset=True)
     regions = []
     with torch.cuda.stream(stream):
         for _ in range(warmup):
@@ -183,6 +198,7 @@ def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmu
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     elapsed, kernel_ms = regions[order[len(order) // 2]]
     info = pv.info()
+    fwd_frames, fwd_fallbacks = pv.forward_stats()            # frames whose forward transform ran fp32-first in the launches above, and how many of them re-ran it in fp64
     pv.close()
     frames = nch * T
     alg_bytes = frames * 2 * hop * 4                          # 2*hop*4 B per channel-frame
@@ -191,6 +207,7 @@ def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmu
     del x, y
     return {"label": label, "frames_per_step_rank": frames, "elapsed": elapsed, "kernel_ms": kernel_ms, "info": info,
             "alg_bytes": alg_bytes, "achieved_gbs": achieved, "parity": parity, "x_prefix": prefix,
+            "fallback_rate": (fwd_fallbacks / fwd_frames) if fwd_frames else None, "fp32_first_frames": fwd_frames,
             "regions_ms_per_step": [r[0] / steps * 1e3 for r in regions], "regions_kernel_ms": [r[1] for r in regions]}
 
 
@@ -549,7 +566,11 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE,
-            "dtype_note": "forward FFT and peak decisions in f64 (decision parity), shift / inverse FFT / overlap-add in f32, I/O f32",
+            "dtype_note": "N = 1024: forward FFT in packed f32 FIRST, peak decisions on its magnitudes where every comparison lies outside a guard band around the f32 transform's "
+                          "error (10 eps max|X|), else the frame's forward FFT again in f64 (fallback_rate; decisions are the reference's either way: 0 uncaught flips in "
+                          "4.7e7 doubly-computed frames, profiles/r05_flip_count.json); PV_FLAG_FP64_FORWARD = every forward FFT in f64 (the round-4 arithmetic, `configs`); "
+                          "other sizes: f64 forward; shift / inverse FFT / overlap-add in f32, I/O f32",
+            "fallback_rate": head["fallback_rate"],
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: " if is_c1 else "") + f"{chs} 48 kHz FFT={fft} hop={hop} pitchFactor={args.pitch}, throughput mode, "
                                    f"{nch} resident channel(s) x {T} hops per GPU per step",
@@ -560,7 +581,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": head["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["achieved_gbs"] / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": info["kernel_name"], "kernel_ms": head["kernel_ms"],
                          "algorithmic_bytes_per_launch": head["alg_bytes"], "traffic_source": traffic_src,
-                         "note": "algorithmic bytes = 2*hop*4 B per channel-frame; the kernel is issue/LDS-bound (fp64 FFT), see DESIGN.md"},
+                         "note": "algorithmic bytes = 2*hop*4 B per channel-frame; the kernel is bound by VALU issue, not by HBM (DESIGN.md section 4)"},
             "parity_rms_vs_oracle": head["parity"],
             "timed_regions": {"count": len(head["regions_kernel_ms"]), "steps_each": args.steps, "reported": "median region",
                               "ms_per_step": head["regions_ms_per_step"], "kernel_ms": head["regions_kernel_ms"],
@@ -594,7 +615,7 @@ def main():
             extras.append({"workload": workload, "value": r["frames_per_step_rank"] * steps / r["elapsed"], "unit": "frames/s", "steps": steps, "warmup": warm,
                            "ms_per_step": r["elapsed"] / steps * 1e3, "kernel_ms": r["kernel_ms"], "kernel": r["info"]["kernel_name"],
                            "roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS, "parity_rms_vs_oracle": r["parity"],
-                           "frames_per_chunk": r["info"]["frames_per_chunk"]})
+                           "frames_per_chunk": r["info"]["frames_per_chunk"], "fallback_rate": r["fallback_rate"]})
         T3 = 1 << 18
         add("C3", f"BASELINE configs[2]: stereo 48 kHz FFT=2048 hop=512 pitchFactor=f32(0.8), 2 ch x {T3} hops resident", 2048, 512, 2, T3,
             torch.full((T3,), 0.8, device=dev, dtype=torch.float32))
@@ -617,6 +638,16 @@ def main():
         sw = (0.5 + 1.5 * (torch.arange(T2, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
         add("sweep", f"headline shape with pitchFactor swept 0.5->2.0 per hop (period 64 hops): mono 48 kHz FFT=1024 hop=256, 1 ch x {T2} hops resident",
             1024, 256, 1, T2, sw, steps=12, warm=4)
+        # ---- the fp32-first forward transform from both sides (round 5): the same launch with every forward FFT in f64 (PV_FLAG_FP64_FORWARD: the round-4 kernels), on white
+        #      noise (no frame falls back) and on two clean partials over a -80 dB floor (EVERY frame falls back: the worst case) ----
+        p15 = torch.full((T2,), 1.5, device=dev, dtype=torch.float32)
+        add("fwd64", f"headline shape with PV_FLAG_FP64_FORWARD (every forward FFT in f64: the round-4 arithmetic): mono 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 1 ch x {T2} hops resident",
+            1024, 256, 1, T2, p15, steps=12, warm=4, flags=phaze_amd.FLAG_FP64_FORWARD)
+        add("white", f"headline shape on WHITE NOISE (uniform, amplitude 0.5): mono 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 1 ch x {T2} hops resident",
+            1024, 256, 1, T2, p15, steps=12, warm=4, signal="white")
+        add("tonal80", f"headline shape on TWO CLEAN PARTIALS over a -80 dB noise floor (worst case of the fp32-first forward transform: every frame re-runs it in f64): "
+            f"mono 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 1 ch x {T2} hops resident", 1024, 256, 1, T2, p15, steps=12, warm=4, signal="tonal80")
+        add("tonal80_fwd64", "the same signal with PV_FLAG_FP64_FORWARD", 1024, 256, 1, T2, p15, steps=12, warm=4, signal="tonal80", flags=phaze_amd.FLAG_FP64_FORWARD)
         # ---- the reference-width flavour of the headline kernel (never the product; build/exp/libphaze_fp64.so, `make -C phaze_amd/csrc fp64`): shifted spectrum,
         #      scatter, residue, c2r pass and inverse FFT in fp64 like the reference's JS doubles.  A library is chosen at import time, so it runs in a child ----
         flib = os.path.join(ROOT, "build", "exp", "libphaze_fp64.so")
