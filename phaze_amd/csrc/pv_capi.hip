@@ -675,9 +675,10 @@ PV_API int pv_exp_flip_stats(pv_handle *h, uint64_t *out)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     unsigned long long st[kFwdStatWords];
     HIPCHK(h, hipMemcpy(st, h->d_fwd_stats, sizeof st, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 10; k++) out[k] = 0;
+    for (int k = 0; k < 12; k++) out[k] = 0;
     for (int i = 0; i < 128; i++) { out[0] += st[2 * i]; out[1] += st[2 * i + 1]; out[2] += st[256 + 2 * i]; out[3] += st[257 + 2 * i]; }
     for (int k = 0; k < 6; k++) out[4 + k] = st[512 + k] & 0xFFFFFFFFull;     // float bits: q_max; max over bins of (err - r eps A) / (eps rms|X|) and / (eps max|X|) for r = 8, 32; max of max|X| / rms|X|
+    out[10] = st[600]; out[11] = st[601];       // frames the fp64 magnitudes prove to be class B; of those, frames the fp32 test calls class A (must be 0)
     return PV_OK;
 }
 #endif
@@ -1016,6 +1017,7 @@ PV_API int pv_exp_read_stamps(pv_handle *h, unsigned *dst, int nchains)
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(dst, h->d_stamps, sizeof(unsigned) * 16 * (size_t)nchains, hipMemcpyDeviceToHost));
+    out[10] = st[600]; out[11] = st[601];       // frames the fp64 magnitudes prove to be class B; of those, frames the fp32 test calls class A (must be 0)
     return PV_OK;
 }
 #endif

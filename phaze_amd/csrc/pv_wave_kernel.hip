@@ -548,6 +548,159 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// ---- which transform FIRST: a frame's class is fixed by its samples, the order of evaluation is not ----
+// A frame is of class B (fp64 spectrum and decisions) iff the guard test above, taken on the fp32 magnitudes, finds an ambiguous bin or the frame out of range;
+// else of class A (fp32 spectrum, fp32 decisions).  A chain whose frames keep coming out as class B (clean tonal material, 16-bit material, silence: every frame)
+// wastes the fp32 transform on each of them.  For such chains the kernel runs the fp64 transform FIRST and proves the class from the fp64 magnitudes alone where it
+// can: with |A32 - A64| <= E_b = 4 eps max|X| per bin (largest seen: 3.3) a pair that is within G_n = G - 2 E_b = 2 eps max|X| (relative part rho_n = rho - 16)
+// of each other in the fp64 magnitudes is within G in the fp32 ones -- class B for sure, the fp32 transform is never run.  A frame that the narrow test does not
+// decide takes the fp32 transform after all (and, if that says B, the fp64 one again).  The predictor is a counter per chain -- +1 for a frame that is class B
+// and provable, -3 otherwise, fp64 first from 4 up: the order pays off above three provable frames in four -- and only ever changes the ORDER: chunked / call-split / resident runs, whose chains meet a frame with different counters, still agree bit for bit.  The same margin (2^12 ulps) keeps a
+// largest magnitude near an end of the guarded range from being judged differently by the two transforms.
+constexpr float GUARD_GN = PV_GUARD_G - 8.0f, GUARD_RHON = PV_GUARD_RHO - 16.0f;
+static_assert(GUARD_GN > 0.f && GUARD_RHON > 0.f, "the guard band is too narrow to prove a frame's class from its fp64 magnitudes");
+constexpr float GUARD_CKN = 2.0f * GUARD_GN * GUARD_GN * GUARD_EPS * GUARD_EPS;
+constexpr float GUARD_RN = GUARD_RHON * GUARD_RHON * GUARD_EPS * GUARD_EPS;
+constexpr unsigned GUARD_M_SLACK = 1u << 12;
+constexpr int PRED_MAX = 7;                  // the per-chain counter saturates here ...
+constexpr unsigned PRED_WIDE = 4u;           // ... and from here on the chain runs the fp64 transform first
+
+// ---- the two forward transforms of one frame: one text for the kernel's inline code and for the out-of-line copy of the F32 instances' rare paths (forward_cold_1024) ----
+// Reference width: Hann (pv:55), pack (the factor 1/2 of the split pass is folded into the table: exact), 512-point complex FFT in fp64, split pass in conjugate
+// pairs: with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved), X[k] = E - j W^k O and X[512-k] = conj(E + j W^k O).  Lane l owns the pairs
+// k = l + 64 r, r < 4 (partner value from lane 64-l, register 7-r): emit(r, X[l + 64 r], X[512 - l - 64 r]); lane 0 also the self-paired bin: emit256(X[256]).
+template <typename EMIT, typename EMIT256, typename ST = NoStamp>
+__device__ __forceinline__ void spectrum64_1024(const float2 (&raw)[8], const pk::c32 (&hw)[8], unsigned char *smem, int l, double2 wl, EMIT emit, EMIT256 emit256, ST st = ST{})
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const double2 *TW1 = reinterpret_cast<const double2 *>(smem_all + TAB_TW1);
+    const double2 *TW2 = reinterpret_cast<const double2 *>(smem_all + TAB_TW2);
+    double2 *S64 = reinterpret_cast<double2 *>(smem);
+    pv_prio(PH_FA);
+    double2 z[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { const v2f xw = v2f{raw[r].x, raw[r].y} * hw[r]; z[r] = double2{(double)xw.x, (double)xw.y}; }
+    fft512_wave<double, false>(z, S64, TW1, TW2, l, st);
+    pv_prio(PH_SPLITX);
+    // partner values through the (now free) transpose scratch: rows 4..7 written lane-contiguous, read back reversed.  Element 512 - k of the pair k = l + 64 r sits
+    // at (3 - r) * 64 + (64 - l) for every lane (lane 0: 64 (8 - r), its own register 8 - r); half the LDS cycles of sixteen bpermutes.  (l = 0, r = 0) reads one
+    // element past the rows: replaced below.
+#pragma unroll
+    for (int r = 4; r < 8; r++) S64[(r - 4) * 64 + l] = z[r];
+    wave_sync();
+    pv_prio(PH_SPLITM);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const double2 zm = S64[(3 - r) * 64 + 64 - l];
+        const double2 E{z[r].x + zm.x, z[r].y - zm.y};
+        const double2 O{z[r].x - zm.x, z[r].y + zm.y};
+        const double2 WO = cmul(wl, mul_w16<double, false>(O, r));         // W_1024^{l+64r} = W^l * W_16^r
+        double2 xa{E.x + WO.y, E.y - WO.x};
+        double2 xb{E.x - WO.y, -(E.y + WO.x)};
+        if (r == 0 && l == 0) {
+            // Z[0] is pre-halved: X[0] = 2(zr + zi), X[512] = 2(zr - zi), both real (bundle:447-508 keep Im = 0)
+            xa = double2{2.0 * (z[0].x + z[0].y), 0.0};
+            xb = double2{2.0 * (z[0].x - z[0].y), 0.0};
+        }
+        emit(r, xa, xb);
+    }
+    if (l == 0) emit256(double2{2.0 * z[4].x, -2.0 * z[4].y});             // k = 256 pairs with itself: W^256 = -j, X = 2 conj(Z)
+}
+
+// fp32 first (round 5): the same in PACKED fp32, half the issue cycles.  The forward FFT is the inverse instance on conjugated data, FFT(z) = conj(IFFT(conj z)), the
+// first conjugation folded into the window product, the second into the split pass: with Zc = conj(Z), E' = Zc[k] + conj(Zc[512-k]), O' = Zc[k] - conj(Zc[512-k]),
+// T = conj(W^k) O':  X[k] = conj(E' + j T), X[512-k] = E' - j T.  wlfs = SC conj(W^l) is the c2r twiddle of the kernel (SC a power of two), isc = 1 / SC takes the
+// scale out again inside the FMAs: exact.
+template <bool REGT1, typename EMIT, typename EMIT256, typename ST = NoStamp>
+__device__ __forceinline__ void spectrum32_1024(const float2 (&raw)[8], const pk::c32 (&hw)[8], unsigned char *smem, int l, pk::c32 wlfs, float isc_, EMIT emit, EMIT256 emit256, ST st = ST{})
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const v4f *TW1F4 = reinterpret_cast<const v4f *>(smem_all + TAB_TW1F);
+    const v4f *TW2F4 = reinterpret_cast<const v4f *>(smem_all + TAB_TW2F);
+    pv_prio(PH_FA);
+    pk::c32 zc[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) zc[r] = pk::mul_conj(pk::c32{raw[r].x, raw[r].y}, hw[r]);       // conj(z), z pre-halved like the fp64 form's
+    fft512_wave_inv_pk<REGT1, ST, true>(zc, reinterpret_cast<pk::c32 *>(smem), TW1F4, TW2F4, l, st);
+    pv_prio(PH_SPLITX);
+    pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem);                       // partner rows 4..7, read back reversed (as in the fp64 form: (l = 0, r = 0) reads one past, replaced below)
+#pragma unroll
+    for (int r = 4; r < 8; r++) XCH[(r - 4) * 64 + l] = zc[r];
+    wave_sync();
+    pv_prio(PH_SPLITM);
+    const pk::c32 isc{isc_, isc_};
+    pk::c32 zm[4];                                                          // all four partner values first: read one by one, each read queues behind the magnitude
+                                                                            // stores of the pair before it (the compiler cannot tell the arrays apart)
+#pragma unroll
+    for (int r = 0; r < 4; r++) zm[r] = XCH[(3 - r) * 64 + 64 - l];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const pk::c32 E = pk::add_conj(zc[r], zm[r]), O = pk::sub_conj(zc[r], zm[r]);
+        const pk::c32 T = pk::cmul(mul_w16_inv_pk(O, r), wlfs);             // SC conj(W^{l + 64 r}) O'
+        pk::c32 xa = pk::conj_fma_j(T, isc, E), xb = pk::fnma_j(T, isc, E);
+        if (r == 0 && l == 0) {
+            xa = pk::c32{2.0f * (zc[0].x - zc[0].y), 0.f};                  // X[0] = 2 (Re Z0 + Im Z0), X[512] = 2 (Re Z0 - Im Z0), Z0 = conj(Zc0)
+            xb = pk::c32{2.0f * (zc[0].x + zc[0].y), 0.f};
+        }
+        emit(r, xa, xb);
+    }
+    if (l == 0) emit256(pk::c32{2.0f * zc[4].x, 2.0f * zc[4].y});           // X[256] = 2 conj(Z[256]) = 2 Zc[256]
+}
+
+// |X|^2 of an fp32 bin, roundings spelled out (every instance must form the same bits: the class of a frame rests on them)
+__device__ __forceinline__ float mag32(pk::c32 x) { return __fmaf_rn(x.y, x.y, __fmul_rn(x.x, x.x)); }
+// the absolute part K of a frame's guard band from the bit pattern of its largest fp32 magnitude; 0: out of the guarded range
+__device__ __forceinline__ float guard_k_of(unsigned mbits) { return (mbits >= GUARD_M_MIN_BITS && mbits < GUARD_M_MAX_BITS) ? GUARD_CK * __uint_as_float(mbits) : 0.f; }
+
+// The forward transforms of the F32 instances' RARE paths, out of line: a frame of class B (fp64), and the fp32 attempt of a chain that runs the fp64 transform first.
+// Inline they quadruple what meets at the merge in front of the peak search, and the register allocator then parks values of the HOT path in scratch memory.
+// Results travel through LDS: |X|^2 -> MAG; the fp32 spectrum -> the transposed stash (!SPREAD_: where the inline code puts it) or, SPREAD_, lane-private slots
+// XV[r * 64 + l] (XA), XV[(4 + r) * 64 + l] (XB), XV[512] (X[256], lane 0) in the stash area that instance does not use.  Returns the fp32 transform's K (wide: 0).
+struct Raw8 { float2 v[8]; };
+template <bool SPREAD_>
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE float forward_cold_1024(Raw8 RW, int wide, double2 wl, pk::c32 wlfs, float isc, unsigned wave_off, int l)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    unsigned char *smem = smem_all + wave_off;
+    float *MAG = reinterpret_cast<float *>(smem + OFF_MAG);
+    unsigned char *XSb = smem + OFF_XS;
+    float2 *XV = reinterpret_cast<float2 *>(XSb);
+    const v4f *HW4 = reinterpret_cast<const v4f *>(smem_all + TAB_HANN);
+    pk::c32 hw[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const v4f h = HW4[j * 64 + l]; hw[2 * j] = pk::c32{h.x, h.y}; hw[2 * j + 1] = pk::c32{h.z, h.w}; }
+    unsigned ystr = 0, ystr_m = 0;
+    if constexpr (!SPREAD_) { ystr = yslot_bytes((unsigned)l); ystr_m = yslot_bytes((unsigned)(512 - 192 - l)); }
+    auto put = [&](int r, float2 a, float2 b) {
+        if constexpr (SPREAD_) { XV[r * 64 + l] = a; XV[(4 + r) * 64 + l] = b; }
+        else { *reinterpret_cast<float2 *>(XSb + ystr + 64 * r) = a; *reinterpret_cast<float2 *>(XSb + ystr_m + 64 * (3 - r)) = b; }
+    };
+    auto put256 = [&](float2 a) { if constexpr (SPREAD_) XV[512] = a; else *reinterpret_cast<float2 *>(XSb + 256) = a; };
+    float guard_k = 0.f;
+    if (wide) {
+        spectrum64_1024(RW.v, hw, smem, l, wl,
+                        [&](int r, double2 xa, double2 xb) {
+                            MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                            MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                            put(r, float2{(float)xa.x, (float)xa.y}, float2{(float)xb.x, (float)xb.y});
+                        },
+                        [&](double2 x256) { MAG[4 + 256] = (float)(x256.x * x256.x + x256.y * x256.y); put256(float2{(float)x256.x, (float)x256.y}); });
+    } else {
+        unsigned mmax = 0u;
+        spectrum32_1024<PV_F32_REGT1>(RW.v, hw, smem, l, wlfs, isc,
+                                      [&](int r, pk::c32 xa, pk::c32 xb) {
+                                          const float ma = mag32(xa), mb = mag32(xb);
+                                          MAG[4 + l + 64 * r] = ma;
+                                          MAG[4 + 512 - l - 64 * r] = mb;
+                                          mmax = max(max(mmax, __float_as_uint(ma)), __float_as_uint(mb));
+                                          put(r, float2{xa.x, xa.y}, float2{xb.x, xb.y});
+                                      },
+                                      [&](pk::c32 x256) { const float m = mag32(x256); MAG[4 + 256] = m; mmax = max(mmax, __float_as_uint(m)); put256(float2{x256.x, x256.y}); });
+        guard_k = guard_k_of(wave_max_u32(mmax));
+    }
+    return guard_k;
+}
+
 // S_ROWS = hop / 128 (rows of 128 samples a frame advances by): 1, 2, 4 or 8
 // AUX = true: test-tap instance (pv_debug_frame); the production instance carries no tap code.
 // RESIDENT = true: streaming instance that stays on the GPU (PV_FLAG_PERSISTENT_STREAM): after its quantum a wave polls the control block in pinned host memory
@@ -585,8 +738,6 @@ __global__ __launch_bounds__(64 * (RESIDENT ? RES_WAVES : WAVES), RESIDENT ? 1 :
     if (!RESIDENT && p.chain_list && (long)blockIdx.x * WGW >= (long)p.chain_count[SPREAD ? 0 : 1]) return;     // no chain of this class left for the workgroup (uniform): not even the tables
     // ---- LDS carve (all dynamic, 16-byte aligned): shared tables, then one private region per wave ----
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    const double2 *TW1 = reinterpret_cast<const double2 *>(smem_all + TAB_TW1);
-    const double2 *TW2 = reinterpret_cast<const double2 *>(smem_all + TAB_TW2);
     const v4f *TW1F4 = reinterpret_cast<const v4f *>(smem_all + TAB_TW1F);
     const v4f *TW2F4 = reinterpret_cast<const v4f *>(smem_all + TAB_TW2F);
     const v4f *HW4 = reinterpret_cast<const v4f *>(smem_all + TAB_HANN);
@@ -728,9 +879,10 @@ resident_top:
     stamps.start();
     const unsigned stamp_t0 = stamps.prev;
 #endif
-    [[maybe_unused]] unsigned n_fallback = 0;                            // F32: frames of this chain that re-ran their forward transform in fp64
+    [[maybe_unused]] unsigned n_fallback = 0;                            // F32: frames of this chain of class B (forward transform in fp64)
+    [[maybe_unused]] unsigned pred = 0;                                  // F32: 0 .. PRED_MAX, >= PRED_WIDE: this chain runs the fp64 transform first (see GUARD_GN)
 #ifdef PV_FLIP_COUNT
-    unsigned n_flip = 0, n_uncaught = 0;
+    unsigned n_flip = 0, n_uncaught = 0, n_sure = 0, n_incons = 0;
 #endif
     for (int m = first_frame; m < last_out; ++m) {
         const float pfm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pf_next)));   // k-rate pitchFactor (pv:47), wave-uniform
@@ -743,154 +895,79 @@ resident_top:
         // ---- forward transform at the reference's width: Hann, pack, 512-point complex FFT in fp64, split pass, |X|^2 -> MAG, the spectrum rounded to fp32 -> XA / XB
         //      (and the transposed stash).  The only forward transform of the !F32 instances; what an F32 instance falls back to when a decision is in doubt ----
         auto forward64 = [&]() {
-            pv_prio(PH_FA);
-            // ---- Hann (pv:55) and pack; the factor 1/2 of the split pass is folded into the table (exact) ----
-            double2 z[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) { const v2f xw = v2f{raw[r].x, raw[r].y} * hw[r]; z[r] = double2{(double)xw.x, (double)xw.y}; }
-
 #ifdef PV_STAMPS
-            fft512_wave<double, false>(z, S64, TW1, TW2, l, [&](int id) { if (id & 1) stamps.mark(id); else stamps.mark(id, true); });
+            auto st64 = [&](int id) { if (id & 1) stamps.mark(id); else stamps.mark(id, true); };
 #else
-            fft512_wave<double, false>(z, S64, TW1, TW2, l);
+            NoStamp st64;
 #endif
-
-            // ---- split pass in conjugate pairs: with E = Z[k] + conj(Z[512-k]), O = Z[k] - conj(Z[512-k]) (Z pre-halved),
-            //      X[k] = E - j W^k O and X[512-k] = conj(E + j W^k O).  Lane l owns the pairs k = l + 64 r, r < 4 (partner value from lane
-            //      64-l, register 7-r), i.e. bins XA[r] = X[l + 64 r] and XB[r] = X[512 - l - 64 r]; lane 0 also owns the self-paired bin 256.
-            pv_prio(PH_SPLITX);
-            {
-                // partner values through the (now free) transpose scratch: rows 4..7 written lane-contiguous, read back reversed.  Element
-                // 512 - k of the pair k = l + 64 r sits at (3 - r) * 64 + (64 - l) for every lane (lane 0: 64 (8 - r), its own register
-                // 8 - r); half the LDS cycles of sixteen bpermutes.  (l = 0, r = 0) reads one element past the rows: replaced below.
-#pragma unroll
-                for (int r = 4; r < 8; r++) S64[(r - 4) * 64 + l] = z[r];
-                wave_sync();
-                pv_prio(PH_SPLITM);
+            spectrum64_1024(raw, hw, smem, l, wl,
+                            [&](int r, double2 xa, double2 xb) {
+                                // ---- |X|^2 -> f32 (pv:82-92) for the neighbour tests, and the spectrum itself, rounded to fp32 (the only thing the shift needs after
+                                //      the decisions) ----
+                                MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                                MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                                XA[r] = float2{(float)xa.x, (float)xa.y};
+                                XB[r] = float2{(float)xb.x, (float)xb.y};
+                                if constexpr (FP64) { XAd[r] = xa; XBd[r] = xb; }
+                                if (dbg) {
+                                    const int ka = l + 64 * r, kb = 512 - ka;
+                                    p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
+                                    p.dbg_X[2 * kb] = xb.x; p.dbg_X[2 * kb + 1] = xb.y;
+                                }
+                            },
+                            [&](double2 x256) {
+                                MAG[4 + 256] = (float)(x256.x * x256.x + x256.y * x256.y);
+                                x256f = float2{(float)x256.x, (float)x256.y};
+                                if constexpr (FP64) x256d = x256;
+                                if (dbg) { p.dbg_X[2 * 256] = x256.x; p.dbg_X[2 * 256 + 1] = x256.y; }
+                            }, st64);
+            if constexpr (!SPREAD) {
+                // into the transposed stash: the lanes that take the decisions (8 consecutive bins each) also move the bins.  Strided-order addresses: bin l + 64 r at
+                // ystr + 64 r, bin 512 - l - 64 r at ystr_m + 64 (3 - r).  Formed HERE from an opaque copy of the lane id (four instructions per frame): as loop
+                // invariants they would live in registers across the forward FFT, the register peak of the kernel, and push other addresses into scratch
+                unsigned ystr, ystr_m;
+                { int lq = l; asm volatile("" : "+v"(lq)); ystr = yslot_bytes((unsigned)lq); ystr_m = yslot_bytes((unsigned)(512 - 192 - lq)); }
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    double2 xa, xb;
-                    {
-                        const double2 zm = S64[(3 - r) * 64 + 64 - l];
-                        const double2 E{z[r].x + zm.x, z[r].y - zm.y};
-                        const double2 O{z[r].x - zm.x, z[r].y + zm.y};
-                        const double2 WO = cmul(wl, mul_w16<double, false>(O, r));     // W_1024^{l+64r} = W^l * W_16^r
-                        xa = double2{E.x + WO.y, E.y - WO.x};
-                        xb = double2{E.x - WO.y, -(E.y + WO.x)};
-                        if (r == 0 && l == 0) {
-                            // Z[0] is pre-halved: X[0] = 2(zr + zi), X[512] = 2(zr - zi), both real (bundle:447-508 keep Im = 0)
-                            xa = double2{2.0 * (z[0].x + z[0].y), 0.0};
-                            xb = double2{2.0 * (z[0].x - z[0].y), 0.0};
-                        }
-                    }
-                    // ---- |X|^2 -> f32 (pv:82-92) for the neighbour tests, and the spectrum itself, rounded to fp32 (the only thing the shift needs after
-                    //      the decisions), into the transposed stash: the lanes that take the decisions (8 consecutive bins each) also move the bins ----
-                    MAG[4 + l + 64 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
-                    MAG[4 + 512 - l - 64 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
-                    XA[r] = float2{(float)xa.x, (float)xa.y};
-                    XB[r] = float2{(float)xb.x, (float)xb.y};
-                    if constexpr (FP64) { XAd[r] = xa; XBd[r] = xb; }
-                    if (dbg) {
-                        const int ka = l + 64 * r, kb = 512 - ka;
-                        p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
-                        p.dbg_X[2 * kb] = xb.x; p.dbg_X[2 * kb + 1] = xb.y;
-                    }
+                    *reinterpret_cast<float2 *>(XSb + ystr + 64 * r) = XA[r];
+                    *reinterpret_cast<float2 *>(XSb + ystr_m + 64 * (3 - r)) = XB[r];
                 }
-                if (l == 0) {
-                    const double2 x256{2.0 * z[4].x, -2.0 * z[4].y};              // k = 256 pairs with itself: W^256 = -j, X = 2 conj(Z)
-                    MAG[4 + 256] = (float)(x256.x * x256.x + x256.y * x256.y);
-                    x256f = float2{(float)x256.x, (float)x256.y};
-                    if constexpr (FP64) x256d = x256;
-                    if (dbg) { p.dbg_X[2 * 256] = x256.x; p.dbg_X[2 * 256 + 1] = x256.y; }
-                }
-                if constexpr (!SPREAD) {
-                    // strided-order addresses of the transposed stash: bin l + 64 r at ystr + 64 r, bin 512 - l - 64 r at ystr_m + 64 (3 - r).  Formed HERE from an
-                    // opaque copy of the lane id (four instructions per frame): as loop invariants they would live in registers across the forward FFT, the
-                    // register peak of the kernel, and push other addresses into scratch
-                    unsigned ystr, ystr_m;
-                    { int lq = l; asm volatile("" : "+v"(lq)); ystr = yslot_bytes((unsigned)lq); ystr_m = yslot_bytes((unsigned)(512 - 192 - lq)); }
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        *reinterpret_cast<float2 *>(XSb + ystr + 64 * r) = XA[r];
-                        *reinterpret_cast<float2 *>(XSb + ystr_m + 64 * (3 - r)) = XB[r];
-                    }
-                    if (l == 0) *reinterpret_cast<float2 *>(XSb + 256) = x256f;                           // slot(256) = 32
-                }
+                if (l == 0) *reinterpret_cast<float2 *>(XSb + 256) = x256f;                           // slot(256) = 32
             }
         };
-        // ---- fp32-first forward transform (round 5; F32 instances).  The peak decisions need the |X|^2 of an fp64 spectrum only where two magnitudes that are compared
-        //      lie within the error of an fp32 transform of each other.  So: Hann, pack, 512-point FFT and split pass in PACKED fp32 (half the issue cycles of the fp64
-        //      form), a guard band around every comparison the decisions rest on (below, at the flags), and the fp64 transform above only for frames with a comparison
-        //      inside its band -- a wave-uniform branch, one frame per wave, no divergence.  A frame's class (guarded / fallen back) is a function of its own samples
-        //      only, so chunked / call-split / resident runs still agree bit for bit.  The forward FFT is the inverse instance on conjugated data: FFT(z) = conj(IFFT(conj z)),
-        //      the first conjugation folded into the window product, the second into the split pass: with Zc = conj(Z), E' = Zc[k] + conj(Zc[512-k]), O' = Zc[k] - conj(Zc[512-k]),
-        //      T = conj(W^k) O':  X[k] = conj(E' + j T), X[512-k] = E' - j T.
-        //      Returns the absolute part K of the frame's guard band (0: the frame is outside the guarded range -- silent, below -117 dB, non-finite or absurdly
-        //      large input -- and takes the fp64 transform unconditionally). ----
+        // ---- fp32-first forward transform (round 5; F32 instances; spectrum32_1024).  The peak decisions need the |X|^2 of an fp64 spectrum only where two magnitudes
+        //      that are compared lie within the error of an fp32 transform of each other: a guard band around every comparison the decisions rest on (below, at the
+        //      flags), and the fp64 transform only for frames with a comparison inside it.  Returns the absolute part K of the frame's guard band (0: the frame is
+        //      outside the guarded range -- silent, below -117 dB, non-finite or absurdly large input -- and takes the fp64 transform unconditionally). ----
         [[maybe_unused]] auto forward32 = [&]() -> float {
-            float guard_k;
-            pv_prio(PH_FA);
-            pk::c32 zc[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) zc[r] = pk::mul_conj(pk::c32{raw[r].x, raw[r].y}, hw[r]);       // conj(z), z pre-halved like the fp64 form's
 #ifdef PV_STAMPS
-            auto st_fwd = [&](int id) { if (id & 1) stamps.mark(id); else stamps.mark(id, true); };
-            fft512_wave_inv_pk<PV_F32_REGT1, decltype(st_fwd), true>(zc, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l, st_fwd);
+            auto st32 = [&](int id) { if (id & 1) stamps.mark(id); else stamps.mark(id, true); };
 #else
-            fft512_wave_inv_pk<PV_F32_REGT1, NoStamp, true>(zc, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l);
+            NoStamp st32;
 #endif
-            pv_prio(PH_SPLITX);
-            {
-                pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem);           // partner rows 4..7, read back reversed (as in the fp64 form: (l = 0, r = 0) reads one past, replaced below)
-#pragma unroll
-                for (int r = 4; r < 8; r++) XCH[(r - 4) * 64 + l] = zc[r];
-                wave_sync();
-                pv_prio(PH_SPLITM);
-                constexpr float ISC = 1.0f / SC;                            // wlfs carries the c2r scale SC (a power of two): taken out again inside the FMAs, exact
-                const pk::c32 isc{ISC, ISC};
-                unsigned mmax = 0u;                                         // bit pattern of the largest |X|^2 this lane has seen
-                pk::c32 zm[4];                                              // all four partner values first: read one by one, each read queues behind the magnitude
-                                                                            // stores of the pair before it (the compiler cannot tell the arrays apart)
-#pragma unroll
-                for (int r = 0; r < 4; r++) zm[r] = XCH[(3 - r) * 64 + 64 - l];
+            unsigned mmax = 0u;                                             // bit pattern of the largest |X|^2 this lane has seen (|X|^2 >= 0: the order of the bit patterns; NaN / Inf on top)
+            spectrum32_1024<PV_F32_REGT1>(raw, hw, smem, l, wlfs, 1.0f / SC,
+                                          [&](int r, pk::c32 xa, pk::c32 xb) {
+                                              const float ma = mag32(xa), mb = mag32(xb);
+                                              MAG[4 + l + 64 * r] = ma;
+                                              MAG[4 + 512 - l - 64 * r] = mb;
+                                              mmax = max(max(mmax, __float_as_uint(ma)), __float_as_uint(mb));
+                                              XA[r] = float2{xa.x, xa.y};
+                                              XB[r] = float2{xb.x, xb.y};
+                                          },
+                                          [&](pk::c32 x256) { const float m = mag32(x256); MAG[4 + 256] = m; mmax = max(mmax, __float_as_uint(m)); x256f = float2{x256.x, x256.y}; }, st32);
+            if constexpr (!SPREAD) {
+                unsigned ystr, ystr_m;
+                { int lq = l; asm volatile("" : "+v"(lq)); ystr = yslot_bytes((unsigned)lq); ystr_m = yslot_bytes((unsigned)(512 - 192 - lq)); }
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const pk::c32 E = pk::add_conj(zc[r], zm[r]), O = pk::sub_conj(zc[r], zm[r]);
-                    const pk::c32 T = pk::cmul(mul_w16_inv_pk(O, r), wlfs);                 // SC conj(W^{l + 64 r}) O'
-                    pk::c32 xa = pk::conj_fma_j(T, isc, E), xb = pk::fnma_j(T, isc, E);
-                    if (r == 0 && l == 0) {
-                        xa = pk::c32{2.0f * (zc[0].x - zc[0].y), 0.f};        // X[0] = 2 (Re Z0 + Im Z0), X[512] = 2 (Re Z0 - Im Z0), Z0 = conj(Zc0)
-                        xb = pk::c32{2.0f * (zc[0].x + zc[0].y), 0.f};
-                    }
-                    const float ma = __fmaf_rn(xa.y, xa.y, __fmul_rn(xa.x, xa.x)), mb = __fmaf_rn(xb.y, xb.y, __fmul_rn(xb.x, xb.x));
-                    MAG[4 + l + 64 * r] = ma;
-                    MAG[4 + 512 - l - 64 * r] = mb;
-                    mmax = max(max(mmax, __float_as_uint(ma)), __float_as_uint(mb));     // (|X|^2 >= 0: the order of the bit patterns; NaN / Inf come out on top)
-                    XA[r] = float2{xa.x, xa.y};
-                    XB[r] = float2{xb.x, xb.y};
+                    *reinterpret_cast<float2 *>(XSb + ystr + 64 * r) = XA[r];
+                    *reinterpret_cast<float2 *>(XSb + ystr_m + 64 * (3 - r)) = XB[r];
                 }
-                if (l == 0) {
-                    x256f = float2{2.0f * zc[4].x, 2.0f * zc[4].y};           // X[256] = 2 conj(Z[256]) = 2 Zc[256]
-                    const float m256 = __fmaf_rn(x256f.y, x256f.y, __fmul_rn(x256f.x, x256f.x));
-                    MAG[4 + 256] = m256;
-                    mmax = max(mmax, __float_as_uint(m256));
-                }
-                if constexpr (!SPREAD) {
-                    unsigned ystr, ystr_m;
-                    { int lq = l; asm volatile("" : "+v"(lq)); ystr = yslot_bytes((unsigned)lq); ystr_m = yslot_bytes((unsigned)(512 - 192 - lq)); }
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        *reinterpret_cast<float2 *>(XSb + ystr + 64 * r) = XA[r];
-                        *reinterpret_cast<float2 *>(XSb + ystr_m + 64 * (3 - r)) = XB[r];
-                    }
-                    if (l == 0) *reinterpret_cast<float2 *>(XSb + 256) = x256f;
-                }
-                // the frame's largest magnitude M sets the absolute part of the guard band; outside [M_MIN, M_MAX) -- silence, very quiet, absurdly large or
-                // non-finite input -- K = 0 and the frame takes the fp64 transform unconditionally
-                const unsigned mb = wave_max_u32(mmax);
-                guard_k = (mb >= GUARD_M_MIN_BITS && mb < GUARD_M_MAX_BITS) ? GUARD_CK * __uint_as_float(mb) : 0.f;
+                if (l == 0) *reinterpret_cast<float2 *>(XSb + 256) = x256f;
             }
-            return guard_k;
+            // the frame's largest magnitude sets the absolute part of the guard band
+            return guard_k_of(wave_max_u32(mmax));
         };
         auto shift_table = [&]() {
             // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change.  BEFORE the prefetch is issued: the
@@ -912,8 +989,15 @@ resident_top:
             }
         };
         [[maybe_unused]] float guardK = 0.f;                               // F32: the absolute part of the guard band of this frame, 0 = frame out of the guarded range
+        [[maybe_unused]] bool wide_first = false;                          // F32, wave-uniform: this chain's frames have been coming out as class B: the fp64 transform first
         if constexpr (!F32) { forward64(); shift_table(); slide_prefetch(); }
-        else { guardK = forward32(); shift_table(); }
+        else {
+            shift_table();                                                  // (a call: before anything of this frame is in flight)
+#ifndef PV_FLIP_COUNT
+            wide_first = pred >= PRED_WIDE;
+#endif
+            if (wide_first) forward64(); else guardK = forward32();
+        }
         wave_sync();
         PV_STAMP(4);
         pv_prio(PH_PEAKS);
@@ -963,93 +1047,143 @@ resident_top:
                     fl[i] = in_range & (nm[i] < mg[i + 2]);
                 }
             };
-            read_mags();
-            take_flags();
-            if constexpr (F32) {
-                // ---- the guard band (see GUARD_CK): is any candidate bin within the fp32 transform's error of the largest of its four neighbours? ----
-                bool amb = !(guardK > 0.f);                                 // frame outside the guarded range
-                {
-                    const pk::c32 KK{guardK, guardK}, RR{GUARD_R, GUARD_R};
-                    float tmin = 1.0f;
+            // is any candidate bin of this lane within the band (K, R) of the largest of its four neighbours?  K = 0: the frame is out of the guarded range
+            [[maybe_unused]] auto in_band = [&](float K, float Rr) -> bool {
+                const pk::c32 KK{K, K}, RR{Rr, Rr};
+                float tmin = 1.0f;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int i = 2 * j;
-                        const pk::c32 c2{__uint_as_float(mg[i + 2]), __uint_as_float(mg[i + 3])}, n2{__uint_as_float(nm[i]), __uint_as_float(nm[i + 1])};
-                        const pk::c32 d2 = pk::sub(c2, n2), s2 = pk::add(c2, n2);
-                        pk::c32 t2 = pk::fms(d2, d2, pk::mul(pk::fma(s2, RR, KK), s2));      // (c - n)^2 - (c + n) (K + R (c + n)): <= 0 inside the band
-                        if (j == 0 && l == 0) t2 = pk::c32{1.f, 1.f};        // bins 0, 1 and 511 are no candidates (pv:97-100)
-                        if (j == 3 && l == 63) t2.y = 1.f;
-                        tmin = fminf(fminf(tmin, t2.x), t2.y);
-                    }
-                    amb |= tmin <= 0.f;
+                for (int j = 0; j < 4; j++) {
+                    const int i = 2 * j;
+                    const pk::c32 c2{__uint_as_float(mg[i + 2]), __uint_as_float(mg[i + 3])}, n2{__uint_as_float(nm[i]), __uint_as_float(nm[i + 1])};
+                    const pk::c32 d2 = pk::sub(c2, n2), s2 = pk::add(c2, n2);
+                    pk::c32 t2 = pk::fms(d2, d2, pk::mul(pk::fma(s2, RR, KK), s2));      // (c - n)^2 - (c + n) (K + R (c + n)): <= 0 inside the band
+                    if (j == 0 && l == 0) t2 = pk::c32{1.f, 1.f};            // bins 0, 1 and 511 are no candidates (pv:97-100)
+                    if (j == 3 && l == 63) t2.y = 1.f;
+                    tmin = fminf(fminf(tmin, t2.x), t2.y);
                 }
+                return !(K > 0.f) | (tmin <= 0.f);
+            };
 #ifdef PV_FLIP_COUNT
-                // Validation build (tools/flip_count.py; never the product): EVERY frame also runs the fp64 transform, and the two flag sets are compared --
-                // frames whose flags differ at all, frames whose flags differ although the guard band did not ask for the fp64 transform (must be none), and
-                // over all candidate bins whose flag differs the largest q = (c - n)^2 / ((c + n) (K + R (c + n))): the guard calls a bin ambiguous for q <= 1,
-                // so sqrt(1 / q_max) is the factor by which the band could shrink before a flip escapes.
-                {
-                    unsigned f32bits = 0;
-                    float q[8];
+            // Validation build (tools/flip_count.py; never the product): EVERY frame runs the fp32 transform and then the fp64 one, and the two are compared --
+            // frames whose flag sets differ at all; frames whose flags differ although the guard band did not ask for the fp64 transform (must be none); over all
+            // candidate bins whose flag differs the largest q = (c - n)^2 / ((c + n) (K + R (c + n))) (the guard calls a bin ambiguous for q <= 1: sqrt(1 / q_max) is
+            // the factor by which the band could shrink before a flip escapes); the error of the fp32 amplitudes beyond a relative allowance, in units of eps max|X|;
+            // and for the class proof from the fp64 magnitudes: frames it calls class B for sure, and of those the ones the fp32 test calls class A (must be none).
+            unsigned vb_f32bits = 0;
+            float vb_q[8], vb_a32[8];
+            bool vb_amb_any = false;
+            float vb_K = 0.f;
+            auto flip_first = [&](float gk) {
+                vb_K = gk;
+                vb_f32bits = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    vb_f32bits |= fl[i] ? (1u << i) : 0u;
+                    const float c = __uint_as_float(mg[i + 2]), n = __uint_as_float(nm[i]), d = c - n, sm = c + n;
+                    vb_q[i] = (gk > 0.f && sm > 0.f) ? (d * d) / (sm * (gk + GUARD_R * sm)) : 0.f;
+                    vb_a32[i] = sqrtf(c);
+                }
+                vb_amb_any = __any(in_band(gk, GUARD_R));
+            };
+            auto flip_second = [&](bool sure_b) {
+                if (vb_K > 0.f && p.fwd_stats) {
+                    float e8 = 0.f, e32 = 0.f, amax = 0.f, a64[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { a64[i] = sqrtf(__uint_as_float(mg[i + 2])); amax = fmaxf(amax, a64[i]); }
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
-                        f32bits |= fl[i] ? (1u << i) : 0u;
-                        const float c = __uint_as_float(mg[i + 2]), n = __uint_as_float(nm[i]), d = c - n, sm = c + n;
-                        q[i] = (guardK > 0.f && sm > 0.f) ? (d * d) / (sm * (guardK + GUARD_R * sm)) : 0.f;
+                        const float e = fabsf(vb_a32[i] - a64[i]);
+                        e8 = fmaxf(e8, e - 8.f * GUARD_EPS * a64[i]);
+                        e32 = fmaxf(e32, e - 32.f * GUARD_EPS * a64[i]);
                     }
-                    const bool amb_any = __any(amb);
-                    float a32[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) a32[i] = sqrtf(__uint_as_float(mg[i + 2]));
-                    forward64();
-                    wave_sync();
-                    pv_prio(PH_PEAKS);
-                    read_mags();
-                    take_flags();
-                    if (guardK > 0.f && p.fwd_stats) {
-                        // error of the fp32 transform in the amplitude of a bin beyond a relative allowance r eps A (r = 8, 32), against eps * rms|X| and eps * max|X| of the frame
-                        float e8 = 0.f, e32 = 0.f, amax = 0.f;
-                        float a64[8];
-#pragma unroll
-                        for (int i = 0; i < 8; i++) { a64[i] = sqrtf(__uint_as_float(mg[i + 2])); amax = fmaxf(amax, a64[i]); }
-#pragma unroll
-                        for (int i = 0; i < 8; i++) {
-                            const float e = fabsf(a32[i] - a64[i]);
-                            e8 = fmaxf(e8, e - 8.f * GUARD_EPS * a64[i]);
-                            e32 = fmaxf(e32, e - 32.f * GUARD_EPS * a64[i]);
-                        }
-                        for (int o = 32; o; o >>= 1) { e8 = fmaxf(e8, __shfl_xor(e8, o, 64)); e32 = fmaxf(e32, __shfl_xor(e32, o, 64)); amax = fmaxf(amax, __shfl_xor(amax, o, 64)); }
-                        if (l == 0) {
-                            atomicMax(reinterpret_cast<unsigned *>(p.fwd_stats + 514), __float_as_uint(e8 / (GUARD_EPS * amax)));
-                            atomicMax(reinterpret_cast<unsigned *>(p.fwd_stats + 516), __float_as_uint(e32 / (GUARD_EPS * amax)));
-                        }
+                    for (int o = 32; o; o >>= 1) { e8 = fmaxf(e8, __shfl_xor(e8, o, 64)); e32 = fmaxf(e32, __shfl_xor(e32, o, 64)); amax = fmaxf(amax, __shfl_xor(amax, o, 64)); }
+                    if (l == 0) {
+                        atomicMax(reinterpret_cast<unsigned *>(p.fwd_stats + 514), __float_as_uint(e8 / (GUARD_EPS * amax)));
+                        atomicMax(reinterpret_cast<unsigned *>(p.fwd_stats + 516), __float_as_uint(e32 / (GUARD_EPS * amax)));
                     }
-                    unsigned diff = 0;
-                    float qmax = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const bool dif = (fl[i] ? 1u : 0u) != ((f32bits >> i) & 1u);
-                        diff |= dif ? 1u : 0u;
-                        if (dif) qmax = fmaxf(qmax, q[i]);
-                    }
-                    const bool flip_any = __any(diff != 0u);
-                    n_fallback += amb_any ? 1u : 0u;
-                    n_flip += flip_any ? 1u : 0u;
-                    n_uncaught += (flip_any && !amb_any) ? 1u : 0u;
-                    if (diff && p.fwd_stats) atomicMax(reinterpret_cast<unsigned *>(p.fwd_stats + 512), __float_as_uint(qmax));
                 }
-#else
-                if (__builtin_expect(__any(amb), 0)) {
-                    // a decision of this frame is in doubt: the transform at the reference's width (raw[] and hw[] are untouched), its magnitudes, its flags
-                    // -- and its spectrum, rounded to fp32, as the frame's sources: a fallen-back frame is exactly a frame of the !F32 instances
-                    forward64();
-                    wave_sync();
-                    pv_prio(PH_PEAKS);
-                    read_mags();
-                    take_flags();
-                    n_fallback++;
+                unsigned diff = 0;
+                float qmax = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const bool dif = (fl[i] ? 1u : 0u) != ((vb_f32bits >> i) & 1u);
+                    diff |= dif ? 1u : 0u;
+                    if (dif) qmax = fmaxf(qmax, vb_q[i]);
                 }
+                const bool flip_any = __any(diff != 0u);
+                n_flip += flip_any ? 1u : 0u;
+                n_uncaught += (flip_any && !vb_amb_any) ? 1u : 0u;
+                n_sure += sure_b ? 1u : 0u;
+                n_incons += (sure_b && !vb_amb_any) ? 1u : 0u;
+                if (diff && p.fwd_stats) atomicMax(reinterpret_cast<unsigned *>(p.fwd_stats + 512), __float_as_uint(qmax));
+            };
 #endif
+            if constexpr (!F32) {
+                read_mags();
+                take_flags();
+            } else {
+                read_mags();
+                take_flags();
+                bool fall = true;
+                if (!wide_first) {
+                    fall = __any(in_band(guardK, GUARD_R));
+#ifdef PV_FLIP_COUNT
+                    flip_first(guardK);
+                    fall = true;
+#endif
+                }
+                if (fall) {
+                    // Rare paths, out of line (forward_cold_1024): the transform hands |X|^2 and the fp32 spectrum over through LDS
+                    auto cold = [&](int wide) -> float {
+                        Raw8 rw;
+#pragma unroll
+                        for (int r = 0; r < 8; r++) rw.v[r] = raw[r];
+                        const float k = forward_cold_1024<SPREAD>(rw, wide, wl, wlfs, 1.0f / SC, wave_off, l);
+                        wave_sync();
+                        pv_prio(PH_PEAKS);
+                        read_mags();
+                        take_flags();
+                        if constexpr (SPREAD) {
+                            const float2 *XV = reinterpret_cast<const float2 *>(XSb);
+#pragma unroll
+                            for (int r = 0; r < 4; r++) { XA[r] = XV[r * 64 + l]; XB[r] = XV[(4 + r) * 64 + l]; }
+                            x256f = XV[512];                                // (only lane 0 uses it)
+                        }
+                        return k;
+                    };
+                    // class B (or, for a chain that runs it first, not known yet): the transform at the reference's width, its magnitudes, its flags -- and its
+                    // spectrum, rounded to fp32, as the frame's sources: a class-B frame is exactly a frame of the !F32 instances
+                    if (!wide_first) cold(1);
+                    // what the fp64 magnitudes alone say about the class (see GUARD_GN)
+                    const unsigned mb = wave_max_u32(max(max(max(pm[3], pm[5]), max(pm[7], pm[9])), mg[2]));       // the largest |X|^2 of bins 0 .. 512
+                    const bool out_sure = mb < GUARD_M_MIN_BITS - GUARD_M_SLACK || mb >= GUARD_M_MAX_BITS + GUARD_M_SLACK;
+                    const bool in_sure = mb >= GUARD_M_MIN_BITS + GUARD_M_SLACK && mb < GUARD_M_MAX_BITS - GUARD_M_SLACK;
+                    const bool sure_b = out_sure || (in_sure && __any(in_band(GUARD_CKN * __uint_as_float(mb), GUARD_RN)));
+#ifdef PV_FLIP_COUNT
+                    flip_second(sure_b);
+#endif
+                    bool class_b = true;
+                    if (wide_first && !sure_b) {
+                        // the fp64 magnitudes do not settle this frame's class: the fp32 transform after all
+                        const float k = cold(0);
+                        class_b = __any(in_band(k, GUARD_R));
+                        // (class B means the fp64 transform once more: keeping its flags and spectrum alive across the call above costs the hot paths their
+                        //  registers -- loop invariants went to scratch memory --, and at the pitchFactor < 1 instance the stash, which the residue paths read,
+                        //  holds the fp32 spectrum now)
+                        if (class_b) cold(1);
+                    }
+                    // The counter: +1 for a frame that is class B and provable, -3 otherwise, fp64 first from PRED_WIDE up.  With the costs measured on the headline shape
+                    // (a class-A frame 0.87, a class-B frame of an fp32-first chain 1.49, an unprovable frame of an fp64-first chain 1.45, resp. 2.3 when it turns out
+                    // class B, of an fp64-only frame) the order pays off above three provable frames in four
+                    pred = (class_b && sure_b) ? min(pred + 1u, (unsigned)PRED_MAX) : (pred > 3u ? pred - 3u : 0u);
+#ifdef PV_FLIP_COUNT
+                    n_fallback += vb_amb_any ? 1u : 0u;
+#else
+                    n_fallback += class_b ? 1u : 0u;
+#endif
+                } else {
+                    pred = pred > 3u ? pred - 3u : 0u;
+                }
                 slide_prefetch();
             }
             // Non-finite magnitudes (NaN / Inf samples in the window): the order of bit patterns is not the order of floats any more.  In the
@@ -1430,6 +1564,8 @@ resident_top:
 #ifdef PV_FLIP_COUNT
             if (n_flip) atomicAdd(st + 256, (unsigned long long)n_flip);
             if (n_uncaught) atomicAdd(st + 257, (unsigned long long)n_uncaught);
+            if (n_sure) atomicAdd(p.fwd_stats + 600, (unsigned long long)n_sure);
+            if (n_incons) atomicAdd(p.fwd_stats + 601, (unsigned long long)n_incons);
 #endif
         }
     }

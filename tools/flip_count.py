@@ -65,10 +65,10 @@ def main():
     L.pv_exp_flip_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     kinds = ["bench", "white", "tonal60", "tonal80", "tonal100", "fuzz_noise", "fuzz_tonal", "sine32", "impulses", "chirp_am", "quantised16"]
     T = 1 << 19
-    rows, tot = [], np.zeros(4, np.uint64)
+    rows, tot, tot_cls = [], np.zeros(4, np.uint64), np.zeros(2, np.uint64)
     qmax_all = 0.0
     for kind in kinds:
-        acc = np.zeros(4, np.uint64); qk = 0.0; run = 0; em = np.zeros(5)
+        acc = np.zeros(4, np.uint64); qk = 0.0; run = 0; em = np.zeros(5); cls = np.zeros(2, np.uint64)
         while int(acc[0]) < per_class:
             hop = (256, 256, 128, 512)[run % 4]
             amp = (1.0, 1.0, 1e-4, 1.0, 30.0, 1.0, 5e-5, 1.0)[run % 8]         # scale invariance: tiny and large signals
@@ -78,21 +78,24 @@ def main():
             pt = torch.full((T,), pf, device=dev, dtype=torch.float32)
             pv = phaze_amd.PhaseVocoder(fft_size=1024, hop_size=hop, max_channels=1, max_hops=1)
             pv.process_batch_device(x.data_ptr(), y.data_ptr(), 1, T, T * hop, pt.data_ptr(), 0, 1)
-            st = (C.c_uint64 * 10)()
+            st = (C.c_uint64 * 12)()
             assert L.pv_exp_flip_stats(pv._h, st) == 0
             pv.close()
             acc += np.array(st[:4], np.uint64)
+            cls += np.array(st[10:12], np.uint64)
             qk = max(qk, float(np.array([st[4]], np.uint32).view(np.float32)[0]))
             em = np.maximum(em, np.array(st[5:10], np.uint32).view(np.float32).astype(np.float64))
             run += 1
             del x, y
         rows.append({"signal": kind, "frames": int(acc[0]), "guard_fallbacks": int(acc[1]), "frames_with_flag_flips": int(acc[2]), "flips_not_caught": int(acc[3]), "q_max": qk,
+                     "class_b_proved_from_fp64_magnitudes": int(cls[0]), "proved_b_but_fp32_test_says_a": int(cls[1]),
                      "abs_err_beyond_8epsA_over_eps_rms": em[0], "abs_err_beyond_8epsA_over_eps_max": em[1], "abs_err_beyond_32epsA_over_eps_rms": em[2],
                      "abs_err_beyond_32epsA_over_eps_max": em[3], "max_peak_over_rms": em[4]})
-        tot += acc; qmax_all = max(qmax_all, qk)
+        tot += acc; tot_cls += cls; qmax_all = max(qmax_all, qk)
         print(f"{kind:12s} frames {int(acc[0]):10d}  fallback {100.0 * int(acc[1]) / int(acc[0]):7.3f} %  frames with flips {int(acc[2]):9d} ({100.0 * int(acc[2]) / int(acc[0]):.3f} %)  "
-              f"NOT caught {int(acc[3])}  q_max {qk:.3e}  (err-8epsA)/(eps rms) {em[0]:.1f} /(eps max) {em[1]:.2f}  (err-32epsA)/(eps rms) {em[2]:.1f} /(eps max) {em[3]:.2f}  max/rms {em[4]:.1f}", flush=True)
+              f"NOT caught {int(acc[3])}  proved B from fp64 {100.0 * int(cls[0]) / int(acc[0]):7.3f} % (inconsistent {int(cls[1])})  q_max {qk:.3e}  (err-8epsA)/(eps rms) {em[0]:.1f} /(eps max) {em[1]:.2f}  (err-32epsA)/(eps rms) {em[2]:.1f} /(eps max) {em[3]:.2f}  max/rms {em[4]:.1f}", flush=True)
     res = {"frames": int(tot[0]), "guard_fallbacks": int(tot[1]), "frames_with_flag_flips": int(tot[2]), "flips_not_caught": int(tot[3]), "q_max": qmax_all,
+           "class_b_proved_from_fp64_magnitudes": int(tot_cls[0]), "proved_b_but_fp32_test_says_a": int(tot_cls[1]),
            "band_shrink_margin": float(np.sqrt(1.0 / qmax_all)) if qmax_all > 0 else None, "classes": rows}
     print(json.dumps(res))
     if out_path:
