@@ -31,6 +31,7 @@
 #define PV_PT 1, 0, 1, 2, 2, 2, 2, 2, 0, 0, 0, 2     // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C3 3.76 -> 3.31 ms)
 #endif
 #include "pv_wave_fft.h"
+#include "pv_guard.h"
 #ifdef PV_W2K_STAMPS  // measurement build (make variant ... EXTRA=-DPV_W2K_STAMPS CAPI_EXTRA=-DPV_STAMPS=1): s_memtime at the stations of a 1-hop launch, per chain
 #define W2K_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0 && p.stamps) p.stamps[16 * chain + (i)] = (unsigned)t_; } while (0)
 #else
@@ -256,9 +257,165 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(cons
 // AUX = true: test-tap instance (pv_debug_frame: X / |X|^2 / peak flags / Y of one frame, incl. the above-Nyquist residue); the production
 // instance carries no tap code.
 // RESIDENT = true: streaming instance that stays on the GPU (PV_FLAG_PERSISTENT_STREAM; see pv_wave_kernel.hip): one wave per channel slot, 1 hop per quantum.
-template <int HOPQ, bool AUX, bool RESIDENT = false>
+// ---- the two forward transforms of one 2048-point frame: one text for the kernel's inline code and for the out-of-line copy of the F32 instances' rare paths ----
+// Reference width: Hann (pv:55), pack by parity, two 512-point fp64 FFTs, decimation-in-time stage, split pass in conjugate pairs: k = l + 64 r pairs with M - k =
+// element 512 + (64 - l) + 64 (7 - r), i.e. zhi[7 - r] of lane 64 - l.  emit(r, X[l + 64 r], X[1024 - l - 64 r]), r < 8; lane 0 also emit512(X[512]).
+template <typename EMIT, typename EMIT512>
+__device__ __forceinline__ void spectrum64_2k(const v4f (&raw)[8], const v4f (&hw)[8], unsigned char *smem, int l, double2 w1024, double2 w2048, EMIT emit, EMIT512 emit512)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const double2 *TW1 = reinterpret_cast<const double2 *>(smem_all + T2_TW1);
+    const double2 *TW2 = reinterpret_cast<const double2 *>(smem_all + T2_TW2);
+    double2 *S64 = reinterpret_cast<double2 *>(smem + O2_S);
+    pv_prio(PH_FA);
+    double2 zlo[8], zhi[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const v4f xw = raw[r] * hw[r];
+        zlo[r] = double2{(double)xw.x, (double)xw.y};                      // ze[l + 64 r] = z[2 n']
+        zhi[r] = double2{(double)xw.z, (double)xw.w};                      // zo[l + 64 r] = z[2 n' + 1]
+    }
+    fft512_wave<double, false>(zlo, S64, TW1, TW2, l);
+    fft512_wave<double, false>(zhi, S64, TW1, TW2, l);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const double2 t = cmul(w1024, mul_w16<double, false>(zhi[r], r));
+        const double2 e = zlo[r];
+        zlo[r] = cadd(e, t);                                               // Z[l + 64 r]
+        zhi[r] = csub(e, t);                                               // Z[l + 64 r + 512]
+    }
+    pv_prio(PH_SPLITX);
+#pragma unroll
+    for (int r = 0; r < 8; r++) S64[r * 64 + l] = zhi[r];
+    wave_sync();
+    pv_prio(PH_SPLITM);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const double2 zm = S64[(7 - r) * 64 + 64 - l];                     // (l = 0, r = 0) reads one element past the rows: replaced below
+        const double2 E{zlo[r].x + zm.x, zlo[r].y - zm.y};
+        const double2 O{zlo[r].x - zm.x, zlo[r].y + zm.y};
+        const double2 WO = cmul(w2048, mul_w32(O, r));
+        double2 xa{E.x + WO.y, E.y - WO.x};
+        double2 xb{E.x - WO.y, -(E.y + WO.x)};
+        if (r == 0 && l == 0) {                                            // Z[0] is pre-halved: X[0] = 2(zr + zi), X[1024] = 2(zr - zi), both real
+            xa = double2{2.0 * (zlo[0].x + zlo[0].y), 0.0};
+            xb = double2{2.0 * (zlo[0].x - zlo[0].y), 0.0};
+        }
+        emit(r, xa, xb);
+    }
+    if (l == 0) emit512(double2{2.0 * zhi[0].x, -2.0 * zhi[0].y});         // k = 512 pairs with itself: X = 2 conj(Z[512])
+}
+
+// fp32 first (round 5; pv_wave_kernel.hip, spectrum32_1024): the same in PACKED fp32 on conjugated data -- FFT(z) = conj(IFFT(conj z)), the first conjugation folded into
+// the window product, the second into the split pass.  wl1024f = conj(W_1024^l) and wl2048s = SC conj(W_2048^l) are the twiddles of the kernel's inverse side (SC a
+// power of two, taken out again by isc = 1 / SC inside the FMAs: exact).
+template <bool REGT1, typename EMIT, typename EMIT512>
+__device__ __forceinline__ void spectrum32_2k(const v4f (&raw)[8], const v4f (&hw)[8], unsigned char *smem, int l, pk::c32 wl1024f, pk::c32 wl2048s, float isc_, EMIT emit, EMIT512 emit512)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const v4f *TW1F4 = reinterpret_cast<const v4f *>(smem_all + T2_TW1F);
+    const v4f *TW2F4 = reinterpret_cast<const v4f *>(smem_all + T2_TW2F);
+    pk::c32 *S = reinterpret_cast<pk::c32 *>(smem + O2_S);
+    pv_prio(PH_FA);
+    pk::c32 zlo[8], zhi[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        zlo[r] = pk::mul_conj(pk::c32{raw[r].x, raw[r].y}, pk::c32{hw[r].x, hw[r].y});      // conj(ze[l + 64 r])
+        zhi[r] = pk::mul_conj(pk::c32{raw[r].z, raw[r].w}, pk::c32{hw[r].z, hw[r].w});      // conj(zo[l + 64 r])
+    }
+    fft512_wave_inv_pk<REGT1, NoStamp, true>(zlo, S, TW1F4, TW2F4, l);
+    fft512_wave_inv_pk<REGT1, NoStamp, true>(zhi, S, TW1F4, TW2F4, l);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const pk::c32 t = pk::cmul(mul_w16_inv_pk8(zhi[r], r), wl1024f);   // conj(W_1024^{l + 64 r}) conj(O[k])
+        const pk::c32 e = zlo[r];
+        zlo[r] = pk::add(e, t);                                            // conj(Z[l + 64 r])
+        zhi[r] = pk::sub(e, t);                                            // conj(Z[l + 64 r + 512])
+    }
+    pv_prio(PH_SPLITX);
+#pragma unroll
+    for (int r = 0; r < 8; r++) S[r * 64 + l] = zhi[r];
+    wave_sync();
+    pv_prio(PH_SPLITM);
+    const pk::c32 isc{isc_, isc_};
+    pk::c32 zm[8];                                                         // every partner value first (pv_wave_kernel.hip: a read behind each magnitude store serialises the pairs)
+#pragma unroll
+    for (int r = 0; r < 8; r++) zm[r] = S[(7 - r) * 64 + 64 - l];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const pk::c32 E = pk::add_conj(zlo[r], zm[r]), O = pk::sub_conj(zlo[r], zm[r]);
+        const pk::c32 T = pk::cmul(mul_w32_inv_pk(O, r), wl2048s);         // SC conj(W_2048^{l + 64 r}) O'
+        pk::c32 xa = pk::conj_fma_j(T, isc, E), xb = pk::fnma_j(T, isc, E);
+        if (r == 0 && l == 0) {
+            xa = pk::c32{2.0f * (zlo[0].x - zlo[0].y), 0.f};
+            xb = pk::c32{2.0f * (zlo[0].x + zlo[0].y), 0.f};
+        }
+        emit(r, xa, xb);
+    }
+    if (l == 0) emit512(pk::c32{2.0f * zhi[0].x, 2.0f * zhi[0].y});        // X[512] = 2 conj(Z[512])
+}
+
+#ifndef PV_F32_REGT1_2K
+#define PV_F32_REGT1_2K true
+#endif
+// The forward transforms of the F32 instances' rare paths, out of line (pv_wave_kernel.hip, forward_cold_1024): a frame of class B (fp64), and the fp32 attempt of a
+// chain that runs the fp64 transform first.  The window is read again from memory; |X|^2 -> MAG (padded layout), the fp32 spectrum -> the stash XS in the scratch, where
+// f < 1 frames put it anyway: the caller takes XA / XB / x512f back from there.  Returns the fp32 transform's K (wide: 0).
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE float forward_cold_2k(int wide, const float *in, const float *hist, int hist_len, int sys, int vec_in, long s0u,
+                                                                         double2 w1024, double2 w2048, pk::c32 wl1024f, pk::c32 wl2048s, float isc, unsigned wave_off, int l)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    unsigned char *smem = smem_all + wave_off;
+    float *MAG = reinterpret_cast<float *>(smem + O2_ROUTE);
+    float2 *XS = reinterpret_cast<float2 *>(smem + O2_S);
+    const v4f *HW4 = reinterpret_cast<const v4f *>(smem_all + T2_HANN);
+    const WaveSrc src{in, hist, hist_len, sys != 0};
+    v4f raw[8], hw[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const long sx = s0u + 4 * l + 256 * r;                             // a multiple of 4: the four samples never straddle history / input
+        const float *q = sx < 0 ? hist + sx + hist_len : in + sx;
+        if ((sys && sx >= 0) || !vec_in) raw[r] = v4f{src.at(sx), src.at(sx + 1), src.at(sx + 2), src.at(sx + 3)};
+        else raw[r] = *reinterpret_cast<const v4f *>(q);
+        hw[r] = HW4[r * 64 + l];
+    }
+    const int pl = l + 4 * (l >> 4), ql = l + 4 * ((l + 15) >> 4);
+    float2 XA[8], XB[8], x512f{0.f, 0.f};
+    float guard_k = 0.f;
+    if (wide) {
+        spectrum64_2k(raw, hw, smem, l, w1024, w2048,
+                      [&](int r, double2 xa, double2 xb) {
+                          MAG[MAG0 + pl + 80 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                          MAG[MAG0 + 1280 - ql - 80 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                          XA[r] = float2{(float)xa.x, (float)xa.y};
+                          XB[r] = float2{(float)xb.x, (float)xb.y};
+                      },
+                      [&](double2 x512) { MAG[MAG0 + 640] = (float)(x512.x * x512.x + x512.y * x512.y); x512f = float2{(float)x512.x, (float)x512.y}; });
+    } else {
+        unsigned mmax = 0u;
+        spectrum32_2k<PV_F32_REGT1_2K>(raw, hw, smem, l, wl1024f, wl2048s, isc,
+                                       [&](int r, pk::c32 xa, pk::c32 xb) {
+                                           const float ma = mag32(xa), mb = mag32(xb);
+                                           MAG[MAG0 + pl + 80 * r] = ma;
+                                           MAG[MAG0 + 1280 - ql - 80 * r] = mb;
+                                           mmax = max(max(mmax, __float_as_uint(ma)), __float_as_uint(mb));
+                                           XA[r] = float2{xa.x, xa.y};
+                                           XB[r] = float2{xb.x, xb.y};
+                                       },
+                                       [&](pk::c32 x512) { const float m = mag32(x512); MAG[MAG0 + 640] = m; mmax = max(mmax, __float_as_uint(m)); x512f = float2{x512.x, x512.y}; });
+        guard_k = guard_k_of(wave_max_u32(mmax));
+    }
+    wave_sync();                                                           // the partner rows of the split pass have been read: the stash may overwrite them
+#pragma unroll
+    for (int r = 0; r < 8; r++) { XS[l + 64 * r] = XA[r]; XS[1024 - l - 64 * r] = XB[r]; }
+    if (l == 0) XS[512] = x512f;
+    return guard_k;
+}
+
+template <int HOPQ, bool AUX, bool RESIDENT = false, bool F32 = false>
 __global__ __launch_bounds__(RESIDENT ? 128 : 64 * WAVES2, RESIDENT ? 1 : 2) PV_NO_DS_MERGE void pv_wave2k_kernel(const PvKernelParams p)   // (resident: 2-wave workgroups, one wave per SIMD, the whole register file)
 {
+    static_assert(!F32 || !AUX, "the fp32-first forward transform is a product path, not the tap instance");
     constexpr int N = N2, M = M2, H = H2;
     constexpr bool HALF = (HOPQ == 1);
     constexpr int S_ROWS = HOPQ / 2, HOP = 128 * HOPQ, R = N / HOP, LROWS = HALF ? 8 : 8 - S_ROWS, L = N - HOP;
@@ -269,8 +426,6 @@ __global__ __launch_bounds__(RESIDENT ? 128 : 64 * WAVES2, RESIDENT ? 1 : 2) PV_
 
     W2K_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    const double2 *TW1 = reinterpret_cast<const double2 *>(smem_all + T2_TW1);
-    const double2 *TW2 = reinterpret_cast<const double2 *>(smem_all + T2_TW2);
     const v4f *TW1F4 = reinterpret_cast<const v4f *>(smem_all + T2_TW1F);
     const v4f *TW2F4 = reinterpret_cast<const v4f *>(smem_all + T2_TW2F);
     const v4f *HW4 = reinterpret_cast<const v4f *>(smem_all + T2_HANN);
@@ -330,7 +485,6 @@ resident_top:
 
     const unsigned wave_off = T2_BYTES + wv * WAVE2_LDS;
     unsigned char *smem = smem_all + wave_off;
-    double2 *S64 = reinterpret_cast<double2 *>(smem + O2_S);
     float2 *Y = reinterpret_cast<float2 *>(smem + O2_S);
     float *MAG = reinterpret_cast<float *>(smem + O2_ROUTE);
     unsigned *ROUTE = reinterpret_cast<unsigned *>(smem + O2_ROUTE);
@@ -429,6 +583,10 @@ resident_top:
     W2K_STAMP(3);
 #endif
 
+    [[maybe_unused]] unsigned n_fallback = 0, pred = 0;                  // F32: class-B frames of this chain; the order counter (pv_guard.h)
+#ifdef PV_FLIP_COUNT
+    unsigned n_flip = 0, n_uncaught = 0, n_sure = 0, n_incons = 0;
+#endif
     for (int m = first_frame; m < last_out; ++m) {
         const bool dbg = AUX && (p.dbg_mag != nullptr) && ch == p.dbg_ch && m == p.dbg_frame;
         int l = lane;
@@ -444,15 +602,8 @@ resident_top:
             for (int r = 0; r < 8; r++) hw[r] = HW4[r * 64 + l];            // the analysis window is always in the natural layout
         }
 
-        pv_prio(PH_FA);
-        // ---- Hann (pv:55), pack by parity, two 512-point fp64 FFTs, decimation-in-time stage ----
-        double2 zlo[8], zhi[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const v4f xw = raw[r] * hw[r];
-            zlo[r] = double2{(double)xw.x, (double)xw.y};                  // ze[l + 64 r] = z[2 n']
-            zhi[r] = double2{(double)xw.z, (double)xw.w};                  // zo[l + 64 r] = z[2 n' + 1]
-        }
+        float2 XA[8], XB[8];                                               // X[l + 64 r], X[1024 - l - 64 r] in fp32: what the shift needs after the decisions
+        float2 x512f{0.f, 0.f};
         if (ROWCACHE) {
             // 768 samples of the window stay in LDS for the next frame (round 4) -- the OLDEST ones the next frame still needs, its rows 0..2: the registers
             // cannot carry them through the frame (the forward FFTs need every one), and re-reading the whole 8 KB window per frame left the oldest rows
@@ -469,54 +620,198 @@ resident_top:
             }
             cache_ok = true;
         }
-        fft512_wave<double, false>(zlo, S64, TW1, TW2, l);
-        fft512_wave<double, false>(zhi, S64, TW1, TW2, l);
+        // ---- forward transform at the reference's width (spectrum64_2k): |X|^2 -> MAG, the spectrum rounded to fp32 -> XA / XB.  The only forward transform of the
+        //      !F32 instances; F32 instances run it out of line (forward_cold_2k) for the frames whose decisions the fp32 transform cannot carry ----
+        [[maybe_unused]] auto forward64 = [&]() {
+            spectrum64_2k(raw, hw, smem, l, w1024, w2048,
+                          [&](int r, double2 xa, double2 xb) {
+                              MAG[MAG0 + pl + 80 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
+                              MAG[MAG0 + 1280 - ql - 80 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
+                              XA[r] = float2{(float)xa.x, (float)xa.y};
+                              XB[r] = float2{(float)xb.x, (float)xb.y};
+                              if (dbg) {
+                                  const int ka = l + 64 * r, kb = 1024 - ka;
+                                  p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
+                                  p.dbg_X[2 * kb] = xb.x; p.dbg_X[2 * kb + 1] = xb.y;
+                              }
+                          },
+                          [&](double2 x512) {
+                              MAG[MAG0 + 640] = (float)(x512.x * x512.x + x512.y * x512.y);
+                              x512f = float2{(float)x512.x, (float)x512.y};
+                              if (dbg) { p.dbg_X[2 * 512] = x512.x; p.dbg_X[2 * 512 + 1] = x512.y; }
+                          });
+        };
+        // ---- fp32 first (round 5; spectrum32_2k): returns the absolute part K of the frame's guard band (pv_guard.h), 0 = out of the guarded range ----
+        [[maybe_unused]] auto forward32 = [&]() -> float {
+            unsigned mmax = 0u;
+            spectrum32_2k<PV_F32_REGT1_2K>(raw, hw, smem, l, wl1024f, wl2048s, 1.0f / SC,
+                                           [&](int r, pk::c32 xa, pk::c32 xb) {
+                                               const float ma = mag32(xa), mb = mag32(xb);
+                                               MAG[MAG0 + pl + 80 * r] = ma;
+                                               MAG[MAG0 + 1280 - ql - 80 * r] = mb;
+                                               mmax = max(max(mmax, __float_as_uint(ma)), __float_as_uint(mb));
+                                               XA[r] = float2{xa.x, xa.y};
+                                               XB[r] = float2{xb.x, xb.y};
+                                           },
+                                           [&](pk::c32 x512) { const float m = mag32(x512); MAG[MAG0 + 640] = m; mmax = max(mmax, __float_as_uint(m)); x512f = float2{x512.x, x512.y}; });
+            return guard_k_of(wave_max_u32(mmax));
+        };
+        // ---- shift table Math.round(p * f) - p (pv:125,147), rebuilt only when f changes ----
+        auto shift_table = [&]() {
+            const unsigned pfb = __float_as_uint(pfm);
+            if (!psh_valid || pfb != psh_key) {
+                psh_key = pfb; psh_valid = true;
+                // Math.round(p * f) - p (pv:125,147) of every candidate bin, DROP where the reference skips the peak (pv:127-129): lane l computes
+                // bins l + 64 r but needs bins 16l..16l+15, so the table is written as an image into the (free) scratch and 32 bytes are read back
+                short *IMG = reinterpret_cast<short *>(smem + O2_S);
+                const double pfd = (double)pfm;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const double2 t = cmul(w1024, mul_w16<double, false>(zhi[r], r));
-            const double2 e = zlo[r];
-            zlo[r] = cadd(e, t);                                           // Z[l + 64 r]
-            zhi[r] = csub(e, t);                                           // Z[l + 64 r + 512]
-        }
-        pv_prio(PH_SPLITX);
-        // ---- split pass in conjugate pairs: k = l + 64 r pairs with M - k = element 512 + (64 - l) + 64 (7 - r), i.e. zhi[7 - r] of lane 64 - l ----
-        float2 XA[8], XB[8];                                               // X[l + 64 r], X[1024 - l - 64 r] rounded to fp32 after the decisions
-        float2 x512f{0.f, 0.f};
-        {
+                for (int r = 0; r < 16; r++) {
+                    const int pk = l + 64 * r;
+                    const double ps = floor((double)pk * pfd + 0.5);
+                    const bool ok = (ps <= (double)H) && (ps >= -(double)(2 * N));
+                    IMG[pk] = ok ? (short)((int)ps - pk) : (short)0x4000;   // DROP pushes every target of the region out of range
+                }
+                wave_sync();
+                typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u_;
+                dq0 = *(lds_v4u_)(smem + O2_S + 32 * l);
+                dq1 = *(lds_v4u_)(smem + O2_S + 32 * l + 16);
+                wave_sync();
+            }
+        };
+        // ---- magnitudes -> peak flags (pv:95-116) for bins 16l..16l+15 ----
+        bool nonfinite = false;                                             // a magnitude of this frame is Inf or NaN (see pv_wave_kernel.hip)
+        unsigned mg[20], pm[19];
+        bool fl[16];
+        auto read_flags = [&]() {
+            typedef const volatile __attribute__((address_space(3))) v2u *lds_v2u;
+            typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
+            const v2u q0 = *(lds_v2u)(&MAG[MAG0 + 20 * l - 6]);            // bins 16 l - 2, 16 l - 1: the tail of the previous group
+            const v4u q1 = *(lds_v4u)(&MAG[MAG0 + 20 * l]);
+            const v4u q2 = *(lds_v4u)(&MAG[MAG0 + 20 * l + 4]);
+            const v4u q3 = *(lds_v4u)(&MAG[MAG0 + 20 * l + 8]);
+            const v4u q4 = *(lds_v4u)(&MAG[MAG0 + 20 * l + 12]);
+            const v2u q5 = *(lds_v2u)(&MAG[MAG0 + 20 * l + 20]);           // bins 16 l + 16, 16 l + 17: the head of the next group
+            mg[0] = q0.x; mg[1] = q0.y;
+            mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w; mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w;
+            mg[10] = q3.x; mg[11] = q3.y; mg[12] = q3.z; mg[13] = q3.w; mg[14] = q4.x; mg[15] = q4.y; mg[16] = q4.z; mg[17] = q4.w;
+            mg[18] = q5.x; mg[19] = q5.y;
 #pragma unroll
-            for (int r = 0; r < 8; r++) S64[r * 64 + l] = zhi[r];
+            for (int j = 3; j < 19; j++) pm[j] = max(mg[j], mg[j + 1]);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                // candidates are 2 <= k < H - 2 = 1023 (pv:97-100): lane 0 drops i < 2, lane 63 drops i = 15
+                const bool in_range = (i < 2) ? (l != 0) : (i == 15) ? (l != 63) : true;
+                fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
+            }
+            {
+                unsigned mx = mg[2];
+#pragma unroll
+                for (int j = 3; j < 19; j += 2) mx = max(mx, pm[j]);
+                nonfinite = __any(mx >= 0x7F800000u);
+            }
+        };
+        if constexpr (!F32) {
+            forward64();
             wave_sync();
-            pv_prio(PH_SPLITM);
+        } else {
+            // ---- the guard band and the order of the two transforms: pv_wave_kernel.hip / pv_guard.h.  This kernel keeps the fp64 transform out of line altogether ----
+            shift_table();                                                  // (its image lives in the scratch: before the transform)
+            // is any candidate bin of this lane within the band (K, R) of the largest of its four neighbours?  K = 0: the frame is out of the guarded range
+            auto in_band = [&](float K, float Rr) -> bool {
+                const pk::c32 KK{K, K}, RR{Rr, Rr};
+                float tmin = 1.0f;
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const double2 zm = S64[(7 - r) * 64 + 64 - l];             // (l = 0, r = 0) reads one element past the rows: replaced below
-                const double2 E{zlo[r].x + zm.x, zlo[r].y - zm.y};
-                const double2 O{zlo[r].x - zm.x, zlo[r].y + zm.y};
-                const double2 WO = cmul(w2048, mul_w32(O, r));
-                double2 xa{E.x + WO.y, E.y - WO.x};
-                double2 xb{E.x - WO.y, -(E.y + WO.x)};
-                if (r == 0 && l == 0) {                                    // Z[0] is pre-halved: X[0] = 2(zr + zi), X[1024] = 2(zr - zi), both real
-                    xa = double2{2.0 * (zlo[0].x + zlo[0].y), 0.0};
-                    xb = double2{2.0 * (zlo[0].x - zlo[0].y), 0.0};
+                for (int j = 0; j < 8; j++) {
+                    const int i = 2 * j;
+                    const unsigned nm0 = max(max(mg[i], mg[i + 1]), pm[i + 3]), nm1 = max(max(mg[i + 1], mg[i + 2]), pm[i + 4]);
+                    const pk::c32 c2{__uint_as_float(mg[i + 2]), __uint_as_float(mg[i + 3])}, n2{__uint_as_float(nm0), __uint_as_float(nm1)};
+                    const pk::c32 d2 = pk::sub(c2, n2), s2 = pk::add(c2, n2);
+                    pk::c32 t2 = pk::fms(d2, d2, pk::mul(pk::fma(s2, RR, KK), s2));      // (c - n)^2 - (c + n) (K + R (c + n)): <= 0 inside the band
+                    if (j == 0 && l == 0) t2 = pk::c32{1.f, 1.f};            // bins 0, 1 and 1023 are no candidates (pv:97-100)
+                    if (j == 7 && l == 63) t2.y = 1.f;
+                    tmin = fminf(fminf(tmin, t2.x), t2.y);
                 }
-                MAG[MAG0 + pl + 80 * r] = (float)(xa.x * xa.x + xa.y * xa.y);
-                MAG[MAG0 + 1280 - ql - 80 * r] = (float)(xb.x * xb.x + xb.y * xb.y);
-                XA[r] = float2{(float)xa.x, (float)xa.y};
-                XB[r] = float2{(float)xb.x, (float)xb.y};
-                if (dbg) {
-                    const int ka = l + 64 * r, kb = 1024 - ka;
-                    p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
-                    p.dbg_X[2 * kb] = xb.x; p.dbg_X[2 * kb + 1] = xb.y;
+                return !(K > 0.f) | (tmin <= 0.f);
+            };
+            auto cold = [&](int wide) -> float {
+                const float k = forward_cold_2k(wide, src.in, src.hist, src.hist_len, src.sys ? 1 : 0, vec_in ? 1 : 0, (long)(m + 1) * HOP - N, w1024, w2048, wl1024f, wl2048s,
+                                                1.0f / SC, wave_off, l);
+                wave_sync();
+                pv_prio(PH_PEAKS);
+                read_flags();
+                const float2 *XS = reinterpret_cast<const float2 *>(smem + O2_S);
+#pragma unroll
+                for (int r = 0; r < 8; r++) { XA[r] = XS[l + 64 * r]; XB[r] = XS[1024 - l - 64 * r]; }
+                x512f = XS[512];                                            // (only lane 0 uses it)
+                return k;
+            };
+#ifdef PV_FLIP_COUNT
+            const bool wide_first = false;
+#else
+            const bool wide_first = pred >= PRED_WIDE;                      // wave-uniform: this chain's frames have been coming out as class B and provably so
+#endif
+            bool fall = true;
+#ifdef PV_FLIP_COUNT
+            unsigned vb_bits = 0; float vb_q[16]; bool vb_amb = false; float vb_K = 0.f;
+#endif
+            if (!wide_first) {
+                const float guardK = forward32();
+                wave_sync();
+                pv_prio(PH_PEAKS);
+                read_flags();
+                fall = __any(in_band(guardK, GUARD_R));
+#ifdef PV_FLIP_COUNT
+                vb_K = guardK; vb_amb = fall; fall = true;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    vb_bits |= fl[i] ? (1u << i) : 0u;
+                    const float c = __uint_as_float(mg[i + 2]), n = __uint_as_float(max(max(mg[i], mg[i + 1]), pm[i + 3])), d = c - n, sm = c + n;
+                    vb_q[i] = (guardK > 0.f && sm > 0.f) ? (d * d) / (sm * (guardK + GUARD_R * sm)) : 0.f;
                 }
+#endif
             }
-            if (l == 0) {
-                const double2 x512{2.0 * zhi[0].x, -2.0 * zhi[0].y};        // k = 512 pairs with itself: X = 2 conj(Z[512])
-                MAG[MAG0 + 640] = (float)(x512.x * x512.x + x512.y * x512.y);
-                x512f = float2{(float)x512.x, (float)x512.y};
-                if (dbg) { p.dbg_X[2 * 512] = x512.x; p.dbg_X[2 * 512 + 1] = x512.y; }
+            if (__builtin_expect(fall, 0)) {
+                cold(1);
+                // what the fp64 magnitudes alone say about the class (pv_guard.h, GUARD_GN)
+                unsigned mx = mg[2];
+#pragma unroll
+                for (int j = 3; j < 19; j += 2) mx = max(mx, pm[j]);
+                const unsigned mb = wave_max_u32(mx);
+                const bool out_sure = mb < GUARD_M_MIN_BITS - GUARD_M_SLACK || mb >= GUARD_M_MAX_BITS + GUARD_M_SLACK;
+                const bool in_sure = mb >= GUARD_M_MIN_BITS + GUARD_M_SLACK && mb < GUARD_M_MAX_BITS - GUARD_M_SLACK;
+                const bool sure_b = out_sure || (in_sure && __any(in_band(GUARD_CKN * __uint_as_float(mb), GUARD_RN)));
+#ifdef PV_FLIP_COUNT
+                {
+                    unsigned diff = 0; float qmax = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) { const bool dif = (fl[i] ? 1u : 0u) != ((vb_bits >> i) & 1u); diff |= dif ? 1u : 0u; if (dif) qmax = fmaxf(qmax, vb_q[i]); }
+                    const bool flip_any = __any(diff != 0u);
+                    n_flip += flip_any ? 1u : 0u;
+                    n_uncaught += (flip_any && !vb_amb) ? 1u : 0u;
+                    n_sure += sure_b ? 1u : 0u;
+                    n_incons += (sure_b && !vb_amb) ? 1u : 0u;
+                    if (diff && p.fwd_stats) atomicMax(reinterpret_cast<unsigned *>(p.fwd_stats + 512), __float_as_uint(qmax));
+                    (void)vb_K;
+                }
+#endif
+                bool class_b = true;
+                if (wide_first && !sure_b) {
+                    // the fp64 magnitudes do not settle this frame's class: the fp32 transform after all; class B means the fp64 one once more
+                    const float k = cold(0);
+                    class_b = __any(in_band(k, GUARD_R));
+                    if (class_b) cold(1);
+                }
+                pred = (class_b && sure_b) ? min(pred + 1u, (unsigned)PRED_MAX) : (pred > 3u ? pred - 3u : 0u);
+#ifdef PV_FLIP_COUNT
+                n_fallback += vb_amb ? 1u : 0u;
+#else
+                n_fallback += class_b ? 1u : 0u;
+#endif
+            } else {
+                pred = pred > 3u ? pred - 3u : 0u;
             }
         }
-        wave_sync();
         // ---- f < 1: above-Nyquist residue, fast form, computed while Y's space can hold a stash of the fp32 spectrum (positions N/2+1 .. N/2+N/8 of
         //      fft.js's buffer = clean first half of the N/4-point sub-DFT of xw[4n+2]: W^{2k} S2[k] = (X[k] - X[k+N/4] + X[k+N/2] - X[k+3N/4]) / 4) ----
         float2 s2v[4] = {float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}};
@@ -539,64 +834,15 @@ resident_top:
             }
             wave_sync();
         }
-        // ---- shift table, rebuilt only when f changes ----
-        {
-            const unsigned pfb = __float_as_uint(pfm);
-            if (!psh_valid || pfb != psh_key) {
-                psh_key = pfb; psh_valid = true;
-                // Math.round(p * f) - p (pv:125,147) of every candidate bin, DROP where the reference skips the peak (pv:127-129): lane l computes
-                // bins l + 64 r but needs bins 16l..16l+15, so the table is written as an image into the (free) scratch and 32 bytes are read back
-                short *IMG = reinterpret_cast<short *>(smem + O2_S);
-                const double pfd = (double)pfm;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int pk = l + 64 * r;
-                    const double ps = floor((double)pk * pfd + 0.5);
-                    const bool ok = (ps <= (double)H) && (ps >= -(double)(2 * N));
-                    IMG[pk] = ok ? (short)((int)ps - pk) : (short)0x4000;   // DROP pushes every target of the region out of range
-                }
-                wave_sync();
-                typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u_;
-                dq0 = *(lds_v4u_)(smem + O2_S + 32 * l);
-                dq1 = *(lds_v4u_)(smem + O2_S + 32 * l + 16);
-                wave_sync();
-            }
+        if constexpr (!F32) {
+            shift_table();
+            pv_prio(PH_PEAKS);
+            read_flags();
         }
-        pv_prio(PH_PEAKS);
-        // ---- peak flags (pv:95-116) for bins 16l..16l+15, nearest peaks, one ROUTE word per source bin ----
+        // ---- nearest peaks, one ROUTE word per source bin ----
         int last_peak = -1, last_shift = 0;
         bool pairwise = false;                                              // f < 1: every collision is a (falling side, rising side) pair (wave-uniform)
-        bool nonfinite = false;                                             // a magnitude of this frame is Inf or NaN (see pv_wave_kernel.hip)
         {
-            unsigned mg[20];
-            typedef const volatile __attribute__((address_space(3))) v2u *lds_v2u;
-            typedef const volatile __attribute__((address_space(3))) v4u *lds_v4u;
-            const v2u q0 = *(lds_v2u)(&MAG[MAG0 + 20 * l - 6]);            // bins 16 l - 2, 16 l - 1: the tail of the previous group
-            const v4u q1 = *(lds_v4u)(&MAG[MAG0 + 20 * l]);
-            const v4u q2 = *(lds_v4u)(&MAG[MAG0 + 20 * l + 4]);
-            const v4u q3 = *(lds_v4u)(&MAG[MAG0 + 20 * l + 8]);
-            const v4u q4 = *(lds_v4u)(&MAG[MAG0 + 20 * l + 12]);
-            const v2u q5 = *(lds_v2u)(&MAG[MAG0 + 20 * l + 20]);           // bins 16 l + 16, 16 l + 17: the head of the next group
-            mg[0] = q0.x; mg[1] = q0.y;
-            mg[2] = q1.x; mg[3] = q1.y; mg[4] = q1.z; mg[5] = q1.w; mg[6] = q2.x; mg[7] = q2.y; mg[8] = q2.z; mg[9] = q2.w;
-            mg[10] = q3.x; mg[11] = q3.y; mg[12] = q3.z; mg[13] = q3.w; mg[14] = q4.x; mg[15] = q4.y; mg[16] = q4.z; mg[17] = q4.w;
-            mg[18] = q5.x; mg[19] = q5.y;
-            unsigned pm[19];
-#pragma unroll
-            for (int j = 3; j < 19; j++) pm[j] = max(mg[j], mg[j + 1]);
-            bool fl[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                // candidates are 2 <= k < H - 2 = 1023 (pv:97-100): lane 0 drops i < 2, lane 63 drops i = 15
-                const bool in_range = (i < 2) ? (l != 0) : (i == 15) ? (l != 63) : true;
-                fl[i] = in_range & (max(max(mg[i], mg[i + 1]), pm[i + 3]) < mg[i + 2]);
-            }
-            {
-                unsigned mx = mg[2];
-#pragma unroll
-                for (int j = 3; j < 19; j += 2) mx = max(mx, pm[j]);
-                nonfinite = __any(mx >= 0x7F800000u);
-            }
             if (dbg) {
 #pragma unroll
                 for (int i = 0; i < 16; i++) { p.dbg_flags[16 * l + i] = fl[i] ? 1 : 0; p.dbg_mag[16 * l + i] = __uint_as_float(mg[i + 2]); }
@@ -878,6 +1124,19 @@ resident_top:
     }
 
     W2K_STAMP(4);
+    if constexpr (F32) {
+        if (p.fwd_stats && lane == 0) {                                     // forward-transform statistics (pv_forward_stats), spread over 128 slots
+            unsigned long long *st = p.fwd_stats + 2 * (chain & 127);
+            atomicAdd(st, (unsigned long long)(last_out - first_frame));
+            if (n_fallback) atomicAdd(st + 1, (unsigned long long)n_fallback);
+#ifdef PV_FLIP_COUNT
+            if (n_flip) atomicAdd(st + 256, (unsigned long long)n_flip);
+            if (n_uncaught) atomicAdd(st + 257, (unsigned long long)n_uncaught);
+            if (n_sure) atomicAdd(p.fwd_stats + 600, (unsigned long long)n_sure);
+            if (n_incons) atomicAdd(p.fwd_stats + 601, (unsigned long long)n_incons);
+#endif
+        }
+    }
     if (chunk == p.nchunks - 1) {
         const int lend = HALF ? (lane ^ (((last_out - first_frame) & 1) << 5)) : lane;     // layout the last frame left the accumulator in
         // The history of the next call, read in ONE batch before anything is stored: written as `hs[i] = src.at(..)` the loads and stores alias as far
@@ -914,10 +1173,12 @@ resident_top:
 template <int HOPQ, bool AUX>
 hipError_t launch2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
-    static std::atomic<bool> attr_done[16];
-    auto k = pv_wave2k_kernel<HOPQ, AUX>;
+    static std::atomic<bool> attr_done[16], attr_done_f[16];
+    // the product's instances run the forward transform in fp32 first (F32; pv_guard.h); with p.fwd64 != 0 (PV_FLAG_FP64_FORWARD) and in the tap instance every frame runs the fp64 one
+    const bool f32 = !AUX && !p.fwd64;
+    auto k = f32 ? pv_wave2k_kernel<HOPQ, AUX, false, !AUX> : pv_wave2k_kernel<HOPQ, AUX, false, false>;
     {
-        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_wave2k_lds_bytes());
+        const hipError_t e = pv_set_dynamic_lds_once(f32 ? attr_done_f : attr_done, reinterpret_cast<const void *>(k), (int)pv_wave2k_lds_bytes());
         if (e != hipSuccess) return e;
     }
     PvKernelParams q = p;
@@ -940,10 +1201,11 @@ hipError_t launch2k(const PvKernelParams &p, int nch, int nchunks, hipStream_t s
 template <int HOPQ>
 hipError_t launch2k_resident(const PvKernelParams &p, int nslots, hipStream_t st)
 {
-    static std::atomic<bool> attr_done[16];
-    auto k = pv_wave2k_kernel<HOPQ, false, true>;
+    static std::atomic<bool> attr_done[16], attr_done_f[16];
+    const bool f32 = !p.fwd64;
+    auto k = f32 ? pv_wave2k_kernel<HOPQ, false, true, true> : pv_wave2k_kernel<HOPQ, false, true, false>;
     {
-        const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), (int)pv_wave2k_lds_bytes());
+        const hipError_t e = pv_set_dynamic_lds_once(f32 ? attr_done_f : attr_done, reinterpret_cast<const void *>(k), (int)pv_wave2k_lds_bytes());
         if (e != hipSuccess) return e;
     }
     PvKernelParams q = p;

@@ -5,7 +5,7 @@ Runs the validation build (`make variant NAME=flip FILE=pv_wave_kernel EXTRA=-DP
 fp32 and the fp64 forward transform and compares the two sets of peak flags, over signal classes x amplitudes x hops, and counts
     frames | frames the guard band sends to fp64 | frames whose two flag sets differ | of those NOT sent to fp64 (must be 0) | largest q of a differing bin
 (q <= 1 is what the guard calls ambiguous: sqrt(1 / q_max) is the factor by which the band could shrink before a flip escapes).
-    PHAZE_LIB=build/exp/libphaze_flip.so python tools/flip_count.py [frames-per-class] [out.json]
+    PHAZE_LIB=build/exp/libphaze_flip.so python tools/flip_count.py [frames-per-class] [out.json] [fft = 1024 | 2048 (FILE=pv_wave2k_kernel)]
 Design / evidence aid, not part of the product."""
 import ctypes as C
 import json
@@ -58,25 +58,26 @@ def gen(kind, n, dev, seed):
 def main():
     per_class = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2_000_000
     out_path = sys.argv[2] if len(sys.argv) > 2 else ""
+    fft = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
     dev = torch.device("cuda", 0)
     L = phaze_amd.load_library()
     if not hasattr(L, "pv_exp_flip_stats"):
         raise SystemExit("this library is not the validation build: PHAZE_LIB=build/exp/libphaze_flip.so")
     L.pv_exp_flip_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     kinds = ["bench", "white", "tonal60", "tonal80", "tonal100", "fuzz_noise", "fuzz_tonal", "sine32", "impulses", "chirp_am", "quantised16"]
-    T = 1 << 19
+    T = (1 << 19) * 1024 // fft
     rows, tot, tot_cls = [], np.zeros(4, np.uint64), np.zeros(2, np.uint64)
     qmax_all = 0.0
     for kind in kinds:
         acc = np.zeros(4, np.uint64); qk = 0.0; run = 0; em = np.zeros(5); cls = np.zeros(2, np.uint64)
         while int(acc[0]) < per_class:
-            hop = (256, 256, 128, 512)[run % 4]
+            hop = (fft // 4, fft // 4, fft // 8 if fft == 1024 else 128, fft // 2)[run % 4]
             amp = (1.0, 1.0, 1e-4, 1.0, 30.0, 1.0, 5e-5, 1.0)[run % 8]         # scale invariance: tiny and large signals
             pf = (1.5, 1.0, 2.0, 1.25)[run % 4]
             x = (gen(kind, T * hop, dev, run) * amp)[None, :].contiguous()
             y = torch.empty_like(x)
             pt = torch.full((T,), pf, device=dev, dtype=torch.float32)
-            pv = phaze_amd.PhaseVocoder(fft_size=1024, hop_size=hop, max_channels=1, max_hops=1)
+            pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=1, max_hops=1)
             pv.process_batch_device(x.data_ptr(), y.data_ptr(), 1, T, T * hop, pt.data_ptr(), 0, 1)
             st = (C.c_uint64 * 12)()
             assert L.pv_exp_flip_stats(pv._h, st) == 0
@@ -94,7 +95,7 @@ def main():
         tot += acc; tot_cls += cls; qmax_all = max(qmax_all, qk)
         print(f"{kind:12s} frames {int(acc[0]):10d}  fallback {100.0 * int(acc[1]) / int(acc[0]):7.3f} %  frames with flips {int(acc[2]):9d} ({100.0 * int(acc[2]) / int(acc[0]):.3f} %)  "
               f"NOT caught {int(acc[3])}  proved B from fp64 {100.0 * int(cls[0]) / int(acc[0]):7.3f} % (inconsistent {int(cls[1])})  q_max {qk:.3e}  (err-8epsA)/(eps rms) {em[0]:.1f} /(eps max) {em[1]:.2f}  (err-32epsA)/(eps rms) {em[2]:.1f} /(eps max) {em[3]:.2f}  max/rms {em[4]:.1f}", flush=True)
-    res = {"frames": int(tot[0]), "guard_fallbacks": int(tot[1]), "frames_with_flag_flips": int(tot[2]), "flips_not_caught": int(tot[3]), "q_max": qmax_all,
+    res = {"fft": fft, "frames": int(tot[0]), "guard_fallbacks": int(tot[1]), "frames_with_flag_flips": int(tot[2]), "flips_not_caught": int(tot[3]), "q_max": qmax_all,
            "class_b_proved_from_fp64_magnitudes": int(tot_cls[0]), "proved_b_but_fp32_test_says_a": int(tot_cls[1]),
            "band_shrink_margin": float(np.sqrt(1.0 / qmax_all)) if qmax_all > 0 else None, "classes": rows}
     print(json.dumps(res))
