@@ -627,27 +627,29 @@ def main():
             8192, 2048, 8, T5, sweep)
         T8 = 1 << 17
         add("8ch", f"8-ch 48 kHz FFT=1024 hop=256 pitchFactor=1.5 (the target's phrasing), 8 ch x {T8} hops resident", 1024, 256, 8, T8,
-            torch.full((T8,), 1.5, device=dev, dtype=torch.float32))
+            torch.full((T8,), 1.5, device=dev, dtype=torch.float32), steps=40, warm=10)   # as many steps as the headline: at 8 steps the fixed cost of a timed region
+                                                                                         # (two synchronizes, two events: ~1 ms of wall clock) read as a 5-8 % "gap" to mono
+                                                                                         # in rounds 3-4; by HIP events the two launches differ by 0.7 % (tools/stride_probe.py)
         add("native", f"the reference's shipped configuration (phase-vocoder.js:6, ola-processor.js:3): stereo 48 kHz FFT=2048 hop=128 (16 overlaps), "
             f"pitchFactor=1.0, 2 ch x {T3} hops resident", 2048, 128, 2, T3, torch.full((T3,), 1.0, device=dev, dtype=torch.float32))
         # the unfavourable half of the reference's parameter range (sliders give f in [0.33, 3], www/index.html:23,28): f < 1 compresses the
         # regions, the scatter collides (pv:169-170) and the last region reads above Nyquist
         T2 = 1 << 20
         add("f0.8", f"headline shape at pitchFactor=f32(0.8): mono 48 kHz FFT=1024 hop=256, 1 ch x {T2} hops resident", 1024, 256, 1, T2,
-            torch.full((T2,), 0.8, device=dev, dtype=torch.float32), steps=12, warm=4)
+            torch.full((T2,), 0.8, device=dev, dtype=torch.float32), steps=24, warm=6)
         sw = (0.5 + 1.5 * (torch.arange(T2, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
         add("sweep", f"headline shape with pitchFactor swept 0.5->2.0 per hop (period 64 hops): mono 48 kHz FFT=1024 hop=256, 1 ch x {T2} hops resident",
-            1024, 256, 1, T2, sw, steps=12, warm=4)
+            1024, 256, 1, T2, sw, steps=24, warm=6)
         # ---- the fp32-first forward transform from both sides (round 5): the same launch with every forward FFT in f64 (PV_FLAG_FP64_FORWARD: the round-4 kernels), on white
         #      noise (no frame falls back) and on two clean partials over a -80 dB floor (EVERY frame falls back: the worst case) ----
         p15 = torch.full((T2,), 1.5, device=dev, dtype=torch.float32)
         add("fwd64", f"headline shape with PV_FLAG_FP64_FORWARD (every forward FFT in f64: the round-4 arithmetic): mono 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 1 ch x {T2} hops resident",
-            1024, 256, 1, T2, p15, steps=12, warm=4, flags=phaze_amd.FLAG_FP64_FORWARD)
+            1024, 256, 1, T2, p15, steps=24, warm=6, flags=phaze_amd.FLAG_FP64_FORWARD)
         add("white", f"headline shape on WHITE NOISE (uniform, amplitude 0.5): mono 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 1 ch x {T2} hops resident",
-            1024, 256, 1, T2, p15, steps=12, warm=4, signal="white")
+            1024, 256, 1, T2, p15, steps=24, warm=6, signal="white")
         add("tonal80", f"headline shape on TWO CLEAN PARTIALS over a -80 dB noise floor (worst case of the fp32-first forward transform: every frame re-runs it in f64): "
-            f"mono 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 1 ch x {T2} hops resident", 1024, 256, 1, T2, p15, steps=12, warm=4, signal="tonal80")
-        add("tonal80_fwd64", "the same signal with PV_FLAG_FP64_FORWARD", 1024, 256, 1, T2, p15, steps=12, warm=4, signal="tonal80", flags=phaze_amd.FLAG_FP64_FORWARD)
+            f"mono 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 1 ch x {T2} hops resident", 1024, 256, 1, T2, p15, steps=24, warm=6, signal="tonal80")
+        add("tonal80_fwd64", "the same signal with PV_FLAG_FP64_FORWARD", 1024, 256, 1, T2, p15, steps=24, warm=6, signal="tonal80", flags=phaze_amd.FLAG_FP64_FORWARD)
         # ---- the reference-width flavour of the headline kernel (never the product; build/exp/libphaze_fp64.so, `make -C phaze_amd/csrc fp64`): shifted spectrum,
         #      scatter, residue, c2r pass and inverse FFT in fp64 like the reference's JS doubles.  A library is chosen at import time, so it runs in a child ----
         flib = os.path.join(ROOT, "build", "exp", "libphaze_fp64.so")

@@ -44,6 +44,9 @@ struct pv_handle {
     float *d_stage_in, *d_stage_out, *d_pitch;   // host-buffer batch staging
     unsigned *d_chain_list;                      // N = 1024 batch launches: chain classes (pv_launch_wave), 2 + 2 * chain_list_cap words
     long chain_list_cap;
+    float *d_snap;                               // pipelined host-buffer batch cut into spans of hops: copy of the live half of the channel state (hist | acc), taken
+    size_t snap_floats;                          //   before the first piece so that a failure in a later piece can put the handle back (allocated on first use)
+    unsigned idle_ticks;                         // resident kernels: constant-rate clock ticks (wall_clock64) after which waves without work leave (~50 ms)
     bool fwd64;                                  // PV_FLAG_FP64_FORWARD: every frame's forward transform in fp64 (the round-4 kernels)
     unsigned long long *d_fwd_stats;             // 128 x {frames computed by an fp32-first instance, frames of those that fell back to fp64} (pv_forward_stats)
     hipStream_t s_in, s_out;                     // pipelined host-buffer batch: H2D of piece k+1 || kernel of piece k || D2H of piece k-1 (created on first use)
@@ -238,6 +241,12 @@ bool host_pinned(const void *ptr)
     if (hipPointerGetAttributes(&a, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
 }
+// ... the whole range [ptr, ptr + bytes): a buffer that is only partly registered (hipHostRegister on a sub-range, a view that runs past its registration) must not
+// take the asynchronous DMA path
+bool host_pinned_range(const void *ptr, size_t bytes)
+{
+    return host_pinned(ptr) && (bytes == 0 || host_pinned(static_cast<const char *>(ptr) + bytes - 1));
+}
 
 // ---- resident streaming kernel (PV_FLAG_PERSISTENT_STREAM) ----
 // One word handed to the resident waves: everything written before it (input, pitchFactor, parameters) is in memory first, and the word itself leaves
@@ -284,6 +293,7 @@ int resident_start(pv_handle *h, unsigned last_seq)
     p.dbg_ch = -1; p.dbg_frame = -1;
     p.done = h->d_done; p.done_seq = last_seq;
     p.ctl = h->d_ctl;
+    p.idle_ticks = h->idle_ticks;
     p.in_cached = h->resident_in_bar ? 1 : 0;
     resident_publish(h, h->h_ctl + 4, 0u);
     // stale completion words must not match a future 16-bit sequence number (a slot unused for exactly 65535 quanta)
@@ -367,6 +377,13 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     h->active_nch = -1;
     h->host_channels = (cfg->flags & PV_FLAG_HOST_CHANNEL_BOOKKEEPING) != 0;
     h->fwd64 = (cfg->flags & PV_FLAG_FP64_FORWARD) != 0;
+    {
+        // the resident waves leave after ~50 ms without work, measured on the device's constant-rate clock (wall_clock64): the host stops and restarts them by ITS
+        // wall clock after 20 ms (pv_process_begin), so the device-side figure must never come out below that -- a poll COUNT did, depending on where the control block lives
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device_id) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+        h->idle_ticks = (unsigned)khz * 50u;
+    }
     {
         const bool generic = (cfg->flags & PV_FLAG_GENERIC_KERNEL) != 0;      // explicit A/B switch (tests, measurements); no environment is read
         h->use_wave = pv_wave_supported(log2n, hop) && !generic;
@@ -521,6 +538,7 @@ int pv_destroy(pv_handle *h)
     (void)hipFree(h->d_stage_in); (void)hipFree(h->d_stage_out); (void)hipFree(h->d_pitch);
     if (h->d_chain_list) (void)hipFree(h->d_chain_list);
     (void)hipFree(h->d_fwd_stats);
+    if (h->d_snap) (void)hipFree(h->d_snap);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_done) (void)hipHostFree((void *)h->h_done);
     if (h->h_ctl) { if (h->resident_bar) (void)hipFree((void *)h->h_ctl); else (void)hipHostFree((void *)h->h_ctl); }
@@ -883,8 +901,9 @@ int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int
     //   * groups of whole streams (contiguous channel rows: the largest DMA segments, no extra halo) when the batch has enough of them, else
     //   * spans of hops: consecutive calls on the carried state, bit-identical to one call (tests: call-splitting invariance).
     // The kernel rate is 10-30x the PCIe rate, so the pieces only have to be large enough for the DMA engines.
-    const bool pinned = host_pinned(in) && host_pinned(out);
     const size_t row_bytes = row * sizeof(float), total = row_bytes * (size_t)nch;
+    const size_t span_bytes = ((size_t)(nch - 1) * (size_t)ch_stride + row) * sizeof(float);       // what the 2D copies touch
+    const bool pinned = host_pinned_range(in, span_bytes) && host_pinned_range(out, span_bytes);
     int pieces = 1;
     bool by_channel = false;
     if (pinned && total >= ((size_t)4 << 20)) {
@@ -901,6 +920,7 @@ int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int
         if (pieces > kMaxPieces) pieces = kMaxPieces;
         if (pieces < 1) pieces = 1;
     }
+    size_t snap_fl = 0;                                                      // > 0: the state snapshot of a hop-span pipeline has been taken
     auto batch = [&]() -> int {
         if (pieces > 1 && !h->pipe_ready) {
             HIPCHK(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
@@ -924,6 +944,21 @@ int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int
         // the device staging buffers hold the WHOLE batch (planar, row = nhops * hop floats per channel): pieces never share bytes, no buffer is
         // reused inside a call, so the only ordering is H2D(k) -> kernel(k) -> D2H(k)
         const int groups = nch / cps;
+        if (!by_channel) {
+            // spans of hops commit the state ping-pong piece by piece: after two pieces both halves are overwritten.  A copy of the live half (every slot in use),
+            // taken before the first piece, is what a failure in a later piece is rolled back to
+            const int used = nch > h->used_channels ? nch : h->used_channels;
+            const size_t fl = (size_t)used * (size_t)(h->L > 0 ? h->L : 1);
+            if (2 * fl > h->snap_floats) {
+                if (h->d_snap) (void)hipFree(h->d_snap);
+                h->d_snap = nullptr; h->snap_floats = 0;
+                HIPCHK(h, hipMalloc(&h->d_snap, 2 * fl * sizeof(float)));
+                h->snap_floats = 2 * fl;
+            }
+            HIPCHK(h, hipMemcpyAsync(h->d_snap, h->d_hist[h->cur], fl * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->d_snap + fl, h->d_acc[h->cur], fl * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+            snap_fl = fl;
+        }
         for (int k = 0; k < pieces; k++) {
             int c0 = 0, cn = nch, m0 = 0, mn = nhops;
             if (by_channel) { c0 = (int)((long)groups * k / pieces) * cps; cn = (int)((long)groups * (k + 1) / pieces) * cps - c0; }
@@ -952,6 +987,11 @@ int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int
         (void)hipStreamSynchronize(h->stream);
         (void)hipGetLastError();
         h->cur = before.cur; h->time_cursor = before.time_cursor; h->active_nch = before.active_nch;
+        if (snap_fl) {                                                       // pieces of a hop-span pipeline may have overwritten the half that is live again: put it back
+            const bool ok = hipMemcpy(h->d_hist[h->cur], h->d_snap, snap_fl * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess &&
+                            hipMemcpy(h->d_acc[h->cur], h->d_snap + snap_fl, snap_fl * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); (void)pv_reset(h); return fail(h, PV_ERR_DEVICE, "pv_process_batch: failed, and the channel state could not be restored: the handle has been reset"); }
+        }
     }
     return rc;
 }

@@ -38,6 +38,7 @@ struct PvKernelParams {
     // next sequence number.  ctl = {seq, nch, t0_mod_n, cur, stop}; state2[] = both halves of the state ping-pong (cur selects hist_in / acc_in).
     const unsigned *ctl;
     float *hist2[2], *acc2[2];
+    unsigned idle_ticks;      // resident form: wall_clock64() ticks without work after which the waves leave (~50 ms; the host restarts them on demand)
     int in_cached;            // resident form: `in` / `pitch` are DEVICE memory the host rewrites through the BAR (cached in L2: system-scope loads);
                               // 0 = pinned host memory (uncached on the device: plain, coalesced loads behind the acquire fence of the poll)
     // N = 1024 batch launches: the chains of the launch sorted into two classes by pv_classify_chains (pv_wave_kernel.hip) -- chain_list[0 .. nchains) holds the

@@ -463,11 +463,12 @@ __global__ __launch_bounds__(RESIDENT ? 128 : 64 * WAVES2, RESIDENT ? 1 : 2) PV_
 resident_top:
     if (RESIDENT) {
         // the control word of pv_wave_kernel_1024's resident form: sequence number (16 bits, never 0) | channel count (7) | ping-pong half (1) | timeCursor / hop mod R (8)
-        unsigned word, idle = 0;
+        unsigned word;
+        const unsigned long long idle0 = wall_clock64();
         for (;;) {
             word = __hip_atomic_load(p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((word & 0xFFFFu) != (last_seq & 0xFFFFu)) break;
-            if (__hip_atomic_load(p.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || ++idle > 60000u) return;   // asked to leave, or ~50 ms without work
+            if (__hip_atomic_load(p.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || wall_clock64() - idle0 > (unsigned long long)p.idle_ticks) return;   // asked to leave, or ~50 ms without work
             __builtin_amdgcn_s_sleep(2);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");

@@ -711,12 +711,13 @@ resident_top:
     if (RESIDENT) {
         // ctl[0] carries the whole quantum in ONE word -- sequence number (low 16 bits, never 0), channel count (7 bits), ping-pong half (1 bit),
         // timeCursor / hop mod R (8 bits) -- so that a successful poll needs no second round trip over PCIe before the input can be requested
-        unsigned word, idle = 0;
+        unsigned word;
+        const unsigned long long idle0 = wall_clock64();
         for (;;) {
             word = __hip_atomic_load(p.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((word & 0xFFFFu) != (last_seq & 0xFFFFu)) break;
             // leave when asked to, or after ~50 ms without work (the host relaunches on demand: a resident wave must never outlive its user)
-            if (__hip_atomic_load(p.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || ++idle > 60000u) return;
+            if (__hip_atomic_load(p.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || wall_clock64() - idle0 > (unsigned long long)p.idle_ticks) return;
             __builtin_amdgcn_s_sleep(2);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                    // system scope: what the host wrote before the word

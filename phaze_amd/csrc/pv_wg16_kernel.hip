@@ -480,11 +480,12 @@ resident_top:
     if (RESIDENT) {
         unsigned *BC = reinterpret_cast<unsigned *>(smem + C::OFF_OCC + 48);
         if (t == 0) {
-            unsigned word, idle = 0;
+            unsigned word;
+            const unsigned long long idle0 = wall_clock64();
             for (;;) {
                 word = __hip_atomic_load(p.ctl + 16 + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if ((word & 0xFFFFu) != (last_seq & 0xFFFFu)) break;
-                if (__hip_atomic_load(p.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || ++idle > 60000u) { word = 0u; break; }
+                if (__hip_atomic_load(p.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || wall_clock64() - idle0 > (unsigned long long)p.idle_ticks) { word = 0u; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             BC[0] = word;

@@ -420,7 +420,10 @@ static napi_value js_batch_window(napi_env env, napi_callback_info info)
  * buffers (what a caller of OLAProcessor.process does, ola-processor.js:159-171) allocates them here and writes its streams in place. */
 static void finalize_pinned(napi_env env, void *data, void *hint)
 {
-    (void)env; (void)hint;
+    /* hint = the block's size: V8 is told that the external memory is gone (it was told about it in allocPinned: page-locked memory is scarce, and an engine that
+     * does not see the bytes behind an external ArrayBuffer has no reason to collect it -- create / close cycles of sharded hosts pinned 2 x 268 MB each) */
+    int64_t after = 0;
+    if (env) (void)napi_adjust_external_memory(env, -(int64_t)(uintptr_t)hint, &after);
     pv_host_free(data);
 }
 
@@ -437,7 +440,8 @@ static napi_value js_alloc_pinned(napi_env env, napi_callback_info info)
     if (rc != PV_OK) return throw_status(env, NULL, rc);
     memset(p, 0, n * sizeof(float));
     napi_value ab, ta;
-    if (napi_create_external_arraybuffer(env, p, n * sizeof(float), finalize_pinned, NULL, &ab) != napi_ok) { pv_host_free(p); napi_throw_error(env, NULL, "napi_create_external_arraybuffer failed"); return NULL; }
+    if (napi_create_external_arraybuffer(env, p, n * sizeof(float), finalize_pinned, (void *)(uintptr_t)(n * sizeof(float)), &ab) != napi_ok) { pv_host_free(p); napi_throw_error(env, NULL, "napi_create_external_arraybuffer failed"); return NULL; }
+    { int64_t after = 0; (void)napi_adjust_external_memory(env, (int64_t)(n * sizeof(float)), &after); }
     NAPI_OK_OR_THROW(env, napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta), "napi_create_typedarray failed");
     return ta;
 }

@@ -115,7 +115,8 @@ class ShardedPhaseVocoder {
 
     info() { return this._handles.map((h) => native.info(h)); }
 
-    close() { for (const h of this._handles) native.destroy(h); this._handles = []; }
+    // (the page-locked shard buffers go with their last reference: dropped here, so that a host that creates and closes sharded processors does not keep them pinned)
+    close() { for (const h of this._handles) native.destroy(h); this._handles = []; this._in = []; this._out = []; this._pitch = []; }
 }
 
 module.exports = { ShardedPhaseVocoder };

@@ -64,12 +64,13 @@ def test_pinned_batch_is_pipelined_and_bit_identical(fft, hop, nch, T, cps, pf):
     assert np.array_equal(got.view(np.uint32), ref2.view(np.uint32))
     K = min(T, 24)
     o = oracle_lib.Oracle(fft, hop, cps).process_planar(x[:cps, :K * hop], np.ascontiguousarray(pitch[0, :K] if pitch.ndim == 2 else pitch[:K]))
-    assert S.rms(ref[:cps, :K * hop].astype(np.float64) - o) < 2e-6
+    assert S.rms(ref[:cps, :K * hop].astype(np.float64) - o) < 2e-7
 
 
-def test_pinned_batch_keeps_other_slots_and_rolls_back():
+def test_pinned_batch_keeps_other_slots_and_a_mixed_buffer_pair_takes_the_plain_path():
     """A pipelined call over nch < used_channels slots carries the other slots' state across the flip(s); a mixed pinned / pageable pair of
-    buffers takes the unpipelined path with the same bits."""
+    buffers takes the unpipelined path with the same bits.  (The roll-back of a pipelined call that fails in a later piece -- the state snapshot in pv_process_batch --
+    has no test: nothing short of a device fault makes a piece fail.)"""
     import phaze_amd
     fft, hop, T = 1024, 256, 8192
     x = _x(3, T * hop, 5)

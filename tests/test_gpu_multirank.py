@@ -95,7 +95,7 @@ def test_rccl_branch_runs_on_hardware_at_world_size_one():
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["n_gpus"] == 1 and j["dist_backend"] == "nccl"
     assert np.isfinite(j["scatter_gather_ms"]) and j["scatter_gather_ms"] > 0
-    assert j["parity_rms_vs_oracle"] < 2e-6 and len(j["timed_regions"]["kernel_ms"]) == 5
+    assert j["parity_rms_vs_oracle"] < 2e-7 and len(j["timed_regions"]["kernel_ms"]) == 5
 
 
 def test_two_bench_ranks_on_one_gpu_run_the_multi_rank_line_end_to_end():
@@ -116,4 +116,4 @@ def test_two_bench_ranks_on_one_gpu_run_the_multi_rank_line_end_to_end():
     assert j["scatter_gather"]["branch"].startswith("send / recv") and j["scatter_gather"]["round_trip_intact"] is True and j["scatter_gather"]["rank0_streams"] == 2
     # whole-job value = frames of BOTH ranks / slowest rank's time (shard.aggregate_rate)
     assert abs(j["value"] - 2 * 8192 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-6
-    assert j["parity_rms_vs_oracle"] < 2e-6 and j["scaling"] == "weak"
+    assert j["parity_rms_vs_oracle"] < 2e-7 and j["scaling"] == "weak"

@@ -14,7 +14,8 @@ import signals as S
 pytestmark = pytest.mark.gpu
 
 PARITY_BAR_RMS = 1e-4        # the north-star tolerance
-REGRESSION_RMS = 2e-6        # what this implementation actually has to hold
+REGRESSION_RMS = 2e-7        # what this implementation actually has to hold (round 5: was 2e-6; worst observed 8e-8 over the fuzz, typically 5e-9 .. 1.5e-8:
+                             # N = 1024 / 2048 frames whose decisions the fp32 forward transform carries take their source spectrum from it, ~1e-7 of the frame's rms)
 
 MAN = S.load_manifest()
 CASES = {c["name"]: c for c in MAN["cases"]}
@@ -62,7 +63,11 @@ def test_streaming_process_matches_reference_golden(name, flags):
     through pinned memory."""
     case = CASES[name]
     sig, pitch = _inputs(case)
-    T, h = min(case["store_hops"], 24), case["hop"]
+    h = case["hop"]
+    # every hop of the cases whose events lie late (the outputs-do-not-mirror-inputs cases: an input that disappears and returns at hops 30 .. 50) in the default form;
+    # 24 hops elsewhere (the other forms run the same C-ABI entry points)
+    late = any(e["hop"] >= 24 for e in case.get("events", []))
+    T = case["store_hops"] if (late and flags == 0) else min(case["store_hops"], 24)
     nmax = S.case_max_channels(case)
     # cases whose outputs do not mirror their inputs ('out_channels' events: ola-processor.js:46-51 reallocates the output buffers on its own): the host does
     # the reference's bookkeeping (PV_FLAG_HOST_CHANNEL_BOOKKEEPING; phaze_amd.PhaseVocoder.process / phase-vocoder.js) with pv_reset_channels_part

@@ -7,7 +7,7 @@ import oracle_lib
 import signals as S
 
 pytestmark = pytest.mark.gpu
-REGRESSION_RMS = 2e-6
+REGRESSION_RMS = 2e-7
 GENERIC = 1          # PV_FLAG_GENERIC_KERNEL
 
 

@@ -52,7 +52,7 @@ def test_every_hand_over_form_gives_the_same_bits(fft, hop, nch):
         assert bad.size == 0, f"flags={flags}: first differing sample {bad[0]} (hop {bad[0] // hop}) of {bad.size}"
     K = 40
     ref = oracle_lib.Oracle(fft, hop, nch).process_planar(x[:, :K * hop], pitch[:K])
-    assert S.rms(base[:, :K * hop].astype(np.float64) - ref) < 2e-6
+    assert S.rms(base[:, :K * hop].astype(np.float64) - ref) < 2e-7
 
 
 def test_resident_kernel_survives_other_calls_on_the_handle():

@@ -93,7 +93,7 @@ def test_node_process_matches_reference_golden(name, flags, tmp_path):
     gold = S.load_golden_out(case)
     err = S.rms(got[:case["store_ch"]].astype(np.float64) - gold)
     assert np.all(np.isfinite(got))
-    assert err < 2e-6, f"{name}: rms {err:.3e}"
+    assert err < 2e-7, f"{name}: rms {err:.3e}"
     print(name, json.loads(r.stdout.strip().splitlines()[-1])["us_per_call"], "us/call")
 
 
@@ -119,7 +119,7 @@ def test_node_two_inputs_match_reference_golden(case, flags, tmp_path):
     got = np.fromfile(tmp_path / "out.f32", dtype="<f4")
     gold = np.concatenate([g.ravel() for g in S.load_golden_multi(case)])
     assert got.shape == gold.shape and np.all(np.isfinite(got))
-    assert S.rms(got.astype(np.float64) - gold) < 2e-6
+    assert S.rms(got.astype(np.float64) - gold) < 2e-7
 
 
 @pytest.mark.gpu
@@ -157,7 +157,7 @@ def test_wav_cli_shifts_pitch(tmp_path):
 def test_node_sharded_streams_in_flight_together(fft, hop, streams, cps, shards, pf, tmp_path):
     """Multi-GPU through the product boundary (independence: phase-vocoder.js:49-50,71): ONE Node process, stream s -> handle s mod G,
     every handle's batch started through the addon's asynchronous entry before the first wait.  On the one-GPU box the G handles share device 0
-    (two kernels in flight on two HIP streams).  The gathered result equals ONE handle bit for bit and the oracle to 2e-6; the busy guard,
+    (two kernels in flight on two HIP streams).  The gathered result equals ONE handle bit for bit and the oracle to 2e-7; the busy guard,
     the async/sync equivalence and a mid-stream migration through exportState / importState are checked on the way."""
     _build()
     T = 12
@@ -180,7 +180,7 @@ def test_node_sharded_streams_in_flight_together(fft, hop, streams, cps, shards,
     got = np.fromfile(tmp_path / "out.f32", dtype="<f4").reshape(streams * cps, T * hop)
     for s in (0, streams - 1):
         ref = oracle_lib.Oracle(fft, hop, cps).process_planar(x[s * cps:(s + 1) * cps], p[s])
-        assert S.rms(got[s * cps:(s + 1) * cps].astype(np.float64) - ref) < 2e-6
+        assert S.rms(got[s * cps:(s + 1) * cps].astype(np.float64) - ref) < 2e-7
 
 
 @pytest.mark.gpu
