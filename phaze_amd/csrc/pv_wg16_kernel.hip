@@ -43,6 +43,26 @@ namespace {
 #ifndef PV_WG16_PT12
 #define PV_WG16_PT12 2, 0, 3, 1, 0, 2, 3, 3, 1
 #endif
+// Phase clock of a THROUGHPUT launch (measurement build only: make variant NAME=wg16ph FILE=pv_wg16_kernel EXTRA=-DPV_WG16_PH CAPI_EXTRA=-DPV_STAMPS=1; tools/read_wg16_phases.py;
+// profiles/r05_wg16_phase_clock.md): s_memtime deltas accumulated per phase by every wave, written by wave 0 of a workgroup at the end of its chain.  A mark that
+// follows a barrier books the wait at that barrier to the phase it closes.
+#ifdef PV_WG16_PH
+struct W16Clock {
+    unsigned prev, acc[20];
+    static __device__ __forceinline__ unsigned now() { __builtin_amdgcn_sched_barrier(0); const unsigned t = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); return t; }
+    __device__ __forceinline__ void start() { for (int i = 0; i < 20; i++) acc[i] = 0; prev = now(); }
+    __device__ __forceinline__ void operator()(int id) { const unsigned t = now(); acc[id] += t - prev; prev = t; }
+};
+#define W16_MARK(id) w16clk(id)
+#define W16_ST , [&](int id) { w16clk(id); }
+#define W16_STI , [&](int id) { w16clk(11 + id); }
+#else
+#define W16_MARK(id)
+#define W16_ST
+#define W16_STI
+#endif
+struct W16NoMark { __device__ __forceinline__ void operator()(int) const {} };
+
 template <int PH, int T_> __device__ __forceinline__ void wg16_prio()
 {
     constexpr int t13[] = {PV_WG16_PT13}, t12[] = {PV_WG16_PT12};
@@ -176,8 +196,8 @@ struct TwA { double2 w1, w2, w4, w8; };
 
 // M = 4096-point complex FFT across the workgroup: in  thread t, reg r <-> element ts + 256 r (ts = (t >> 4) + 16 (t & 15)),
 //                                                     out thread t, reg r <-> bin t + 256 r.  S: the 64 KB scratch.
-template <int T_>
-__device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA &tw, const double2 *TWB, int t)
+template <int T_, typename ST = W16NoMark>
+__device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA &tw, const double2 *TWB, int t, ST st = ST{})
 {
     radix16_fwd(a);
     {
@@ -190,17 +210,20 @@ __device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA
     // exchange inside the groups of 16 lanes: [reg k0][lane n1] -> [reg n1][lane k0]; element (k0, n1) of group g at 256 g + 16 k0 + (n1 ^ k0)
     const int c = t & 15, g = t >> 4;
     double2 *Sg = S + 256 * g;
+    st(0);
     wg16_prio<1, T_>();
 #pragma unroll
     for (int k = 0; k < 16; k++) Sg[16 * k + (c ^ k)] = a[k];
     wave_sync();                                                        // the 16 lanes of a group sit in one wave: LDS traffic of a wave executes in order
 #pragma unroll
     for (int n = 0; n < 16; n++) a[n] = Sg[16 * c + (n ^ c)];
+    st(1);
     wg16_prio<0, T_>();
     radix16_fwd(a);
     constexpr int K2 = T_ / 16;
 #pragma unroll
     for (int k = 1; k < 16; k++) a[k] = dmul(a[k], TWB[(k - 1) * K2 + g]);
+    st(2);
     wg16_prio<1, T_>();
     __syncthreads();                                                    // every wave is done with its in-wave exchange: the rows below overwrite other waves' groups
 #pragma unroll
@@ -212,6 +235,7 @@ __device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA
 #pragma unroll
         for (int n = 0; n < K2; n++) a[K2 * h + n] = S[T_ * (g + K2 * h) + 16 * n + c];
     __syncthreads();                                                    // the scratch is free again
+    st(3);
     wg16_prio<0, T_>();
     if (K2 == 16) {
         radix16_fwd(a);
@@ -224,14 +248,15 @@ __device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA
 #pragma unroll
         for (int k = 0; k < 8; k++) { a[2 * k] = lo[k]; a[2 * k + 1] = hi[k]; }
     }
+    st(4);
 }
 
 // The inverse in packed fp32, the same passes backwards: in thread t, reg r <-> bin t + 256 r, out thread t, reg r <-> element ts + 256 r.
 // The caller guarantees that nobody still reads the first 32 KB of the scratch; the data of the cross-wave exchange is consumed before the function returns its
 // in-wave exchange, which lives in the SECOND 32 KB (no barrier between the two).
 struct TwAf { pk::c32 w1, w2, w4, w8; };
-template <int T_>
-__device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, const TwAf &tw, const pk::c32 *TWBF, int t)
+template <int T_, typename ST = W16NoMark>
+__device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, const TwAf &tw, const pk::c32 *TWBF, int t, ST st = ST{})
 {
     const int c = t & 15, g = t >> 4;
     constexpr int K2 = T_ / 16;
@@ -247,6 +272,7 @@ __device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, co
 #pragma unroll
         for (int n = 0; n < 8; n++) { a[n] = lo[n]; a[8 + n] = hi[n]; }
     }
+    st(0);
     wg16_prio<4, T_>();
 #pragma unroll
     for (int h = 0; h < 16 / K2; h++)
@@ -255,17 +281,20 @@ __device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, co
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) a[k] = S[T_ * k + t];                  // thread (n0 = g, k0 = c), reg k1
+    st(1);
     wg16_prio<3, T_>();
 #pragma unroll
     for (int k = 1; k < 16; k++) a[k] = pk::cmul(a[k], TWBF[(k - 1) * K2 + g]);
     radix16_inv_pk(a);
     pk::c32 *Sg = S + 16 * T_ + 256 * g;                                // second half of the scratch (fp32 elements are half the size)
+    st(2);
     wg16_prio<4, T_>();
 #pragma unroll
     for (int n = 0; n < 16; n++) Sg[16 * c + (n ^ c)] = a[n];           // thread (n0, k0 = c), reg n1 = n
     wave_sync();
 #pragma unroll
     for (int k = 0; k < 16; k++) a[k] = Sg[16 * k + (c ^ k)];           // thread (n0, n1 = c), reg k0
+    st(3);
     wg16_prio<3, T_>();
     {
         const pk::c32 w3 = pk::cmul(tw.w1, tw.w2), w5 = pk::cmul(tw.w4, tw.w1), w6 = pk::cmul(tw.w4, tw.w2), w7 = pk::cmul(tw.w4, w3);
@@ -276,6 +305,7 @@ __device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, co
         a[15] = pk::cmul(a[15], pk::cmul(tw.w8, w7));
     }
     radix16_inv_pk(a);
+    st(4);
 }
 
 // o * W_32^r (fp64, split pass) and o * exp(+2 pi j r / 32) (packed fp32, c2r pass), r = 0..7 compile-time: the row part of W_8192^{t + 256 r}
@@ -551,6 +581,10 @@ resident_top:
     int emit_v = first_out;
     asm volatile("" : "+v"(emit_v));
     __syncthreads();
+#ifdef PV_WG16_PH
+    W16Clock w16clk;
+    w16clk.start();
+#endif
 
     for (int m = first_frame; m < last_out; ++m) {
         int tq = t;
@@ -580,7 +614,7 @@ resident_top:
 #pragma unroll
             for (int r = 0; r < 16; r++) XQ[(tsq + T * r - 1) >> 1] = raw[r].x * (2.0f * hw[r].x);
         }
-        fft_wg16<T>(z, S64, twa, TWB, tq);
+        fft_wg16<T>(z, S64, twa, TWB, tq W16_ST);
 
         // ---- split pass in conjugate pairs: thread tq owns the pairs k = tq + 256 r, r < 8: XA[r] = X[k], XB[r] = X[M - k]; thread 0 also the self-paired bin M/2.
         //      The partner values Z[M - k] are rows 8..15 of other threads -> LDS ----
@@ -656,7 +690,9 @@ resident_top:
                 dq1 = v4u{sh[8] | (sh[9] << 16), sh[10] | (sh[11] << 16), sh[12] | (sh[13] << 16), sh[14] | (sh[15] << 16)};
             }
         }
+        W16_MARK(5);
         __syncthreads();                                                   // magnitudes (and the stash) complete
+        W16_MARK(6);
         // ---- above-Nyquist residue, fast form: W^{2k} S2[k] = (X[k] - X[k+N/4] + X[k+N/2] - X[k+3N/4]) / 4, k = 1 + tq + 256 j (see pv_wg_kernel.hip) ----
         float2 s2v[4] = {float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}};
         if (pf < 1.0) {
@@ -733,6 +769,7 @@ resident_top:
             if (l == 0) OCC[wv] = occ;
         }
         __syncthreads();                                                   // also: every MAG read is done -> ROUTE may overwrite MAG
+        W16_MARK(7);
         int cprev = NEGPD, cnext = POSPD, last_peak = -1, last_shift = 0;
         {
             const unsigned long long mine = OCC[wv];
@@ -805,6 +842,7 @@ resident_top:
         if (tq == 0) Y[M] = float2{0.f, 0.f};
         const bool need_res = upper_end > H;
         __syncthreads();
+        W16_MARK(8);
         wg16_prio<7, T>();
         // ---- shiftPeaks (pv:119-173) ----
         {
@@ -918,6 +956,7 @@ resident_top:
         }
         if (nonfinite && l == 0) Y[1 + wv] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};   // the reference's frame is NaN: so is this one
         __syncthreads();
+        W16_MARK(9);
         if (dbg) {
 #pragma unroll
             for (int r = 0; r < 16; r++) { const int k = tq + T * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
@@ -963,7 +1002,8 @@ resident_top:
         }
         const float2 f1 = cconj(p.tw32[(2 * tsi) & (N - 1)]), f2 = cconj(p.tw32[(4 * tsi) & (N - 1)]), f4 = cconj(p.tw32[(8 * tsi) & (N - 1)]), f8 = cconj(p.tw32[(16 * tsi) & (N - 1)]);
         const TwAf twaf{pk::c32{f1.x, f1.y}, pk::c32{f2.x, f2.y}, pk::c32{f4.x, f4.y}, pk::c32{f8.x, f8.y}};
-        fft_wg16_inv_pk<T>(zi, reinterpret_cast<pk::c32 *>(smem), twaf, TWBF, tqi);
+        W16_MARK(10);
+        fft_wg16_inv_pk<T>(zi, reinterpret_cast<pk::c32 *>(smem), twaf, TWBF, tqi W16_STI);
         // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
         wg16_prio<5, T>();
         {
@@ -987,8 +1027,17 @@ resident_top:
                 acc[r] = (s < LROWS) ? float2{acc[s].x + fr[s].x, acc[s].y + fr[s].y} : fr[s];
             }
         }
+        W16_MARK(16);
         __syncthreads();
+        W16_MARK(17);
     }
+#ifdef PV_WG16_PH
+    if (p.stamps && t == 0) {
+        unsigned *o = p.stamps + 32 * ((long)ch * gridDim.x + chunk);
+        for (int i = 0; i < 20; i++) o[i] = w16clk.acc[i];
+        o[20] = (unsigned)(last_out - first_frame);
+    }
+#endif
 
     if (chunk == (int)gridDim.x - 1) {
 #pragma unroll
