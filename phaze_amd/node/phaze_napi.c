@@ -589,6 +589,29 @@ static napi_value js_info(napi_env env, napi_callback_info info)
     return o;
 }
 
+/* forwardStats(handle[, reset]) -> {frames, fallbacks}   (pv_forward_stats, round 5: frames whose forward transform ran fp32-first, and how many of them re-ran it in
+ * fp64 because a peak decision -- phase-vocoder.js:95-116 -- lay within the fp32 transform's error; what a host looks at before it chooses PV_FLAG_FP64_FORWARD) */
+static napi_value js_forward_stats(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK_OR_THROW(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL), "bad arguments");
+    pv_slot *slot = unwrap(env, argv[0]);
+    if (!slot) return NULL;
+    bool reset = false;
+    if (argc >= 2) napi_get_value_bool(env, argv[1], &reset);
+    uint64_t frames = 0, fallbacks = 0;
+    const int rc = pv_forward_stats(slot->h, &frames, &fallbacks, reset ? 1 : 0);
+    if (rc != PV_OK) return throw_status(env, slot->h, rc);
+    napi_value o, a, b;
+    NAPI_OK_OR_THROW(env, napi_create_object(env, &o), "napi_create_object failed");
+    napi_create_double(env, (double)frames, &a);
+    napi_create_double(env, (double)fallbacks, &b);
+    napi_set_named_property(env, o, "frames", a);
+    napi_set_named_property(env, o, "fallbacks", b);
+    return o;
+}
+
 static napi_value init(napi_env env, napi_value exports)
 {
     const napi_property_descriptor props[] = {
@@ -607,6 +630,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"reset", NULL, js_reset, NULL, NULL, NULL, napi_enumerable, NULL},
         {"timeCursor", NULL, js_time_cursor, NULL, NULL, NULL, napi_enumerable, NULL},
         {"info", NULL, js_info, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"forwardStats", NULL, js_forward_stats, NULL, NULL, NULL, napi_enumerable, NULL},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     return exports;

@@ -43,7 +43,7 @@ def test_addon_loads_and_exports_surface():
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout)
     assert d["native"] == sorted(["create", "destroy", "process", "processBatch", "reset", "timeCursor", "info", "processBegin", "processEnd",
-                                  "processBatchAsync", "exportState", "importState", "deviceCount", "allocPinned", "batchWindow"])
+                                  "processBatchAsync", "exportState", "importState", "deviceCount", "allocPinned", "batchWindow", "forwardStats"])
     assert d["desc"] == [{"name": "pitchFactor", "defaultValue": 1}]          # phase-vocoder.js:17-22
     assert d["registered"] and d["hasProcess"]
 
