@@ -564,9 +564,12 @@ __device__ __forceinline__ void spectrum32_1024(const float2 (&raw)[8], const pk
     for (int r = 0; r < 8; r++) zc[r] = pk::mul_conj(pk::c32{raw[r].x, raw[r].y}, hw[r]);       // conj(z), z pre-halved like the fp64 form's
     fft512_wave_inv_pk<REGT1, ST, true>(zc, reinterpret_cast<pk::c32 *>(smem), TW1F4, TW2F4, l, st);
     pv_prio(PH_SPLITX);
-    pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem);                       // partner rows 4..7, read back reversed (as in the fp64 form: (l = 0, r = 0) reads one past, replaced below)
+    // partner rows 4..7, read back reversed.  (l = 0, r = 0) reads one element past the rows: Z[512] = Z[0] is put there, and the pair k = 0 goes through the same
+    // arithmetic as the others (E' = 2 Re, O' = 2 j Im, W^0 = 1: X[0] = 2 (Re Z0 + Im Z0), X[512] = 2 (Re Z0 - Im Z0), with the roundings of the closed form)
+    pk::c32 *XCH = reinterpret_cast<pk::c32 *>(smem);
 #pragma unroll
     for (int r = 4; r < 8; r++) XCH[(r - 4) * 64 + l] = zc[r];
+    if (l == 0) XCH[256] = zc[0];
     wave_sync();
     pv_prio(PH_SPLITM);
     const pk::c32 isc{isc_, isc_};
@@ -578,11 +581,7 @@ __device__ __forceinline__ void spectrum32_1024(const float2 (&raw)[8], const pk
     for (int r = 0; r < 4; r++) {
         const pk::c32 E = pk::add_conj(zc[r], zm[r]), O = pk::sub_conj(zc[r], zm[r]);
         const pk::c32 T = pk::cmul(mul_w16_inv_pk(O, r), wlfs);             // SC conj(W^{l + 64 r}) O'
-        pk::c32 xa = pk::conj_fma_j(T, isc, E), xb = pk::fnma_j(T, isc, E);
-        if (r == 0 && l == 0) {
-            xa = pk::c32{2.0f * (zc[0].x - zc[0].y), 0.f};                  // X[0] = 2 (Re Z0 + Im Z0), X[512] = 2 (Re Z0 - Im Z0), Z0 = conj(Zc0)
-            xb = pk::c32{2.0f * (zc[0].x + zc[0].y), 0.f};
-        }
+        const pk::c32 xa = pk::conj_fma_j(T, isc, E), xb = pk::fnma_j(T, isc, E);
         emit(r, xa, xb);
     }
     if (l == 0) emit256(pk::c32{2.0f * zc[4].x, 2.0f * zc[4].y});           // X[256] = 2 conj(Z[256]) = 2 Zc[256]
@@ -882,17 +881,14 @@ resident_top:
 #else
             NoStamp st32;
 #endif
-            unsigned mmax = 0u;                                             // bit pattern of the largest |X|^2 this lane has seen (|X|^2 >= 0: the order of the bit patterns; NaN / Inf on top)
             spectrum32_1024<PV_F32_REGT1>(raw, hw, smem, l, wlfs, 1.0f / SC,
                                           [&](int r, pk::c32 xa, pk::c32 xb) {
-                                              const float ma = mag32(xa), mb = mag32(xb);
-                                              MAG[4 + l + 64 * r] = ma;
-                                              MAG[4 + 512 - l - 64 * r] = mb;
-                                              mmax = max(max(mmax, __float_as_uint(ma)), __float_as_uint(mb));
+                                              MAG[4 + l + 64 * r] = mag32(xa);
+                                              MAG[4 + 512 - l - 64 * r] = mag32(xb);
                                               XA[r] = float2{xa.x, xa.y};
                                               XB[r] = float2{xb.x, xb.y};
                                           },
-                                          [&](pk::c32 x256) { const float m = mag32(x256); MAG[4 + 256] = m; mmax = max(mmax, __float_as_uint(m)); x256f = float2{x256.x, x256.y}; }, st32);
+                                          [&](pk::c32 x256) { MAG[4 + 256] = mag32(x256); x256f = float2{x256.x, x256.y}; }, st32);
             if constexpr (!SPREAD) {
                 unsigned ystr, ystr_m;
                 { int lq = l; asm volatile("" : "+v"(lq)); ystr = yslot_bytes((unsigned)lq); ystr_m = yslot_bytes((unsigned)(512 - 192 - lq)); }
@@ -903,8 +899,7 @@ resident_top:
                 }
                 if (l == 0) *reinterpret_cast<float2 *>(XSb + 256) = x256f;
             }
-            // the frame's largest magnitude sets the absolute part of the guard band
-            return guard_k_of(wave_max_u32(mmax));
+            return 0.f;                                                     // (the band's K comes from the magnitudes once they are read back in natural order: see the flags)
         };
         auto shift_table = [&]() {
             // ---- Math.round(peak * f) - peak (pv:125,147) for every possible peak bin, cached while f does not change.  BEFORE the prefetch is issued: the
@@ -933,7 +928,7 @@ resident_top:
 #ifndef PV_FLIP_COUNT
             wide_first = pred >= PRED_WIDE;
 #endif
-            if (wide_first) forward64(); else guardK = forward32();
+            if (wide_first) forward64(); else (void)forward32();
         }
         wave_sync();
         PV_STAMP(4);
@@ -1063,6 +1058,9 @@ resident_top:
                 take_flags();
                 bool fall = true;
                 if (!wide_first) {
+                    // the frame's largest magnitude (|X|^2 >= 0: the order of the bit patterns; NaN / Inf come out on top) sets the absolute part of the band: the
+                    // lane's own eight bins (and bin 512 behind lane 63's) are in registers here -- four maxima the non-finite test shares
+                    guardK = guard_k_of(wave_max_u32(max(max(max(pm[3], pm[5]), max(pm[7], pm[9])), mg[2])));
                     fall = __any(in_band(guardK, GUARD_R));
 #ifdef PV_FLIP_COUNT
                     flip_first(guardK);
