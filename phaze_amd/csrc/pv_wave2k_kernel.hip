@@ -460,6 +460,7 @@ __global__ __launch_bounds__(RESIDENT ? 128 : 64 * WAVES2, RESIDENT ? 1 : 2) PV_
     int t0_mod_n = p.t0_mod_n;
     unsigned done_seq = p.done_seq;
     unsigned last_seq = p.done_seq;                                      // resident: the last quantum completed before this launch
+    [[maybe_unused]] unsigned pred = 0;                                  // F32: the order counter of this chain (pv_guard.h); a resident wave's quanta are ONE chain of a stream
 resident_top:
     if (RESIDENT) {
         // the control word of pv_wave_kernel_1024's resident form: sequence number (16 bits, never 0) | channel count (7) | ping-pong half (1) | timeCursor / hop mod R (8)
@@ -584,7 +585,7 @@ resident_top:
     W2K_STAMP(3);
 #endif
 
-    [[maybe_unused]] unsigned n_fallback = 0, pred = 0;                  // F32: class-B frames of this chain; the order counter (pv_guard.h)
+    [[maybe_unused]] unsigned n_fallback = 0;                            // F32: class-B frames of this chain
 #ifdef PV_FLIP_COUNT
     unsigned n_flip = 0, n_uncaught = 0, n_sure = 0, n_incons = 0;
 #endif

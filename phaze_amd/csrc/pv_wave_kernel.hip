@@ -706,6 +706,8 @@ __global__ __launch_bounds__(64 * (RESIDENT ? RES_WAVES : WAVES), RESIDENT ? 1 :
     int t0_mod_n = p.t0_mod_n;
     unsigned done_seq = p.done_seq;
     unsigned last_seq = p.done_seq;                                      // resident: the last quantum completed before this launch
+    [[maybe_unused]] unsigned pred = 0;                                  // F32: 0 .. PRED_MAX, >= PRED_WIDE: this chain runs the fp64 transform first (pv_guard.h).  Declared in front
+                                                                         // of the resident form's loop: a resident wave's quanta are ONE chain of a stream
 resident_top:
     if (RESIDENT) {
         // ctl[0] carries the whole quantum in ONE word -- sequence number (low 16 bits, never 0), channel count (7 bits), ping-pong half (1 bit),
@@ -816,7 +818,6 @@ resident_top:
     const unsigned stamp_t0 = stamps.prev;
 #endif
     [[maybe_unused]] unsigned n_fallback = 0;                            // F32: frames of this chain of class B (forward transform in fp64)
-    [[maybe_unused]] unsigned pred = 0;                                  // F32: 0 .. PRED_MAX, >= PRED_WIDE: this chain runs the fp64 transform first (see GUARD_GN)
 #ifdef PV_FLIP_COUNT
     unsigned n_flip = 0, n_uncaught = 0, n_sure = 0, n_incons = 0;
 #endif
