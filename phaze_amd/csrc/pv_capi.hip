@@ -294,6 +294,7 @@ int resident_start(pv_handle *h, unsigned last_seq)
     p.done = h->d_done; p.done_seq = last_seq;
     p.ctl = h->d_ctl;
     p.idle_ticks = h->idle_ticks;
+    p.fwd64 = h->fwd64 ? 1 : 0; p.fwd_stats = h->d_fwd_stats;
     p.in_cached = h->resident_in_bar ? 1 : 0;
     resident_publish(h, h->h_ctl + 4, 0u);
     // stale completion words must not match a future 16-bit sequence number (a slot unused for exactly 65535 quanta)

@@ -117,3 +117,34 @@ def test_guarded_range_of_amplitudes(fft, hop, scale):
     yo = oracle_lib.Oracle(fft, hop, 1).process_planar(x, p)
     assert np.all(np.isfinite(y))
     assert S.rms(y.astype(np.float64) - yo) < 2e-7 * max(S.rms(yo), 1e-30) / 0.1
+
+
+@pytest.mark.parametrize("fft,hop", [(1024, 256), (2048, 512)])
+@pytest.mark.parametrize("kind", ["tonal80", "switching"])
+def test_resident_waves_carry_the_order_counter_without_showing_it(fft, hop, kind):
+    """On the resident kernel (PV_FLAG_PERSISTENT_STREAM) a wave's quanta are ONE chain: its order counter lives across them, so a clean tonal stream runs the fp64
+    transform first after a few quanta.  The bits are those of the batch call."""
+    import phaze_amd
+    T, nch = 80, 2
+    x = np.stack([_signal(kind, T * hop, 7 + c) for c in range(nch)])
+    pitch = np.full(T, 1.5, np.float32)
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T)
+    ref = pv.process_batch(x, pitch)
+    pv.close()
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, flags=phaze_amd.FLAG_PERSISTENT_STREAM)
+    out = np.zeros_like(ref)
+    for m in range(T):
+        o = [np.zeros(hop, np.float32) for _ in range(nch)]
+        pv.process([[x[c, m * hop:(m + 1) * hop] for c in range(nch)]], [o], {"pitchFactor": pitch[m:m + 1]})
+        for c in range(nch):
+            out[c, m * hop:(m + 1) * hop] = o[c]
+    frames, fallbacks = pv.forward_stats()
+    pv.close()
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (fft, hop, kind)
+    assert frames == T * nch and (kind != "tonal80" or fallbacks >= 0.9 * frames), (frames, fallbacks)
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=1, flags=phaze_amd.FLAG_PERSISTENT_STREAM | phaze_amd.FLAG_FP64_FORWARD)
+    for m in range(4):                                              # the flag reaches the resident instance too: no fp32-first frame is counted
+        o = [np.zeros(hop, np.float32) for _ in range(nch)]
+        pv.process([[x[c, m * hop:(m + 1) * hop] for c in range(nch)]], [o], {"pitchFactor": pitch[m:m + 1]})
+    assert pv.forward_stats() == (0, 0)
+    pv.close()
