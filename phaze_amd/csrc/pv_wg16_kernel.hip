@@ -585,6 +585,8 @@ resident_top:
     W16Clock w16clk;
     w16clk.start();
 #endif
+    TwA twa_next;
+    { const int ts0 = (t >> 4) + K2 * (t & 15); twa_next = TwA{p.tw64[(2 * ts0) & (N - 1)], p.tw64[(4 * ts0) & (N - 1)], p.tw64[(8 * ts0) & (N - 1)], p.tw64[(16 * ts0) & (N - 1)]}; }
 
     for (int m = first_frame; m < last_out; ++m) {
         int tq = t;
@@ -600,7 +602,11 @@ resident_top:
         // addresses derived from the opaque thread id, instead of occupying registers across the phases that need every one of them: the pass-A twiddles here,
         // the Hann values and the inverse's twiddles in front of the inverse FFT.
         const int tsq = (tq >> 4) + K2 * (tq & 15);
-        const TwA twa{p.tw64[(2 * tsq) & (N - 1)], p.tw64[(4 * tsq) & (N - 1)], p.tw64[(8 * tsq) & (N - 1)], p.tw64[(16 * tsq) & (N - 1)]};   // W_4096^{ts k}, k = 1, 2, 4, 8
+        // W_M^{ts k}, k = 1, 2, 4, 8: loaded behind the previous frame's inverse FFT (round 5: at the top of the frame the first use, ~150 instructions on, came before the
+        // loads did) -- where the registers allow it: at hop = N / 2 sixteen more live values across the loop edge spill (22-28 VGPRs), there the loads stay here
+        constexpr bool TWA_AHEAD = (S_ROWS != 8);
+        if constexpr (!TWA_AHEAD) twa_next = TwA{p.tw64[(2 * tsq) & (N - 1)], p.tw64[(4 * tsq) & (N - 1)], p.tw64[(8 * tsq) & (N - 1)], p.tw64[(16 * tsq) & (N - 1)]};
+        const TwA twa = twa_next;
         const double2 wl = p.tw64[tq];                                      // split pass: W_N^{tq + 256 r} = wl * W_32^r
         // ---- Hann (pv:55), pack, forward FFT in fp64 (the split pass's 1/2 is folded into the window, exact) ----
         wg16_prio<0, T>();
@@ -662,6 +668,10 @@ resident_top:
                 if (tq == 0) Y[M / 2] = xHf;
             }
         }
+        // conj(W^{2k}) of this thread's first bin k = 1 + tq of the fast residue (f < 1; k = 1 + tq + 256 j: times conj(W_16^j)): a load from the global table, issued HERE,
+        // two barriers ahead of its use -- behind the "magnitudes complete" barrier it was an exposed round trip in every f < 1 frame (profiles/r05_wg16_phase_clock.md)
+        float2 s2w0{1.f, 0.f};
+        if (pf < 1.0) s2w0 = cconj(p.tw32[2 * (1 + tq)]);
         // slide the raw window; the rows the next frame adds are issued here
         {
             const int mn = (m + 1 < last_out) ? m + 1 : m;
@@ -696,7 +706,6 @@ resident_top:
         // ---- above-Nyquist residue, fast form: W^{2k} S2[k] = (X[k] - X[k+N/4] + X[k+N/2] - X[k+3N/4]) / 4, k = 1 + tq + 256 j (see pv_wg_kernel.hip) ----
         float2 s2v[4] = {float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}};
         if (pf < 1.0) {
-            const float2 s2w0 = cconj(p.tw32[2 * (1 + tq)]);               // conj(W^{2k}) of this thread's first bin k = 1 + tq; k = 1 + tq + 256 j: times conj(W_16^j)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int k = 1 + tq + T * j;                                // k in [1, N/8]
@@ -1004,6 +1013,7 @@ resident_top:
         const TwAf twaf{pk::c32{f1.x, f1.y}, pk::c32{f2.x, f2.y}, pk::c32{f4.x, f4.y}, pk::c32{f8.x, f8.y}};
         W16_MARK(10);
         fft_wg16_inv_pk<T>(zi, reinterpret_cast<pk::c32 *>(smem), twaf, TWBF, tqi W16_STI);
+        if constexpr (S_ROWS != 8) twa_next = TwA{p.tw64[(2 * tsi) & (N - 1)], p.tw64[(4 * tsi) & (N - 1)], p.tw64[(8 * tsi) & (N - 1)], p.tw64[(16 * tsi) & (N - 1)]};   // the next frame's pass-A twiddles
         // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
         wg16_prio<5, T>();
         {
