@@ -36,6 +36,15 @@ template <typename T2> __device__ __forceinline__ T2 cconj(T2 a) { return T2{a.x
 // multiply by -j (forward) / +j (inverse)
 template <bool INV, typename T2> __device__ __forceinline__ T2 cmul_mj(T2 a) { return INV ? T2{-a.y, a.x} : T2{a.y, -a.x}; }
 
+// a * b rounded to fp32 as an operation of its own: a plain product (also `__fmul_rn`) is contracted into a following add -- one rounding less than the reference's
+// Float32Array elements (pv:55,67); see pv_device_common.h
+__device__ __forceinline__ float mul_rounded(float a, float b)
+{
+    float d;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 __device__ __forceinline__ int bitrev(int v, int bits) { return bits == 0 ? 0 : (int)(__brev((unsigned)v) >> (32 - bits)); }
 // base-4 digit reversal over nd digits
 __device__ __forceinline__ int digitrev4(int v, int nd)
@@ -109,10 +118,10 @@ __device__ __forceinline__ void residue_upper_half(float2 *B, const FrameSrc &sr
         constexpr int nd = (LOG2N - 2) / 2;
         for (int t = N / 8 + tid; t < N / 4; t += THREADS) {          // bundle:468-508
             const int off = digitrev4(t, nd);
-            const float a = src.at(s0 + off) * hann[off];
-            const float b = src.at(s0 + off + N / 4) * hann[off + N / 4];
-            const float c = src.at(s0 + off + N / 2) * hann[off + N / 2];
-            const float d = src.at(s0 + off + 3 * N / 4) * hann[off + 3 * N / 4];
+            const float a = mul_rounded(src.at(s0 + off), hann[off]);
+            const float b = mul_rounded(src.at(s0 + off + N / 4), hann[off + N / 4]);
+            const float c = mul_rounded(src.at(s0 + off + N / 2), hann[off + N / 2]);
+            const float d = mul_rounded(src.at(s0 + off + 3 * N / 4), hann[off + 3 * N / 4]);
             const float t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
             B[4 * t] = float2{t0 + t2, 0.f};
             B[4 * t + 1] = float2{t1, -t3};
@@ -123,8 +132,8 @@ __device__ __forceinline__ void residue_upper_half(float2 *B, const FrameSrc &sr
         constexpr int nd = (LOG2N - 1) / 2;
         for (int t = N / 4 + tid; t < N / 2; t += THREADS) {          // bundle:447-463
             const int off = digitrev4(t, nd);
-            const float a = src.at(s0 + off) * hann[off];
-            const float b = src.at(s0 + off + N / 2) * hann[off + N / 2];
+            const float a = mul_rounded(src.at(s0 + off), hann[off]);
+            const float b = mul_rounded(src.at(s0 + off + N / 2), hann[off + N / 2]);
             B[2 * t] = float2{a + b, 0.f};
             B[2 * t + 1] = float2{a - b, 0.f};
         }
@@ -411,17 +420,17 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
         // ---- 12. Hann (pv:67), overlap-add in reference order (ola:149-157), emit hop (ola:111-118), shift (ola:130-137) ----
         const bool emit = (m >= first_out);
         for (int j = tid; j < hop; j += THREADS) {
-            const float fr = __fmul_rn(frame[j], p.hann[j]);               // rounded to fp32 before the accumulation (Float32Array, pv:67)
+            const float fr = mul_rounded(frame[j], p.hann[j]);               // rounded to fp32 before the accumulation (Float32Array, pv:67)
             float a = 0.f;
             int slot = 0;
             if (L > 0) { slot = ring + j; if (slot >= L) slot -= L; a = acc[slot]; }
             const float o = a + fr * invR;
             if (emit) outp[(long)m * hop + j] = o;
-            if (L > 0) acc[slot] = __fmul_rn(frame[j + L], p.hann[j + L]) * invR;   // freed slot receives the new tail (0 + x)
+            if (L > 0) acc[slot] = mul_rounded(frame[j + L], p.hann[j + L]) * invR;   // freed slot receives the new tail (0 + x)
         }
         for (int j = hop + tid; j < L; j += THREADS) {
             int slot = ring + j; if (slot >= L) slot -= L;
-            acc[slot] = acc[slot] + __fmul_rn(frame[j], p.hann[j]) * invR;
+            acc[slot] = acc[slot] + mul_rounded(frame[j], p.hann[j]) * invR;
         }
         if (L > 0) { ring += hop; if (ring >= L) ring -= L; }
         __syncthreads();

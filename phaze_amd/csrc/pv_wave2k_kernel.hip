@@ -198,7 +198,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_2k(cons
         for (int i = 0; i < 4; i++) {                                      // QN / 2 = 256 radix-2 blocks per quarter; input index = base-4 digit reversal of the block
             const int lb = l + 64 * i, blk = base / 2 + lb;
             const int off = digitrev4_2k(blk, (LOG2N - 1) / 2);
-            const float a = src.at(s0 + off) * hann[off], b = src.at(s0 + off + N / 2) * hann[off + N / 2];
+            const float a = mul_rounded(src.at(s0 + off), hann[off]), b = mul_rounded(src.at(s0 + off + N / 2), hann[off + N / 2]);
             Q[2 * lb] = float2{a + b, 0.f};
             Q[2 * lb + 1] = float2{a - b, 0.f};
         }
@@ -1086,7 +1086,7 @@ resident_top:
             v4f fr[8];
 #pragma unroll
             for (int r = 0; r < 8; r++)                                    // rounded to fp32 BEFORE the accumulation like the reference's Float32Array (pv:67): no contraction into the adds
-                fr[r] = v4f{__fmul_rn(zA[r].x, hw[r].x), __fmul_rn(zA[r].y, hw[r].y), __fmul_rn(zB[r].x, hw[r].z), __fmul_rn(zB[r].y, hw[r].w)};
+                fr[r] = v4f{mul_rounded(zA[r].x, hw[r].x), mul_rounded(zA[r].y, hw[r].y), mul_rounded(zB[r].x, hw[r].z), mul_rounded(zB[r].y, hw[r].w)};
             if (HALF) {
                 // lane L holds samples 256 r + 4 (L ^ 32 par) ..: the half of the lanes with li < 32 holds the earlier half row
                 const bool early = li < 32;

@@ -29,8 +29,18 @@
 #ifndef PV_PAIRWISE
 #define PV_PAIRWISE 1
 #endif
+// Reference-width flavour (never the product; `make fp64` -> build/exp/libphaze_fp64.so, DESIGN.md section 4, pv_wave_kernel.hip has the N = 1024 one): with
+// -DPV_FP64_FLAVOUR=1 the shifted spectrum, the scatter (plain stores for f >= 1, claim rounds for f < 1), the above-Nyquist residue (always the re-run stage
+// structure), the c2r pass and the inverse FFT run in fp64 like the reference (freqComplexBufferShifted / inverseTransform are JS doubles, bundle:102-114;
+// phase-vocoder.js:37-39,161-170).  Y, the hand-over and the quarter buffer are twice as wide (135 KB / 68 KB of LDS): ONE workgroup per CU (two at N = 4096), 512 VGPRs.
+// It prices the product's fp32 shift / inverse at N = 4096 / 8192 (tests/test_gpu_fp64_flavour.py, one line of bench.py).
+#ifndef PV_FP64_FLAVOUR
+#define PV_FP64_FLAVOUR 0
+#endif
 
 namespace {
+
+constexpr bool FP64W = PV_FP64_FLAVOUR != 0;
 
 // wave priority per phase (pv_wave_fft.h has the story): the SIMD's two waves belong to DIFFERENT workgroups; the latency chains between the transforms (short LDS
 // round trips behind barriers) run above the arithmetic of the transforms, whose exchanges are lowest.  One table per size, phases in this order: forward arithmetic, forward
@@ -79,16 +89,17 @@ struct QC {
     // inside the scratch, between the two FFTs:
     static constexpr int OFF_Y = 0;                       // float2[H]                 | fp32 spectrum stash (f < 1) before Y is zeroed
     static constexpr int MAG0 = 8;                        // magnitudes / routes start 8 words in (bins -2, -1 of thread 0's window stay inside)
-    static constexpr int OFF_ROUTE = ((8 * H + 15) / 16) * 16;   // u32 routes | f32 mags, both padded (pv_wave2k_kernel.hip) | u32 claim words [H] (plain)
+    static constexpr int YB = FP64W ? 16 : 8;             // bytes per bin of Y / per element of the quarter and hand-over buffers
+    static constexpr int OFF_ROUTE = ((YB * H + 15) / 16) * 16;   // u32 routes | f32 mags, both padded (pv_wave2k_kernel.hip) | u32 claim words [H] (plain)
     static constexpr int ROUTE_WORDS = MAG0 + PM + 8;
     static constexpr int OFF_RESQ = ((OFF_ROUTE + 4 * H + 15) / 16) * 16;   // float2[N / 4] one residue quarter | c2r hand-over
-    static constexpr int SCRATCH = OFF_RESQ + 2 * N;      // 65568 / 32800
+    static constexpr int SCRATCH = OFF_RESQ + (YB / 4) * N;   // 65568 / 32800
     static_assert(OFF_ROUTE + 4 * ROUTE_WORDS <= SCRATCH && 16 * M <= SCRATCH, "routes / the fp64 exchange");
     static_assert(OFF_ROUTE >= 16 * 8 * T, "MAG must not alias the partner rows of the split pass");
     // i32 LASTIN[T], FIRSTIN[T].  N = 4096: inside the quarter buffer, behind the tail of the padded magnitudes (free between the end of the previous frame's inverse and
     // this frame's scatter / c2r hand-over) -- behind the scratch they are the 1 KB that costs the fourth workgroup of the CU; N = 8192 keeps them behind the scratch
     // (measured: the pitch sweep 2 % faster that way)
-    static constexpr bool NEAR_IN = (LOG2N_ == 12);
+    static constexpr bool NEAR_IN = (LOG2N_ == 12) && !FP64W;
     static constexpr int OFF_NEAR = NEAR_IN ? OFF_RESQ + N : SCRATCH;
     static_assert(!NEAR_IN || (OFF_NEAR >= OFF_ROUTE + 4 * ROUTE_WORDS && OFF_NEAR + 8 * T <= SCRATCH), "LASTIN / FIRSTIN");
     // after the scratch:
@@ -97,7 +108,7 @@ struct QC {
     static constexpr int OFF_TWBF = OFF_TWB + 16 * 15 * K2;   // float2[15][K2] conj, fp32
     static constexpr int OFF_XQ = OFF_TWBF + 8 * 15 * K2;   // f32[N / 4] windowed samples xw[4n + 2] of the frame (f < 0.75): base stage of the general residue
     static constexpr int LDS_BYTES = OFF_XQ + N;          // 81632 (two workgroups per CU) / 39840 (four)
-    static_assert((LDS_BYTES + 256 + 511) / 512 * 512 * (512 / T) <= 160 * 1024, "workgroups per CU (256 static bytes: __syncthreads_or)");
+    static_assert((LDS_BYTES + 256 + 511) / 512 * 512 * (FP64W ? 256 / T : 512 / T) <= 160 * 1024, "workgroups per CU (256 static bytes: __syncthreads_or)");
 };
 
 // ---- radix-16 butterflies, natural order in and out: X[q + 4 p] = sum_j W4^{j p} ( W16^{j q} sum_m a[j + 4 m] W4^{m q} ) ----
@@ -308,6 +319,71 @@ __device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, co
     st(4);
 }
 
+// ---- fp64 flavour: the inverse in doubles.  The radix-16 inverse DFT is the forward one between two conjugations (sign flips); the passes are fft_wg16_inv_pk's, the
+//      twiddles the forward tables' conjugates, and the in-wave exchange reuses the scratch of the cross-wave exchange behind a barrier (the flavour does not race) ----
+__device__ __forceinline__ void radix16_inv_d(double2 (&a)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) a[i].y = -a[i].y;
+    radix16_fwd(a);
+#pragma unroll
+    for (int i = 0; i < 16; i++) a[i].y = -a[i].y;
+}
+template <int T_>
+__device__ __forceinline__ void fft_wg16_inv_d(double2 (&a)[16], double2 *S, const TwA &tw, const double2 *TWB, int t)
+{
+    const int c = t & 15, g = t >> 4;
+    constexpr int K2 = T_ / 16;
+    if (K2 == 16) {
+        radix16_inv_d(a);
+    } else {
+        double2 lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { lo[k] = a[2 * k]; hi[k] = a[2 * k + 1]; }
+        radix8<double, true>(lo);
+        radix8<double, true>(hi);
+#pragma unroll
+        for (int n = 0; n < 8; n++) { a[n] = lo[n]; a[8 + n] = hi[n]; }
+    }
+#pragma unroll
+    for (int h = 0; h < 16 / K2; h++)
+#pragma unroll
+        for (int n = 0; n < K2; n++) S[T_ * (g + K2 * h) + 16 * n + c] = a[K2 * h + n];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = S[T_ * k + t];
+#pragma unroll
+    for (int k = 1; k < 16; k++) a[k] = dmulc(a[k], TWB[(k - 1) * K2 + g]);
+    radix16_inv_d(a);
+    __syncthreads();                                                    // every row of the cross-wave exchange has been read
+    double2 *Sg = S + 256 * g;
+#pragma unroll
+    for (int n = 0; n < 16; n++) Sg[16 * c + (n ^ c)] = a[n];
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = Sg[16 * k + (c ^ k)];
+    {
+        const double2 w3 = dmul(tw.w1, tw.w2), w5 = dmul(tw.w4, tw.w1), w6 = dmul(tw.w4, tw.w2), w7 = dmul(tw.w4, w3);
+        a[1] = dmulc(a[1], tw.w1); a[2] = dmulc(a[2], tw.w2); a[3] = dmulc(a[3], w3); a[4] = dmulc(a[4], tw.w4);
+        a[5] = dmulc(a[5], w5); a[6] = dmulc(a[6], w6); a[7] = dmulc(a[7], w7); a[8] = dmulc(a[8], tw.w8);
+        a[9] = dmulc(a[9], dmul(tw.w8, tw.w1)); a[10] = dmulc(a[10], dmul(tw.w8, tw.w2)); a[11] = dmulc(a[11], dmul(tw.w8, w3));
+        a[12] = dmulc(a[12], dmul(tw.w8, tw.w4)); a[13] = dmulc(a[13], dmul(tw.w8, w5)); a[14] = dmulc(a[14], dmul(tw.w8, w6)); a[15] = dmulc(a[15], dmul(tw.w8, w7));
+    }
+    radix16_inv_d(a);
+}
+
+// v * exp(+2 pi j ridx / N) in doubles (rotate_route's fp64 twin)
+template <int R_, int LOG2N_>
+__device__ __forceinline__ double2 rotate_route_d(unsigned route, double2 v, const double2 *__restrict__ tw64)
+{
+    const unsigned ridx = (route >> 16) & ((1u << LOG2N_) - 1u);
+    if (R_ == 4) { const unsigned q = ridx >> (LOG2N_ - 2); return q == 0 ? v : q == 1 ? double2{-v.y, v.x} : q == 2 ? double2{-v.x, -v.y} : double2{v.y, -v.x}; }   // j^q exactly
+    const double2 w = tw64[ridx];
+    return double2{__fma_rn(v.x, w.x, __dmul_rn(v.y, w.y)), __fma_rn(v.y, w.x, -__dmul_rn(v.x, w.y))};
+}
+template <int R_, int LOG2N_> __device__ __forceinline__ float2 rotate_any(unsigned route, float2 v, const float2 *tw32, const double2 *) { return rotate_route<R_, LOG2N_>(route, v, tw32); }
+template <int R_, int LOG2N_> __device__ __forceinline__ double2 rotate_any(unsigned route, double2 v, const float2 *, const double2 *tw64) { return rotate_route_d<R_, LOG2N_>(route, v, tw64); }
+
 // o * W_32^r (fp64, split pass) and o * exp(+2 pi j r / 32) (packed fp32, c2r pass), r = 0..7 compile-time: the row part of W_8192^{t + 256 r}
 __device__ __forceinline__ double2 mul_w32_16(double2 o, int r)
 {
@@ -325,8 +401,8 @@ __device__ __forceinline__ pk::c32 mul_w32_inv_pk16(pk::c32 o, int r)
 }
 
 // Workgroup-wide claim rounds (pv_wg_kernel.hip): atomic MIN on the claim word, the smallest pending source bin wins the round.  CLAIM[0..H) all-ones on entry and exit.
-template <int NS, int H_>
-__device__ __forceinline__ void claim_rounds_wg16(const unsigned (&rt)[NS], const float2 (&ys)[NS], const int (&id)[NS], float2 *Y, unsigned *CLAIM)
+template <int NS, int H_, typename V2>
+__device__ __forceinline__ void claim_rounds_wg16(const unsigned (&rt)[NS], const V2 (&ys)[NS], const int (&id)[NS], V2 *Y, unsigned *CLAIM)
 {
     unsigned pend = 0;
     unsigned tg[NS];
@@ -342,7 +418,7 @@ __device__ __forceinline__ void claim_rounds_wg16(const unsigned (&rt)[NS], cons
         for (int r = 0; r < NS; r++) if (pend & (1u << r)) atomicMin(&CLAIM[tg[r]], (unsigned)id[r]);
         __syncthreads();
         unsigned c[NS];
-        float2 o[NS];
+        V2 o[NS];
 #pragma unroll
         for (int r = 0; r < NS; r++) c[r] = CLAIM[tg[r]];
 #pragma unroll
@@ -350,7 +426,7 @@ __device__ __forceinline__ void claim_rounds_wg16(const unsigned (&rt)[NS], cons
 #pragma unroll
         for (int r = 0; r < NS; r++) {
             if ((pend & (1u << r)) && c[r] == (unsigned)id[r]) {
-                Y[tg[r]] = float2{o[r].x + ys[r].x, o[r].y + ys[r].y};
+                Y[tg[r]] = V2{o[r].x + ys[r].x, o[r].y + ys[r].y};
                 CLAIM[tg[r]] = 0xFFFFFFFFu;
                 pend &= ~(1u << r);
             }
@@ -392,8 +468,8 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(co
                     a = XQ[(off - 2) >> 2]; b = XQ[((off - 2) >> 2) + N / 16]; c = XQ[((off - 2) >> 2) + N / 8]; d = XQ[((off - 2) >> 2) + 3 * N / 16];
                 } else {
                     const int off = digitrev4_16(base / 4 + lb, nd);
-                    a = src.at(s0 + off) * hann[off]; b = src.at(s0 + off + N / 4) * hann[off + N / 4];
-                    c = src.at(s0 + off + N / 2) * hann[off + N / 2]; d = src.at(s0 + off + 3 * N / 4) * hann[off + 3 * N / 4];
+                    a = mul_rounded(src.at(s0 + off), hann[off]); b = mul_rounded(src.at(s0 + off + N / 4), hann[off + N / 4]);
+                    c = mul_rounded(src.at(s0 + off + N / 2), hann[off + N / 2]); d = mul_rounded(src.at(s0 + off + 3 * N / 4), hann[off + 3 * N / 4]);
                 }
                 const float t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
                 Q[4 * lb] = float2{t0 + t2, 0.f};
@@ -409,7 +485,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(co
                 const int off = digitrev4_16((base == N / 2 ? N / 4 : base / 2) + lb, nd);
                 float a, b;
                 if (base == N / 2) { a = XQ[(off - 2) >> 2]; b = XQ[((off - 2) >> 2) + N / 8]; }     // quarter 2: sub-FFT of xw[4n + 2], from the frame's stash
-                else { a = src.at(s0 + off) * hann[off]; b = src.at(s0 + off + N / 2) * hann[off + N / 2]; }
+                else { a = mul_rounded(src.at(s0 + off), hann[off]); b = mul_rounded(src.at(s0 + off + N / 2), hann[off + N / 2]); }
                 Q[2 * lb] = float2{a + b, 0.f};
                 Q[2 * lb + 1] = float2{a - b, 0.f};
             }
@@ -464,10 +540,93 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(co
     }
 }
 
+// fp64 flavour: the same stage structure in doubles -- every quarter from the source samples (the window product rounded to fp32 as the reference's Float32Array does,
+// pv:55), the three stage twiddles table entries like fft.js's (bundle:329-441), the sources added by claim rounds.
+template <int LOG2N, int R_>
+__device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16_d(const float *in, const float *hist, int hist_len, bool sys, long s0, const float *__restrict__ hann,
+                                                                                 const double2 *__restrict__ tw64, int t, int upper_end, int up_delta, unsigned up_ridx, double *dbg_X)
+{
+    using C = QC<LOG2N>;
+    constexpr int N = C::N, H = C::H, T = C::T, QN = N / 4;
+    constexpr bool BASE4 = (LOG2N % 2) == 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2 *Y = reinterpret_cast<double2 *>(smem + C::OFF_Y);
+    unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);
+    double2 *Q = reinterpret_cast<double2 *>(smem + C::OFF_RESQ);
+    const WaveSrc src{in, hist, hist_len, sys};
+    auto xw = [&](int off) -> double { return (double)mul_rounded(src.at(s0 + off), hann[off]); };
+    for (int base = N / 2; base < N && base < upper_end; base += QN) {
+        if (BASE4) {
+            constexpr int nd = (LOG2N - 2) / 2;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int lb = t + T * i;
+                const int off = digitrev4_16(base / 4 + lb, nd);
+                const double a = xw(off), b = xw(off + N / 4), c = xw(off + N / 2), d = xw(off + 3 * N / 4);
+                const double t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+                Q[4 * lb] = double2{t0 + t2, 0.0};
+                Q[4 * lb + 1] = double2{t1, -t3};
+                Q[4 * lb + 2] = double2{t0 - t2, 0.0};
+                Q[4 * lb + 3] = double2{t1, t3};
+            }
+        } else {
+            constexpr int nd = (LOG2N - 1) / 2;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int lb = t + T * i;
+                const int off = digitrev4_16(base / 2 + lb, nd);
+                const double a = xw(off), b = xw(off + N / 2);
+                Q[2 * lb] = double2{a + b, 0.0};
+                Q[2 * lb + 1] = double2{a - b, 0.0};
+            }
+        }
+        __syncthreads();
+        constexpr int LOG2BASE = BASE4 ? 2 : 1;
+        for (int log2m = LOG2BASE + 2; log2m <= LOG2N - 2; log2m += 2) {
+            const int q = (1 << log2m) >> 2, hq = q >> 1;
+            const int nblocks = QN >> log2m;
+            const int tws = LOG2N - log2m;
+            for (int u = t; u < nblocks * (hq + 1); u += T) {
+                int blk, i;
+                if (u < nblocks * hq) { blk = u / hq; i = u - blk * hq; } else { blk = u - nblocks * hq; i = hq; }
+                const int o = blk << log2m;
+                const double2 A = Q[o + i];
+                const double2 Bv = cmul(Q[o + q + i], tw64[i << tws]);
+                const double2 Cc = cmul(Q[o + 2 * q + i], tw64[2 * (i << tws)]);
+                const double2 D = cmul(Q[o + 3 * q + i], tw64[3 * (i << tws)]);
+                const double2 T0 = cadd(A, Cc), T1 = csub(A, Cc), T2 = cadd(Bv, D), T3 = csub(Bv, D);
+                Q[o + i] = cadd(T0, T2);
+                Q[o + q + i] = double2{T1.x + T3.y, T1.y - T3.x};
+                if (i == 0) {
+                    Q[o + 2 * q] = csub(T0, T2);
+                } else if (i != hq) {
+                    Q[o + q - i] = double2{T1.x - T3.y, -(T1.y + T3.x)};
+                    Q[o + 2 * q - i] = double2{T0.x - T2.x, -(T0.y - T2.y)};
+                }
+            }
+            __syncthreads();
+        }
+        if (dbg_X)
+            for (int i = t; i < QN; i += T) if (base + i >= H) { dbg_X[2 * (base + i)] = Q[i].x; dbg_X[2 * (base + i) + 1] = Q[i].y; }
+        unsigned rt[8];
+        double2 ys[8];
+        int id[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int b = base + t + T * j, tgt = b + up_delta;
+            rt[j] = (b >= H && b < upper_end && tgt >= 0 && tgt < H) ? ((up_ridx << 16) | (unsigned)tgt) : NOROUTE;
+            ys[j] = rotate_route_d<R_, LOG2N>(rt[j], Q[t + T * j], tw64);
+            id[j] = b - N / 2;
+        }
+        claim_rounds_wg16<8, H>(rt, ys, id, Y, CLAIM);
+        __syncthreads();
+    }
+}
+
 // S_ROWS = hop / (N / 16) in {2, 4, 8, 16}: the frame advances by whole register rows (N / 16 samples), overlap-add accumulator and input window live in registers.
 // AUX: test-tap instance.  RESIDENT: streaming instance that stays on the GPU (see pv_wg_kernel.hip).
 template <int LOG2N, int S_ROWS, bool AUX, bool RESIDENT = false>
-__global__ __launch_bounds__(QC<LOG2N>::T, RESIDENT ? 1 : 2) PV_NO_DS_MERGE void pv_wg16_kernel(const PvKernelParams p)
+__global__ __launch_bounds__(QC<LOG2N>::T, (RESIDENT || FP64W) ? 1 : 2) PV_NO_DS_MERGE void pv_wg16_kernel(const PvKernelParams p)
 {
     using C = QC<LOG2N>;
     constexpr int N = C::N, M = C::M, H = C::H, T = C::T, K2 = C::K2, NW = C::NW, PR = C::PR, PM = C::PM;
@@ -613,7 +772,7 @@ resident_top:
         double2 z[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) z[r] = double2{(double)(raw[r].x * hw[r].x), (double)(raw[r].y * hw[r].y)};
-        if (pf < 0.75 && ((tq >> 4) & 1)) {
+        if (!FP64W && pf < 0.75 && ((tq >> 4) & 1)) {
             // the general residue (f < 0.75 only) rebuilds quarter 2 of fft.js's buffer from the windowed samples xw[4n + 2] = sample 2 (ts + 256 r) of the threads
             // with an odd ts: stashed in natural order while they are in registers (pv_wg_kernel.hip)
             float *XQ = reinterpret_cast<float *>(smem + C::OFF_XQ);
@@ -625,6 +784,7 @@ resident_top:
         // ---- split pass in conjugate pairs: thread tq owns the pairs k = tq + 256 r, r < 8: XA[r] = X[k], XB[r] = X[M - k]; thread 0 also the self-paired bin M/2.
         //      The partner values Z[M - k] are rows 8..15 of other threads -> LDS ----
         float2 XA[8], XB[8], xHf{0.f, 0.f};
+        [[maybe_unused]] double2 XAd[8], XBd[8], xHd{0.0, 0.0};                // fp64 flavour: the source spectrum stays in doubles
         wg16_prio<2, T>();
         {
 #pragma unroll
@@ -649,6 +809,7 @@ resident_top:
                 MAG[C::MAG0 + PM - ql - PR * r] = (float)(xb.x * xb.x + xb.y * xb.y);
                 XA[r] = float2{(float)xa.x, (float)xa.y};
                 XB[r] = float2{(float)xb.x, (float)xb.y};
+                if constexpr (FP64W) { XAd[r] = xa; XBd[r] = xb; }
                 if (dbg) {
                     const int ka = tq + T * r, kb = M - ka;
                     p.dbg_X[2 * ka] = xa.x; p.dbg_X[2 * ka + 1] = xa.y;
@@ -661,7 +822,8 @@ resident_top:
                 if (dbg) { p.dbg_X[M] = xH.x; p.dbg_X[M + 1] = xH.y; }
             }
             xHf = float2{(float)xH.x, (float)xH.y};
-            if (pf < 1.0) {                                                // fp32 spectrum stash for the fast residue (Y is not live yet; it aliases the partner rows)
+            if constexpr (FP64W) xHd = xH;
+            if (!FP64W && pf < 1.0) {                                                // fp32 spectrum stash for the fast residue (Y is not live yet; it aliases the partner rows)
                 __syncthreads();
 #pragma unroll
                 for (int r = 0; r < 8; r++) { Y[tq + T * r] = XA[r]; Y[M - tq - T * r] = XB[r]; }
@@ -670,8 +832,9 @@ resident_top:
         }
         // conj(W^{2k}) of this thread's first bin k = 1 + tq of the fast residue (f < 1; k = 1 + tq + 256 j: times conj(W_16^j)): a load from the global table, issued HERE,
         // two barriers ahead of its use -- behind the "magnitudes complete" barrier it was an exposed round trip in every f < 1 frame (profiles/r05_wg16_phase_clock.md)
-        float2 s2w0{1.f, 0.f};
-        if (pf < 1.0) s2w0 = cconj(p.tw32[2 * (1 + tq)]);
+        // (the RAW table entry: a conjugation inside the branch would make the branch wait for its own load)
+        float2 s2raw{1.f, 0.f};
+        if (!FP64W && pf < 1.0) s2raw = p.tw32[2 * (1 + tq)];
         // slide the raw window; the rows the next frame adds are issued here
         {
             const int mn = (m + 1 < last_out) ? m + 1 : m;
@@ -705,13 +868,14 @@ resident_top:
         W16_MARK(6);
         // ---- above-Nyquist residue, fast form: W^{2k} S2[k] = (X[k] - X[k+N/4] + X[k+N/2] - X[k+3N/4]) / 4, k = 1 + tq + 256 j (see pv_wg_kernel.hip) ----
         float2 s2v[4] = {float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}, float2{0.f, 0.f}};
-        if (pf < 1.0) {
+        if (!FP64W && pf < 1.0) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int k = 1 + tq + T * j;                                // k in [1, N/8]
                 const float2 x0 = Y[k], x1 = Y[k + M / 2], x2 = Y[M - k], x3 = Y[M / 2 - k];
                 const float2 tsum{0.25f * ((x0.x - x1.x) + (x2.x - x3.x)), 0.25f * ((x0.y - x1.y) - (x2.y - x3.y))};
                 const float c8 = 0.92387953251128675613f, s8 = 0.38268343236508977173f, h8 = 0.70710678118654752440f;
+                const float2 s2w0 = cconj(s2raw);
                 const float2 wj = (j == 0) ? s2w0 : (j == 1) ? cmul(s2w0, float2{c8, s8}) : (j == 2) ? cmul(s2w0, float2{h8, h8}) : cmul(s2w0, float2{s8, c8});
                 s2v[j] = cmul(tsum, wj);
             }
@@ -846,15 +1010,56 @@ resident_top:
         if (last_peak >= 0 && last_shift < 0) { upper_end = H - last_shift; if (upper_end > N) upper_end = N; }      // DROP is positive
         const float2 wlf = cconj(p.tw32[tq]);                               // c2r twiddle e^{+2 pi j tq / N}: loaded a phase ahead of its use
         // ---- zero Y (pv:121) ----
+        [[maybe_unused]] double2 *Yd = reinterpret_cast<double2 *>(smem + C::OFF_Y);
+        if constexpr (FP64W) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) *reinterpret_cast<v4f *>(&Y[2 * tq + 2 * T * r]) = v4f{0.f, 0.f, 0.f, 0.f};
-        if (tq == 0) Y[M] = float2{0.f, 0.f};
+            for (int r = 0; r < 16; r++) *reinterpret_cast<v4f *>(&Yd[tq + T * r]) = v4f{0.f, 0.f, 0.f, 0.f};
+            if (tq == 0) Yd[M] = double2{0.0, 0.0};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) *reinterpret_cast<v4f *>(&Y[2 * tq + 2 * T * r]) = v4f{0.f, 0.f, 0.f, 0.f};
+            if (tq == 0) Y[M] = float2{0.f, 0.f};
+        }
         const bool need_res = upper_end > H;
         __syncthreads();
         W16_MARK(8);
         wg16_prio<7, T>();
         // ---- shiftPeaks (pv:119-173) ----
-        {
+        if constexpr (FP64W) {
+            // fp64 flavour: plain stores for f >= 1 (disjoint regions); f < 1 (and NaN): `+=` collisions (pv:169-170) by claim rounds in ascending batches, then the
+            // sources above Nyquist (all owned by the last peak, pv:133) from the re-run stage structure -- neither the pairwise scatter nor the closed form of the residue
+            if (pf >= 1.0) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const unsigned ra = ROUTE[C::MAG0 + pl + PR * r], ta = ra & 0xFFFFu;
+                    const unsigned rb = ROUTE[C::MAG0 + PM - ql - PR * r], tb = rb & 0xFFFFu;
+                    if (ta < (unsigned)H) Yd[ta] = rotate_route_d<R, LOG2N>(ra, XAd[r], p.tw64);
+                    if (tb < (unsigned)H) Yd[tb] = rotate_route_d<R, LOG2N>(rb, XBd[r], p.tw64);
+                }
+                if (tq == 0) { const unsigned rt = ROUTE[C::MAG0 + PM / 2], tg = rt & 0xFFFFu; if (tg < (unsigned)H) Yd[tg] = rotate_route_d<R, LOG2N>(rt, xHd, p.tw64); }
+            } else {
+                unsigned rt0[9], rt1[9]; double2 ys0[9], ys1[9]; int id0[9], id1[9];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    id0[r] = tq + T * r; rt0[r] = ROUTE[C::MAG0 + pl + PR * r]; ys0[r] = rotate_route_d<R, LOG2N>(rt0[r], XAd[r], p.tw64);
+                    id1[r] = M - tq - T * r; rt1[r] = ROUTE[C::MAG0 + PM - ql - PR * r]; ys1[r] = rotate_route_d<R, LOG2N>(rt1[r], XBd[r], p.tw64);
+                }
+                id0[8] = 0; rt0[8] = NOROUTE; ys0[8] = double2{0.0, 0.0};
+                id1[8] = M / 2; rt1[8] = (tq == 0) ? ROUTE[C::MAG0 + PM / 2] : NOROUTE; ys1[8] = rotate_route_d<R, LOG2N>(rt1[8], xHd, p.tw64);
+                __syncthreads();                                            // every ROUTE read is done: the region becomes the claim words
+#pragma unroll
+                for (int r = 0; r < 16; r++) CLAIM[tq + T * r] = 0xFFFFFFFFu;
+                if (tq == 0) CLAIM[M] = 0xFFFFFFFFu;
+                claim_rounds_wg16<9, H>(rt0, ys0, id0, Yd, CLAIM);
+                claim_rounds_wg16<9, H>(rt1, ys1, id1, Yd, CLAIM);
+                if (need_res) {
+                    __syncthreads();
+                    const int up_delta = last_shift;
+                    residue_scatter_wg16_d<LOG2N, R>(src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw64, tq, upper_end, up_delta,
+                                                     (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1), dbg ? p.dbg_X : nullptr);
+                }
+            }
+        } else {
             if (pf >= 1.0) {
                 auto scatter = [&](auto mode_tag) {
                     constexpr int MODE = decltype(mode_tag)::value;
@@ -963,18 +1168,51 @@ resident_top:
                 }
             }
         }
-        if (nonfinite && l == 0) Y[1 + wv] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};   // the reference's frame is NaN: so is this one
+        if (nonfinite && l == 0) {                                         // the reference's frame is NaN: so is this one
+            if constexpr (FP64W) Yd[1 + wv] = double2{__longlong_as_double(0x7FF8000000000000ll), __longlong_as_double(0x7FF8000000000000ll)};
+            else Y[1 + wv] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};
+        }
         __syncthreads();
         W16_MARK(9);
         if (dbg) {
+            auto yat = [&](int k) -> float2 { if constexpr (FP64W) return float2{(float)Yd[k].x, (float)Yd[k].y}; else return Y[k]; };
 #pragma unroll
-            for (int r = 0; r < 16; r++) { const int k = tq + T * r; p.dbg_Y[2 * k] = Y[k].x; p.dbg_Y[2 * k + 1] = Y[k].y; }
-            if (tq == 0) { p.dbg_Y[2 * M] = Y[M].x; p.dbg_Y[2 * M + 1] = Y[M].y; }
+            for (int r = 0; r < 16; r++) { const int k = tq + T * r; p.dbg_Y[2 * k] = yat(k).x; p.dbg_Y[2 * k + 1] = yat(k).y; }
+            if (tq == 0) { p.dbg_Y[2 * M] = yat(M).x; p.dbg_Y[2 * M + 1] = yat(M).y; }
         }
+        // the inverse's pass-A twiddles conj(W_M^{ts k}), k = 1, 2, 4, 8: issued HERE, in front of the c2r pass and its barrier.  Behind it, next to the sixteen window
+        // loads, their place in the memory queue is the compiler's choice -- and vmcnt counts in order: when they come out BEHIND the window loads, the inverse FFT
+        // waits for all twenty (round 5: 3.05 -> 3.53 ms on C5 when an unrelated change flipped that order)
+        [[maybe_unused]] float2 f1{1.f, 0.f}, f2{1.f, 0.f}, f4{1.f, 0.f}, f8{1.f, 0.f};
+        if constexpr (!FP64W) { f1 = cconj(p.tw32[(2 * tsq) & (N - 1)]); f2 = cconj(p.tw32[(4 * tsq) & (N - 1)]); f4 = cconj(p.tw32[(8 * tsq) & (N - 1)]); f8 = cconj(p.tw32[(16 * tsq) & (N - 1)]); }
         wg16_prio<8, T>();
         // ---- c2r pre-pass in conjugate pairs, packed fp32 (see pv_wg_kernel.hip): thread tq computes k = tq + 256 r, r < 8, and hands Z[M - k] over through LDS ----
         pk::c32 zi[16];
-        {
+        [[maybe_unused]] double2 zd[16];
+        if constexpr (FP64W) {
+            // c2r pre-pass in fp64: Z[k] = SC ((Yk + Ym*) + j e^{+2 pi j k / N} (Yk - Ym*)), conjugate pairs as in the product
+            constexpr double sc = 2.0 / ((double)N * (double)R);
+            const double2 wlc{wl.x, -wl.y};
+            double2 zb[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = tq + T * r;
+                double2 yk = Yd[k], ym = Yd[M - k];
+                if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
+                const double2 E{yk.x + ym.x, yk.y - ym.y}, O{yk.x - ym.x, yk.y + ym.y};
+                const double2 c = cmul(cconj(mul_w32_16(cconj(O), r)), wlc);   // O * exp(+2 pi j r / 32) * exp(+2 pi j tq / N)
+                zd[r] = double2{(E.x - c.y) * sc, (E.y + c.x) * sc};        // E + j c
+                zb[r] = double2{(E.x + c.y) * sc, -(E.y - c.x) * sc};       // conj(E - j c)
+            }
+            const double2 yH = Yd[M / 2];
+            double2 *XCHd = reinterpret_cast<double2 *>(smem + C::OFF_RESQ);
+#pragma unroll
+            for (int r = 0; r < 8; r++) if (r > 0 || tq > 0) XCHd[8 * T - tq - T * r] = zb[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 8; r < 16; r++) zd[r] = XCHd[tq + T * (r - 8)];
+            if (tq == 0) zd[8] = double2{2.0 * yH.x * sc, -2.0 * yH.y * sc};
+        } else {
             constexpr float sc = 2.0f / ((float)N * (float)R);                // 1/N of the inverse, 1/R of the overlap-add, 2 for the 0.5 * Hann table (exact)
             const pk::c32 wlfs{wlf.x * sc, wlf.y * sc};                       // c2r twiddle with the scale folded in
             const pk::c32 scsc{sc, sc};
@@ -1009,10 +1247,16 @@ resident_top:
 #pragma unroll
             for (int r = 0; r < 16; r++) hw[r] = *reinterpret_cast<const float2 *>(p.hann + N + 2 * (tsi + T * r));
         }
-        const float2 f1 = cconj(p.tw32[(2 * tsi) & (N - 1)]), f2 = cconj(p.tw32[(4 * tsi) & (N - 1)]), f4 = cconj(p.tw32[(8 * tsi) & (N - 1)]), f8 = cconj(p.tw32[(16 * tsi) & (N - 1)]);
+        if constexpr (FP64W) {
+            const TwA twi{p.tw64[(2 * tsi) & (N - 1)], p.tw64[(4 * tsi) & (N - 1)], p.tw64[(8 * tsi) & (N - 1)], p.tw64[(16 * tsi) & (N - 1)]};
+            fft_wg16_inv_d<T>(zd, S64, twi, TWB, tqi);
+#pragma unroll
+            for (int r = 0; r < 16; r++) zi[r] = pk::c32{(float)zd[r].x, (float)zd[r].y};     // fromComplexArray -> Float32Array (bundle:46-51)
+        } else {
         const TwAf twaf{pk::c32{f1.x, f1.y}, pk::c32{f2.x, f2.y}, pk::c32{f4.x, f4.y}, pk::c32{f8.x, f8.y}};
         W16_MARK(10);
         fft_wg16_inv_pk<T>(zi, reinterpret_cast<pk::c32 *>(smem), twaf, TWBF, tqi W16_STI);
+        }
         if constexpr (S_ROWS != 8) twa_next = TwA{p.tw64[(2 * tsi) & (N - 1)], p.tw64[(4 * tsi) & (N - 1)], p.tw64[(8 * tsi) & (N - 1)], p.tw64[(16 * tsi) & (N - 1)]};   // the next frame's pass-A twiddles
         // ---- Hann (pv:67), overlap-add in reference order, emit, shift ----
         wg16_prio<5, T>();
@@ -1021,7 +1265,7 @@ resident_top:
             float2 fr[16];
 #pragma unroll
             for (int r = 0; r < 16; r++)                                   // rounded to fp32 BEFORE the accumulation like the reference's Float32Array (pv:67)
-                fr[r] = float2{__fmul_rn(zi[r].x, hw[r].x), __fmul_rn(zi[r].y, hw[r].y)};
+                { const pk::c32 f = pk::mul(zi[r], pk::c32{hw[r].x, hw[r].y}); fr[r] = float2{f.x, f.y}; }   // an asm multiply: see mul_rounded (pv_device_common.h)
 #pragma unroll
             for (int r = 0; r < S_ROWS; r++) {
                 const float2 o{acc[r].x + fr[r].x, acc[r].y + fr[r].y};

@@ -351,8 +351,8 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(cons
             constexpr int nd = (LOG2N - 2) / 2;
             const int blk = base / 4 + t;                                  // QN/4 = T blocks per quarter
             const int off = digitrev4_(blk, nd);
-            const float a = src.at(s0 + off) * hann[off], b = src.at(s0 + off + N / 4) * hann[off + N / 4];
-            const float c = src.at(s0 + off + N / 2) * hann[off + N / 2], d = src.at(s0 + off + 3 * N / 4) * hann[off + 3 * N / 4];
+            const float a = mul_rounded(src.at(s0 + off), hann[off]), b = mul_rounded(src.at(s0 + off + N / 4), hann[off + N / 4]);
+            const float c = mul_rounded(src.at(s0 + off + N / 2), hann[off + N / 2]), d = mul_rounded(src.at(s0 + off + 3 * N / 4), hann[off + 3 * N / 4]);
             const float t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
             Q[4 * t] = float2{t0 + t2, 0.f};
             Q[4 * t + 1] = float2{t1, -t3};
@@ -364,7 +364,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg(cons
             for (int i = 0; i < 2; i++) {                                  // QN/2 = 2T blocks per quarter
                 const int lb = t + T * i, blk = base / 2 + lb;
                 const int off = digitrev4_(blk, nd);
-                const float a = src.at(s0 + off) * hann[off], b = src.at(s0 + off + N / 2) * hann[off + N / 2];
+                const float a = mul_rounded(src.at(s0 + off), hann[off]), b = mul_rounded(src.at(s0 + off + N / 2), hann[off + N / 2]);
                 Q[2 * lb] = float2{a + b, 0.f};
                 Q[2 * lb + 1] = float2{a - b, 0.f};
             }
@@ -978,7 +978,7 @@ resident_top:
             float2 fr[8];
 #pragma unroll
             for (int r = 0; r < 8; r++)                                    // rounded to fp32 BEFORE the accumulation like the reference's Float32Array (pv:67): no contraction into the adds
-                fr[r] = float2{__fmul_rn(zi[r].x, hw[r].x * invR), __fmul_rn(zi[r].y, hw[r].y * invR)};
+                fr[r] = float2{mul_rounded(zi[r].x, hw[r].x * invR), mul_rounded(zi[r].y, hw[r].y * invR)};
             if (RING) {
                 // phase 1: samples below N - hop read their slot (emit the first hop, accumulate the rest); phase 2: the last hop samples
                 // of the frame take over the slots the emitted hop freed (0 + x, ola:130-137)
