@@ -1451,6 +1451,15 @@ resident_top:
         fft512_wave_inv_pk(zi, reinterpret_cast<pk::c32 *>(S32), TW1F4, TW2F4, l);
 #endif
         }
+        // The rows and the pitchFactor prefetched for the next frame are CONSUMED here, in front of this frame's output stores.  vmcnt counts loads and stores in ONE queue, in
+        // order: left to the loop's back edge, the first use of the prefetched registers (the copies of the loop-carried window, the readfirstlane of f at the top) waits
+        // for the stores issued after the loads as well -- `s_waitcnt vmcnt(0)` at the top of every frame, a store's full round trip to memory.  Here, a thousand
+        // instructions after their issue, the loads have landed and the wait is free; the stores then stay in flight across the loop edge.
+#ifndef PV_NO_CONSUME
+#pragma unroll
+        for (int r = 8 - S_ROWS; r < 8; r++) asm volatile("" :: "v"(raw[r]));
+        asm volatile("" :: "v"(pf_next));
+#endif
         // ---- Hann (pv:67), overlap-add in reference order (ola:149-157), emit (ola:111-118), shift (ola:130-137) ----
         pv_prio(PH_OLA);
         {
