@@ -390,8 +390,8 @@ int pv_create(const pv_config *cfg, pv_handle **out)
         h->use_wave = pv_wave_supported(log2n, hop) && !generic;
         h->use_wg = pv_wg_supported(log2n, hop) && !generic;
         const bool wg_only = (cfg->flags & PV_FLAG_WORKGROUP_KERNEL) != 0;    // A/B: the eight-element workgroup kernel where a one-wave / sixteen-element kernel exists
-        h->use_wave2k = h->use_wg && !wg_only && pv_wave2k_supported(log2n, hop);
         h->use_wg16 = h->use_wg && !wg_only && pv_wg16_supported(log2n, hop);
+        h->use_wave2k = h->use_wg && !wg_only && !h->use_wg16 && pv_wave2k_supported(log2n, hop);   // (the two never meet in the product; the reference-width flavour's sixteen-element kernel also takes N = 2048)
     }
 
 #define CHK(call)                                                          \

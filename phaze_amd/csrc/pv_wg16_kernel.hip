@@ -108,7 +108,7 @@ struct QC {
     static constexpr int OFF_TWBF = OFF_TWB + 16 * 15 * K2;   // float2[15][K2] conj, fp32
     static constexpr int OFF_XQ = OFF_TWBF + 8 * 15 * K2;   // f32[N / 4] windowed samples xw[4n + 2] of the frame (f < 0.75): base stage of the general residue
     static constexpr int LDS_BYTES = OFF_XQ + N;          // 81632 (two workgroups per CU) / 39840 (four)
-    static_assert((LDS_BYTES + 256 + 511) / 512 * 512 * (FP64W ? 256 / T : 512 / T) <= 160 * 1024, "workgroups per CU (256 static bytes: __syncthreads_or)");
+    static_assert(LOG2N_ == 11 || (LDS_BYTES + 256 + 511) / 512 * 512 * (FP64W ? 256 / T : 512 / T) <= 160 * 1024, "workgroups per CU (256 static bytes: __syncthreads_or)");
 };
 
 // ---- radix-16 butterflies, natural order in and out: X[q + 4 p] = sum_j W4^{j p} ( W16^{j q} sum_m a[j + 4 m] W4^{m q} ) ----
@@ -250,7 +250,7 @@ __device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA
     wg16_prio<0, T_>();
     if (K2 == 16) {
         radix16_fwd(a);
-    } else {                                                            // two radix-8 DFTs over n0; bin t + T (h + 2 k2) <- register 8 h + k2
+    } else if (K2 == 8) {                                               // two radix-8 DFTs over n0; bin t + T (h + 2 k2) <- register 8 h + k2
         double2 lo[8], hi[8];
 #pragma unroll
         for (int n = 0; n < 8; n++) { lo[n] = a[n]; hi[n] = a[8 + n]; }
@@ -258,6 +258,15 @@ __device__ __forceinline__ void fft_wg16(double2 (&a)[16], double2 *S, const TwA
         radix8<double, false>(hi);
 #pragma unroll
         for (int k = 0; k < 8; k++) { a[2 * k] = lo[k]; a[2 * k + 1] = hi[k]; }
+    } else {                                                            // K2 = 4 (N = 2048, the fp64 flavour only): four radix-4 DFTs over n0; bin t + T (h + 4 k2) <- register 4 h + k2
+        double2 b[16];
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const double2 s02 = cadd(a[4 * h], a[4 * h + 2]), d02 = csub(a[4 * h], a[4 * h + 2]), s13 = cadd(a[4 * h + 1], a[4 * h + 3]), d13 = csub(a[4 * h + 1], a[4 * h + 3]);
+            b[h] = cadd(s02, s13); b[h + 4] = double2{d02.x + d13.y, d02.y - d13.x}; b[h + 8] = csub(s02, s13); b[h + 12] = double2{d02.x - d13.y, d02.y + d13.x};
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) a[r] = b[r];
     }
     st(4);
 }
@@ -274,7 +283,7 @@ __device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, co
     wg16_prio<3, T_>();
     if (K2 == 16) {
         radix16_inv_pk(a);
-    } else {                                                            // register 8 h + k2 <- bin t + T (h + 2 k2); two radix-8 inverse DFTs over k2 -> n0
+    } else if (K2 == 8) {                                               // register 8 h + k2 <- bin t + T (h + 2 k2); two radix-8 inverse DFTs over k2 -> n0
         pk::c32 lo[8], hi[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) { lo[k] = a[2 * k]; hi[k] = a[2 * k + 1]; }
@@ -282,6 +291,15 @@ __device__ __forceinline__ void fft_wg16_inv_pk(pk::c32 (&a)[16], pk::c32 *S, co
         pk::radix8_inv(hi);
 #pragma unroll
         for (int n = 0; n < 8; n++) { a[n] = lo[n]; a[8 + n] = hi[n]; }
+    } else {                                                            // K2 = 4: register 4 h + k2 <- bin t + T (h + 4 k2); four radix-4 inverse DFTs over k2 -> n0
+        pk::c32 b[16];
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const pk::c32 s02 = pk::add(a[h], a[h + 8]), d02 = pk::sub(a[h], a[h + 8]), s13 = pk::add(a[h + 4], a[h + 12]), d13 = pk::sub(a[h + 4], a[h + 12]);
+            b[4 * h] = pk::add(s02, s13); b[4 * h + 1] = pk::add_j(d02, d13); b[4 * h + 2] = pk::sub(s02, s13); b[4 * h + 3] = pk::sub_j(d02, d13);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) a[r] = b[r];
     }
     st(0);
     wg16_prio<4, T_>();
@@ -336,7 +354,7 @@ __device__ __forceinline__ void fft_wg16_inv_d(double2 (&a)[16], double2 *S, con
     constexpr int K2 = T_ / 16;
     if (K2 == 16) {
         radix16_inv_d(a);
-    } else {
+    } else if (K2 == 8) {
         double2 lo[8], hi[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) { lo[k] = a[2 * k]; hi[k] = a[2 * k + 1]; }
@@ -344,6 +362,15 @@ __device__ __forceinline__ void fft_wg16_inv_d(double2 (&a)[16], double2 *S, con
         radix8<double, true>(hi);
 #pragma unroll
         for (int n = 0; n < 8; n++) { a[n] = lo[n]; a[8 + n] = hi[n]; }
+    } else {
+        double2 b[16];
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const double2 s02 = cadd(a[h], a[h + 8]), d02 = csub(a[h], a[h + 8]), s13 = cadd(a[h + 4], a[h + 12]), d13 = csub(a[h + 4], a[h + 12]);
+            b[4 * h] = cadd(s02, s13); b[4 * h + 1] = double2{d02.x - d13.y, d02.y + d13.x}; b[4 * h + 2] = csub(s02, s13); b[4 * h + 3] = double2{d02.x + d13.y, d02.y - d13.x};
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) a[r] = b[r];
     }
 #pragma unroll
     for (int h = 0; h < 16 / K2; h++)
@@ -1354,15 +1381,18 @@ hipError_t launch_wg16_n(const PvKernelParams &p, int nch, int nchunks, hipStrea
 
 bool pv_wg16_supported(int log2n, int hop)
 {
-    if (log2n != 12 && log2n != 13) return false;
+    // (the fp64 flavour also takes N = 2048 -- T = 64 threads, M = 16 * 16 * 4 --: C3's shape in reference-width arithmetic; the product runs pv_wave2k_kernel there, which is
+    //  3 % faster than this kernel at that size, tools/experiments/README.md)
+    if (log2n != 12 && log2n != 13 && !(FP64W && log2n == 11)) return false;
     const int N = 1 << log2n;
     return hop == N / 8 || hop == N / 4 || hop == N / 2 || hop == N;
 }
-size_t pv_wg16_lds_bytes(int log2n) { return log2n == 12 ? QC<12>::LDS_BYTES : QC<13>::LDS_BYTES; }
-int pv_wg16_threads(int log2n) { return log2n == 12 ? QC<12>::T : QC<13>::T; }
+size_t pv_wg16_lds_bytes(int log2n) { return log2n == 11 ? QC<11>::LDS_BYTES : log2n == 12 ? QC<12>::LDS_BYTES : QC<13>::LDS_BYTES; }
+int pv_wg16_threads(int log2n) { return log2n == 11 ? QC<11>::T : log2n == 12 ? QC<12>::T : QC<13>::T; }
 
 hipError_t pv_launch_wg16(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
 {
+    if constexpr (FP64W) { if (log2n == 11) return launch_wg16_n<11>(p, nch, nchunks, st); }
     return log2n == 12 ? launch_wg16_n<12>(p, nch, nchunks, st) : launch_wg16_n<13>(p, nch, nchunks, st);
 }
 

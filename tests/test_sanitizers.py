@@ -140,7 +140,7 @@ def _run_addon(tmp_path):
 @pytest.mark.skipif(NODE is None, reason="node not installed")
 def test_napi_addon_error_paths_under_asan(tmp_path):
     out = _run_addon(tmp_path)
-    assert out["exports"] == 15 and out["bad"] == "FFT size must be a power of two and bigger than 1" and out["nohandle"] == "throws"
+    assert out["exports"] == 16 and out["bad"] == "FFT size must be a power of two and bigger than 1" and out["nohandle"] == "throws"
     if out["devices"] == 0:
         assert "no HIP device" in out["nodev"]
 
