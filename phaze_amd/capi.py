@@ -182,9 +182,18 @@ class PhaseVocoder:
         self.max_channels, self.max_hops = max_channels, max_hops
         self._host_channels = bool(flags & FLAG_HOST_CHANNEL_BOOKKEEPING)
         self._nin = self._nout = 1                          # "default to 1 channel per input / output until we know more" (ola-processor.js:24-33)
+        # host bookkeeping only: what it takes to reproduce an output channel that lost its input while outputs[0].length stayed (see _stale_frame)
+        self._device_id, self._flags = device_id, flags
+        self._window = np.zeros((max_channels, fft_size), np.float32) if self._host_channels else None   # inputBuffers as the reference holds them (ola-processor.js:59,121-127)
+        self._stale = {}                                    # channel -> [frame / nbOverlaps as the last real quantum added it, quanta it has been re-added since]
+        self._last_pitch = None
+        self._scratch = None
 
     # -- lifetime --
     def close(self):
+        if getattr(self, "_scratch", None) is not None:
+            self._scratch.close()
+            self._scratch = None
         if getattr(self, "_h", None) and self._h.value:
             self._L.pv_destroy(self._h)
             self._h = C.c_void_p()
@@ -254,10 +263,26 @@ class PhaseVocoder:
             # the reference's reallocateChannelsIfNeeded (ola-processor.js:38-52): inputs and outputs are two separate events
             if len(outputs[0]) < nch:
                 raise TypeError("outputs[0] has fewer channels than inputs[0]: the reference's processOLA dereferences outputs[i][j] (phase-vocoder.js:51) and throws")
+            out_changed = len(outputs[0]) != self._nout
             if nch != self._nin:
+                if not out_changed:
+                    # One corner of ola-processor.js (149-157): `outputBuffersToRetrieve` is only reallocated with the OUTPUT channels, so an output channel whose input
+                    # disappears keeps its last frame there, and handleOutputBuffersToRetrieve goes on adding that stale frame (and shifting) every quantum.  Nobody
+                    # hears it (writeOutputs walks the input channels) -- unless the input returns before the output count changes: then the channel's pending sums
+                    # are those of the stale frame.  Lost channels: remember the frame; regained channels: their accumulator becomes what the reference's has become.
+                    for c in range(nch, min(self._nin, self._nout, self.max_channels)):
+                        self._stale[c] = [self._stale_frame(c), 0]
+                    regained = {c: self._stale_accumulator(c) for c in range(self._nin, min(nch, self.max_channels)) if c in self._stale}
+                else:
+                    regained = {}
                 self.reset_channels(0, self.max_channels, STATE_HISTORY)
+                self._window[:] = 0.0
+                for c, acc in regained.items():
+                    self.import_state(c, acc=acc)
+                    del self._stale[c]
                 self._nin = nch
-            if len(outputs[0]) != self._nout:
+            if out_changed:
+                self._stale.clear()                                              # allocateOutputChannels: fresh (zeroed) outputBuffersToRetrieve (ola-processor.js:74-85)
                 self.reset_channels(0, self.max_channels, STATE_ACCUMULATOR)
                 self._nout = len(outputs[0])
         pf = np.asarray(parameters["pitchFactor"], dtype=np.float32)
@@ -272,7 +297,42 @@ class PhaseVocoder:
         self._check(self._L.pv_process(self._h, ip, op, nch, 0 if paused else self.hop_size, C.c_float(pitch)))
         for c in range(min(nch, len(outs))):
             outs[c][:] = tmp[c]
+        if self._host_channels:
+            h = self.hop_size
+            for c in range(min(nch, self.max_channels)):                           # readInputs + shiftInputBuffers (ola-processor.js:89-127)
+                w = self._window[c]
+                if h < self.fft_size:
+                    w[:-h] = w[h:].copy()
+                w[-h:] = 0.0 if paused else keep[c]
+            self._last_pitch = pitch
+            for rec in self._stale.values():
+                rec[1] += 1
         return True
+
+    def _stale_frame(self, ch):
+        """The windowed frame / nbOverlaps that the last quantum added for channel `ch`, recomputed on a one-channel scratch handle from the window the reference's
+        inputBuffers held (zero accumulator in: the hop that comes out and the accumulator left behind ARE the frame, 0 + x being exact)."""
+        N, h = self.fft_size, self.hop_size
+        t = self.time_cursor
+        if self._last_pitch is None or t < h:
+            return np.zeros(N, np.float32)                                        # no frame yet: outputBuffersToRetrieve still holds its zeros
+        if self._scratch is None:
+            self._scratch = PhaseVocoder(N, h, 1, 1, self._device_id, 0, self._flags & FLAG_FP64_FORWARD)
+        sc = self._scratch
+        sc.import_state(0, hist=self._window[ch, :N - h], acc=np.zeros(N - h, np.float32), time_cursor=t - h)
+        out = [[np.zeros(h, np.float32)]]
+        sc.process([[self._window[ch, N - h:].copy()]], out, {"pitchFactor": np.array([self._last_pitch], np.float32)})
+        return np.concatenate([out[0][0], sc.export_state(0)[1]]).astype(np.float32)
+
+    def _stale_accumulator(self, ch):
+        """outputBuffers of a channel whose stale frame has been re-added for q quanta (f32 adds in the reference's order, ola-processor.js:130-157)."""
+        N, h = self.fft_size, self.hop_size
+        frame, q = self._stale[ch]
+        a = np.concatenate([self.export_state(ch)[1], np.zeros(h, np.float32)]).astype(np.float32)
+        for _ in range(min(q, N // h + 1)):                                       # (after N / hop quanta the sums no longer change)
+            a = a + frame
+            a = np.concatenate([a[h:], np.zeros(h, np.float32)])
+        return a[:N - h]
 
     # -- the hot call, batch forms --
     def process_batch(self, x, pitch, channels_per_stream=0, out=None):

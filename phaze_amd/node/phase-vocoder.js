@@ -18,7 +18,7 @@
 const path = require("path");
 const native = require(path.join(__dirname, "phaze_napi.node"));
 
-const HOST_CHANNEL_BOOKKEEPING = 128, STATE_HISTORY = 1, STATE_ACCUMULATOR = 2;   // PV_FLAG_HOST_CHANNEL_BOOKKEEPING, PV_STATE_* of include/phaze_amd.h
+const HOST_CHANNEL_BOOKKEEPING = 128, FP64_FORWARD = 256, STATE_HISTORY = 1, STATE_ACCUMULATOR = 2;   // PV_FLAG_HOST_CHANNEL_BOOKKEEPING, PV_STATE_* of include/phaze_amd.h
 const BUFFERED_BLOCK_SIZE = 2048;   // reference default (phase-vocoder.js:6)
 const WEBAUDIO_BLOCK_SIZE = 128;    // reference default (ola-processor.js:3)
 
@@ -54,6 +54,12 @@ class PhaseVocoderProcessor extends Base {
         this._channels = [];                                            // inputs[i].length the input side was "allocated" for
         this._outChannels = [];                                         // outputs[i].length the output side was "allocated" for
         this._capacity = [];
+        // what it takes to reproduce an output channel that lost its input while outputs[i].length stayed (reallocateChannelsIfNeeded, _staleFrame):
+        this._rings = [];                                               // per input, per channel slot: the last blockSize input samples as a ring (inputBuffers, ola-processor.js:59,121-127)
+        this._ringPos = [];                                             // per input: where the next block goes
+        this._stale = [];                                               // per input: Map channel -> { frame: frame / nbOverlaps as the last real quantum added it, q: quanta it has been re-added }
+        this._lastPitch = undefined;
+        this._scratch = null;
         this._flags |= HOST_CHANNEL_BOOKKEEPING;                        // the resets below replace the C ABI's own (mirrored) channel-count rule
         for (let i = 0; i < (this.nbInputs | 0); i++) {
             // "default to 1 channel per input until we know more" (ola-processor.js:24-27); capacity 2 avoids a
@@ -63,7 +69,45 @@ class PhaseVocoderProcessor extends Base {
             this._handles.push(native.create({ fftSize: this.blockSize, hopSize: this.hopSize, maxChannels: 2, maxHops: this._maxHops, deviceId: this.deviceId, flags: this._flags }));
             this._channels.push(1);
             this._outChannels.push(1);
+            this._rings.push([new Float32Array(this.blockSize), new Float32Array(this.blockSize)]);
+            this._ringPos.push(0);
+            this._stale.push(new Map());
         }
+    }
+
+    /** The last blockSize input samples of channel c of input i, oldest first (the reference's inputBuffers after shiftInputBuffers). */
+    _window(i, c) {
+        const N = this.blockSize, ring = this._rings[i][c], pos = this._ringPos[i], w = new Float32Array(N);
+        w.set(ring.subarray(pos), 0);
+        w.set(ring.subarray(0, pos), N - pos);
+        return w;
+    }
+
+    /** The windowed frame / nbOverlaps the last quantum added for channel c of input i, recomputed on a one-channel scratch handle from that window with a zero
+     *  accumulator: the hop that comes out and the accumulator left behind ARE the frame (0 + x is exact). */
+    _staleFrame(i, c) {
+        const N = this.blockSize, h = this.hopSize, t = native.timeCursor(this._handles[i]);
+        if (this._lastPitch === undefined || t < h) return new Float32Array(N);      // no frame yet: outputBuffersToRetrieve still holds its zeros
+        if (!this._scratch) this._scratch = native.create({ fftSize: N, hopSize: h, maxChannels: 1, maxHops: 1, deviceId: this.deviceId, flags: this._flags & FP64_FORWARD });
+        const w = this._window(i, c), out = [new Float32Array(h)];
+        native.importState(this._scratch, 0, w.slice(0, N - h), new Float32Array(N - h), t - h);
+        native.process(this._scratch, [w.slice(N - h)], out, this._lastPitch);
+        const frame = new Float32Array(N);
+        frame.set(out[0], 0);
+        if (N > h) frame.set(native.exportState(this._scratch, 0).acc, h);
+        return frame;
+    }
+
+    /** outputBuffers of a channel whose stale frame has been re-added for q quanta: f32 adds in the reference's order (ola-processor.js:130-157). */
+    _staleAccumulator(i, c) {
+        const N = this.blockSize, h = this.hopSize, rec = this._stale[i].get(c), a = new Float32Array(N);
+        if (N > h) a.set(native.exportState(this._handles[i], c).acc, 0);
+        for (let n = Math.min(rec.q, N / h + 1); n > 0; n--) {                         // (after N / hop quanta the sums no longer change)
+            for (let k = 0; k < N; k++) a[k] += rec.frame[k];
+            a.copyWithin(0, h);
+            a.fill(0, N - h);
+        }
+        return a.slice(0, N - h);
     }
 
     get timeCursor() { return this._handles.length ? native.timeCursor(this._handles[0]) : 0; }   // phase-vocoder.js:31
@@ -75,6 +119,15 @@ class PhaseVocoderProcessor extends Base {
             const nbOut = (outputs && outputs[i]) ? outputs[i].length : nb;          // (the batch entry points have no output arrays: mirrored)
             const inChanged = nb !== this._channels[i], outChanged = nbOut !== this._outChannels[i];
             if (!inChanged && !outChanged) continue;
+            // One corner of ola-processor.js:149-157: `outputBuffersToRetrieve` is only reallocated with the OUTPUT channels, so an output channel whose input
+            // disappears keeps its last frame there and handleOutputBuffersToRetrieve goes on adding that stale frame (and shifting) every quantum.  Nobody hears it
+            // (writeOutputs walks the input channels) unless the input returns before the output count changes: then the channel's pending sums are the stale frame's.
+            const regained = new Map();
+            if (inChanged && !outChanged) {
+                for (let c = nb; c < Math.min(this._channels[i], this._outChannels[i]); c++) this._stale[i].set(c, { frame: this._staleFrame(i, c), q: 0 });
+                for (let c = this._channels[i]; c < nb; c++) if (this._stale[i].has(c)) regained.set(c, this._staleAccumulator(i, c));
+            }
+            if (outChanged) this._stale[i].clear();                                   // allocateOutputChannels: fresh zeroed outputBuffersToRetrieve (ola-processor.js:74-85)
             if (Math.max(nb, nbOut) > this._capacity[i]) {
                 // more channel slots than the handle owns: a bigger handle.  What the reference would keep across this call -- the side that did NOT change --
                 // moves over (the other side starts from zeros anyway); timeCursor survives (phase-vocoder.js:31,71)
@@ -90,8 +143,24 @@ class PhaseVocoderProcessor extends Base {
                 if (inChanged) native.reset(this._handles[i], 0, this._capacity[i], STATE_HISTORY);          // allocateInputChannels: fresh zeroed input buffers
                 if (outChanged) native.reset(this._handles[i], 0, this._capacity[i], STATE_ACCUMULATOR);     // allocateOutputChannels: fresh zeroed output buffers
             }
+            for (const [c, acc] of regained) { native.importState(this._handles[i], c, null, acc); this._stale[i].delete(c); }
+            while (this._rings[i].length < this._capacity[i]) this._rings[i].push(new Float32Array(this.blockSize));
+            if (inChanged) { for (const r of this._rings[i]) r.fill(0); this._ringPos[i] = 0; }
             this._channels[i] = nb;
             this._outChannels[i] = nbOut;
+        }
+    }
+
+    /** readInputs + shiftInputBuffers (ola-processor.js:89-127) on the host's copy of the input windows; one more quantum for every stale frame. */
+    _afterQuantum(inputs, paused, pitchFactor) {
+        const h = this.hopSize, N = this.blockSize;
+        this._lastPitch = pitchFactor;
+        if (N % h !== 0) return;                                // (no whole number of overlaps: the reference's buffers have no meaning there either)
+        for (let i = 0; i < this._handles.length; i++) {
+            const pos = this._ringPos[i], rings = this._rings[i];
+            for (let c = 0; c < inputs[i].length; c++) { if (paused) rings[c].fill(0, pos, pos + h); else rings[c].set(inputs[i][c], pos); }
+            this._ringPos[i] = (pos + h) % N;
+            for (const rec of this._stale[i].values()) rec.q++;
         }
     }
 
@@ -107,6 +176,7 @@ class PhaseVocoderProcessor extends Base {
         if (this._handles.length === 1) {
             const ins = paused ? inputs[0].map(() => PhaseVocoderProcessor._EMPTY) : inputs[0];
             native.process(this._handles[0], ins, outputs[0] || [], pitchFactor);
+            this._afterQuantum(inputs, paused, pitchFactor);
             return true;                                        // ola-processor.js:170
         }
         // several inputs = several independent processors (phase-vocoder.js:49-50): launch them all, then collect them all -- every
@@ -125,6 +195,7 @@ class PhaseVocoderProcessor extends Base {
             throw e;
         }
         for (let i = 0; i < this._handles.length; i++) native.processEnd(this._handles[i], outputs[i] || [], counts[i]);
+        this._afterQuantum(inputs, paused, pitchFactor);
         return true;                                            // ola-processor.js:170
     }
 
@@ -155,6 +226,7 @@ class PhaseVocoderProcessor extends Base {
     close() {
         for (const h of this._handles) native.destroy(h);
         this._handles = [];
+        if (this._scratch) { native.destroy(this._scratch); this._scratch = null; }
     }
 }
 PhaseVocoderProcessor._EMPTY = new Float32Array(0);

@@ -66,7 +66,8 @@ MAN = S.load_manifest()
 CASES = {c["name"]: c for c in MAN["cases"]}
 NODE_CASES = ["c2_1024_256_mono_pf1.5_tonal", "c3_2048_512_stereo_pf0.8_noise", "native_2048_128_mono_pf1.5_noise",
               "pause_1024_256_stereo_noise", "chanchange_1024_256_noise", "arate_1024_256_mono_tonal", "weird_pf_1024_256_mono_noise",
-              "c5s_8192_2048_mono_sweep16_tonal", "outch_1024_256_mono_noise", "outch_2048_128_stereo_tonal"]
+              "c5s_8192_2048_mono_sweep16_tonal", "outch_1024_256_mono_noise", "outch_2048_128_stereo_tonal",
+              "stale_1024_256_stereo_tonal", "stale_2048_128_stereo_noise"]   # (the last two: an output channel that loses its input and gets it back, ola-processor.js:149-157)
 
 
 @pytest.mark.gpu
