@@ -44,6 +44,8 @@ struct pv_handle {
     float *d_stage_in, *d_stage_out, *d_pitch;   // host-buffer batch staging
     unsigned *d_chain_list;                      // N = 1024 batch launches: chain classes (pv_launch_wave), 2 + 2 * chain_list_cap words
     long chain_list_cap;
+    unsigned char *d_gscratch;                   // N >= 16384: the generic kernel's per-workgroup scratch in device memory (pv_kernel_gscratch_bytes), grown on demand
+    size_t gscratch_cap;
     float *d_snap;                               // pipelined host-buffer batch cut into spans of hops: copy of the live half of the channel state (hist | acc), taken
     size_t snap_floats;                          //   before the first piece so that a failure in a later piece can put the handle back (allocated on first use)
     unsigned idle_ticks;                         // resident kernels: constant-rate clock ticks (wall_clock64) after which waves without work leave (~50 ms)
@@ -200,6 +202,22 @@ int launch_chain(pv_handle *h, const float *d_in, float *d_out, int ch0, int nch
             }
             list = h->d_chain_list;
         }
+        if (!h->use_wave && !h->use_wg) {
+            // N >= 16384: the generic kernel keeps its fp32 buffer and its overlap-add ring (N = 32768: its fp64 buffer too) in device memory, one slice per workgroup
+            const size_t stride = pv_kernel_gscratch_bytes(h->log2n, h->hop);
+            if (stride) {
+                const size_t need = stride * (size_t)nch * (size_t)nchunks;
+                if (need > ((size_t)16 << 30)) return fail(h, PV_ERR_CAPACITY, "fft_size >= 16384: the launch needs more than 16 GiB of scratch (fewer channels or hops per call)");
+                if (need > h->gscratch_cap) {
+                    HIPCHK(h, hipStreamSynchronize(h->stream));
+                    if (h->d_gscratch) (void)hipFree(h->d_gscratch);
+                    h->d_gscratch = nullptr; h->gscratch_cap = 0;
+                    HIPCHK(h, hipMalloc(&h->d_gscratch, need));
+                    h->gscratch_cap = need;
+                }
+                p.gscratch = h->d_gscratch; p.gscratch_stride = stride;
+            }
+        }
         e = h->use_wave ? pv_launch_wave(p, nch, nchunks, h->stream, spread, list)
           : h->use_wg ? pv_launch_wg(h->log2n, p, nch, nchunks, h->stream, !h->use_wg16)
                       : pv_launch_chain(h->log2n, p, nch, nchunks, h->stream);
@@ -353,7 +371,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     if (hop <= 0 || N % hop != 0) return fail(nullptr, PV_ERR_ARGUMENT, "hop_size must be positive and divide fft_size");
     int log2n = 0;
     while ((1 << log2n) < N) log2n++;
-    if (log2n < 6 || log2n > 13) return fail(nullptr, PV_ERR_UNSUPPORTED, "fft_size must be within 64..8192 for the gfx950 kernels");
+    if (log2n < 6 || log2n > 15) return fail(nullptr, PV_ERR_UNSUPPORTED, "fft_size must be within 64..32768 for the gfx950 kernels");
     if (hop < 2) return fail(nullptr, PV_ERR_UNSUPPORTED, "hop_size must be >= 2");
     {
         const bool generic = (cfg->flags & PV_FLAG_GENERIC_KERNEL) != 0;
@@ -538,6 +556,7 @@ int pv_destroy(pv_handle *h)
     for (int i = 0; i < 2; i++) { (void)hipFree(h->d_hist[i]); (void)hipFree(h->d_acc[i]); }
     (void)hipFree(h->d_stage_in); (void)hipFree(h->d_stage_out); (void)hipFree(h->d_pitch);
     if (h->d_chain_list) (void)hipFree(h->d_chain_list);
+    if (h->d_gscratch) (void)hipFree(h->d_gscratch);
     (void)hipFree(h->d_fwd_stats);
     if (h->d_snap) (void)hipFree(h->d_snap);
     if (h->h_pin) (void)hipHostFree(h->h_pin);

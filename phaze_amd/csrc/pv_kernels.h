@@ -50,6 +50,8 @@ struct PvKernelParams {
     // only when a decision is in doubt (pv_wave_kernel.hip: F32).  fwd64 != 0: every frame at the reference's width (PV_FLAG_FP64_FORWARD: the round-4 kernels).
     int fwd64;
     unsigned long long *fwd_stats;   // 128 x {frames computed by an F32 instance, frames of those that fell back}; null: not counted
+    unsigned char *gscratch;  // N >= 16384 (pv_chain_kernel's global-scratch instances): pv_kernel_gscratch_bytes() per workgroup, workgroup (ch, chunk) at (ch * nchunks + chunk) * stride
+    unsigned long long gscratch_stride;
     unsigned *stamps;         // measurement builds only (-DPV_STAMPS, tools/exp_headline.sh): [chain][16] accumulated s_memtime deltas per phase
 };
 
@@ -68,6 +70,7 @@ inline hipError_t pv_set_dynamic_lds_once(std::atomic<bool> (&done)[16], const v
 
 int pv_kernel_threads(int log2n);
 size_t pv_kernel_lds_bytes(int log2n, int hop);
+size_t pv_kernel_gscratch_bytes(int log2n, int hop);      // per workgroup; 0 for N <= 8192 (everything in LDS)
 hipError_t pv_launch_chain(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st);
 
 // wave-per-frame kernel for N = 1024 (pv_wave_kernel.hip)

@@ -16,6 +16,7 @@
 // the path is LDS/VALU bound.  No compatibility layers: wave64, gfx950 only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "pv_kernels.h"
 #include "pv_signal.h"
@@ -176,7 +177,10 @@ __device__ __forceinline__ double js_round(double x)   // Math.round (pv:125): n
 // ------------------------------------------------------------------------------------------------
 // The chain kernel
 // ------------------------------------------------------------------------------------------------
-template <int LOG2N, int THREADS>
+// GM (round 5; the sizes beyond the LDS of a CU, which the reference takes like any other power of two, bundle:4-8): 0 = every buffer in LDS (N <= 8192);
+// 1 = the fp32 buffer B and the overlap-add ring in a global-memory scratch of the workgroup (N = 16384: the fp64 buffer alone is 128 KB); 2 = the fp64 buffer as well
+// (N = 32768).  The workgroup's barriers order its global accesses as they order its LDS accesses (workgroup-scope fences).  Slow and complete: no BASELINE config.
+template <int LOG2N, int THREADS, int GM = 0>
 __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams p)
 {
     constexpr int N = 1 << LOG2N, M = N / 2, H = M + 1, LOG2M = LOG2N - 1;
@@ -187,17 +191,20 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
     const int ch = blockIdx.y, chunk = blockIdx.x;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double2 *A = reinterpret_cast<double2 *>(smem);                       // [M+1] fp64: packed FFT, then X[0..M]
-    float2 *B = reinterpret_cast<float2 *>(smem + 16 * (M + 1));          // [N] fp32: mag (alias) / Y[0..M] / residue (M, N)
-    float *acc = reinterpret_cast<float *>(smem + 16 * (M + 1) + 8 * N);  // [L] overlap-add ring
-    unsigned long long *masks = reinterpret_cast<unsigned long long *>(smem + 16 * (M + 1) + 8 * N + 4 * ((L + 1) & ~1));
+    unsigned char *gm = GM ? p.gscratch + ((size_t)ch * gridDim.x + chunk) * p.gscratch_stride : nullptr;
+    unsigned char *abase = (GM == 2) ? gm : smem;                          // where the fp64 buffer lives
+    unsigned char *bbase = (GM == 2) ? gm + 16 * (M + 1) : (GM == 1) ? gm : smem + 16 * (M + 1);
+    double2 *A = reinterpret_cast<double2 *>(abase);                      // [M+1] fp64: packed FFT, then X[0..M]
+    float2 *B = reinterpret_cast<float2 *>(bbase);                        // [N] fp32: mag (alias) / Y[0..M] / residue (M, N)
+    float *acc = reinterpret_cast<float *>(bbase + 8 * N);                // [L] overlap-add ring
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(GM == 2 ? smem : GM == 1 ? smem + 16 * (M + 1) : smem + 16 * (M + 1) + 8 * N + 4 * ((L + 1) & ~1));
     int *wprev = reinterpret_cast<int *>(masks + NWORDS);                 // largest peak in words < w (or -1)
     int *wnext = wprev + NWORDS;                                          // smallest peak in words > w (or BIG)
     float *magv = reinterpret_cast<float *>(B);                           // alias: mags die before Y is zeroed
     float2 *Zb = reinterpret_cast<float2 *>(A);                           // alias: inverse FFT runs where X lived
     const float *frame = reinterpret_cast<const float *>(A);              // real output of the c2r transform
     float2 *Af = reinterpret_cast<float2 *>(A);                           // X[0..M] rounded to fp32, in place over the first half of A (after the decisions)
-    unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + 8 * (M + 1) + 8);   // [H] claim words of the f < 1 scatter, in the half of A the rounding frees
+    unsigned *CLAIM = reinterpret_cast<unsigned *>(abase + 8 * (M + 1) + 8);  // [H] claim words of the f < 1 scatter, in the half of A the rounding frees
     constexpr int BIG = 1 << 30;
 
     const int first_out = chunk * p.frames_per_chunk;
@@ -333,13 +340,22 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
         //          reference's loops (pv:122,146) -- whatever the timing of the waves: chunked, unchunked and call-split runs agree bit for
         //          bit for every f (float atomics, used here before, add in arrival order) ----
         const bool disjoint = (pf >= 1.0);
-        constexpr int SPT = (N + THREADS - 1) / THREADS;                  // sources per thread (<= 32)
+        // (the global-scratch instances take their sources in batches of 16 per thread, ascending: the order of accumulation is the same, the registers are not)
+        constexpr int SPT_ALL = (N + THREADS - 1) / THREADS;              // sources per thread
+        constexpr int NBATCH = GM ? (SPT_ALL + 15) / 16 : 1;
+        constexpr int SPT = SPT_ALL / NBATCH;                             // ... per batch (<= 32)
+        static_assert(SPT * NBATCH == SPT_ALL && SPT <= 32, "sources per thread");
+        if (!disjoint) {
+            for (int k = tid; k < H; k += THREADS) CLAIM[k] = 0xFFFFFFFFu;
+            if (NBATCH > 1) __syncthreads();
+        }
+        for (int bt = 0; bt < NBATCH; bt++) {
         float2 ys[SPT];
         unsigned short tg[SPT];
         unsigned pend = 0;
 #pragma unroll
         for (int i = 0; i < SPT; i++) {
-            const int b = tid + i * THREADS;
+            const int b = tid + (bt * SPT + i) * THREADS;
             ys[i] = float2{0.f, 0.f};
             tg[i] = 0;
             if (b >= upper_end) continue;
@@ -374,14 +390,13 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
             else pend |= 1u << i;
         }
         if (!disjoint) {
-            for (int k = tid; k < H; k += THREADS) CLAIM[k] = 0xFFFFFFFFu;
             while (__syncthreads_or(pend != 0u)) {
 #pragma unroll
-                for (int i = 0; i < SPT; i++) if (pend & (1u << i)) atomicMin(&CLAIM[tg[i]], (unsigned)(tid + i * THREADS));
+                for (int i = 0; i < SPT; i++) if (pend & (1u << i)) atomicMin(&CLAIM[tg[i]], (unsigned)(tid + (bt * SPT + i) * THREADS));
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < SPT; i++) {
-                    if ((pend & (1u << i)) && CLAIM[tg[i]] == (unsigned)(tid + i * THREADS)) {
+                    if ((pend & (1u << i)) && CLAIM[tg[i]] == (unsigned)(tid + (bt * SPT + i) * THREADS)) {
                         const float2 o = B[tg[i]];
                         B[tg[i]] = float2{o.x + ys[i].x, o.y + ys[i].y};
                         CLAIM[tg[i]] = 0xFFFFFFFFu;                        // only the winner touches the word; losers re-post after the barrier
@@ -389,6 +404,7 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
                     }
                 }
             }
+        }
         }
         if (nonfinite && lane == 0) B[1 + wave] = float2{__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u)};
         __syncthreads();
@@ -447,11 +463,12 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
     pv_signal_done<true>(p.done, p.done_seq, (long)ch * gridDim.x + chunk);
 }
 
-template <int LOG2N, int THREADS>
+template <int LOG2N, int THREADS, int GM = 0>
 hipError_t launch_one(const PvKernelParams &p, int nch, int nchunks, size_t lds, hipStream_t st)
 {
     static std::atomic<bool> attr_done[16];
-    auto k = pv_chain_kernel<LOG2N, THREADS>;
+    auto k = pv_chain_kernel<LOG2N, THREADS, GM>;
+    if (GM && (p.gscratch == nullptr || p.gscratch_stride < pv_kernel_gscratch_bytes(LOG2N, p.hop))) return hipErrorInvalidValue;
     {
         const hipError_t e = pv_set_dynamic_lds_once(attr_done, reinterpret_cast<const void *>(k), 160 * 1024 - 512);   // __syncthreads_or keeps a few static bytes
         if (e != hipSuccess) return e;
@@ -466,14 +483,24 @@ int pv_kernel_threads(int log2n)
 {
     if (log2n <= 10) return 64;
     if (log2n == 11) return 128;
-    return 256;
+    return log2n <= 13 ? 256 : 512;
 }
 
 size_t pv_kernel_lds_bytes(int log2n, int hop)
 {
     const int N = 1 << log2n, M = N / 2, H = M + 1, L = N - hop;
     const int nwords = (H + 63) / 64;
+    if (log2n >= 15) return (size_t)nwords * 16;                                       // masks + nearest-peak words only
+    if (log2n == 14) return (size_t)16 * (M + 1) + (size_t)nwords * 16;                // + the fp64 buffer
     return (size_t)16 * (M + 1) + (size_t)8 * N + (size_t)4 * ((L + 1) & ~1) + (size_t)nwords * 16;
+}
+
+size_t pv_kernel_gscratch_bytes(int log2n, int hop)
+{
+    if (log2n < 14) return 0;
+    const size_t N = (size_t)1 << log2n, M = N / 2, L = N - (size_t)hop;
+    const size_t b = 8 * N + 4 * ((L + 1) & ~(size_t)1) + (log2n >= 15 ? 16 * (M + 1) : 0);
+    return (b + 255) & ~(size_t)255;
 }
 
 hipError_t pv_launch_chain(int log2n, const PvKernelParams &p, int nch, int nchunks, hipStream_t st)
@@ -488,6 +515,8 @@ hipError_t pv_launch_chain(int log2n, const PvKernelParams &p, int nch, int nchu
     case 11: return launch_one<11, 128>(p, nch, nchunks, lds, st);
     case 12: return launch_one<12, 256>(p, nch, nchunks, lds, st);
     case 13: return launch_one<13, 256>(p, nch, nchunks, lds, st);
+    case 14: return launch_one<14, 512, 1>(p, nch, nchunks, lds, st);
+    case 15: return launch_one<15, 512, 2>(p, nch, nchunks, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
