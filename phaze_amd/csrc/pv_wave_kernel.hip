@@ -664,13 +664,24 @@ __global__ __launch_bounds__(64 * (RESIDENT ? RES_WAVES : WAVES), RESIDENT ? 1 :
     long chain = (long)blockIdx.x * WGW + wv;
     bool listed = true;
     if (!RESIDENT && p.chain_list) {
+        // The waves of a workgroup take list entries a whole grid apart (wave w of workgroup b: entry w * gridDim.x + b), not twelve neighbours.  Neighbouring
+        // chains are neighbouring stretches of a stream and cost alike -- class-B frames come in clusters --, and a launch ends with its slowest chain: next to
+        // average chains on its SIMD a slow one inherits their issue slots when they finish; next to its equally slow neighbours it does not
+        // (profiles/r05_chain_times.md).
+#ifndef PV_CHAIN_BLOCKED
+        chain = (long)wv * gridDim.x + blockIdx.x;
+#endif
         const long total = (long)p.nch * p.nchunks;
         listed = chain < (long)p.chain_count[SPREAD ? 0 : 1];
         chain = listed ? (long)p.chain_list[(SPREAD ? 0 : total) + chain] : total;
     }
     const int ch = (int)(chain / p.nchunks), chunk = (int)(chain - (long)ch * p.nchunks);
 
+#ifndef PV_CHAIN_BLOCKED
+    if (!RESIDENT && p.chain_list && (long)blockIdx.x >= (long)p.chain_count[SPREAD ? 0 : 1]) return;           // no chain of this class left for the workgroup (uniform): not even the tables
+#else
     if (!RESIDENT && p.chain_list && (long)blockIdx.x * WGW >= (long)p.chain_count[SPREAD ? 0 : 1]) return;     // no chain of this class left for the workgroup (uniform): not even the tables
+#endif
     // ---- LDS carve (all dynamic, 16-byte aligned): shared tables, then one private region per wave ----
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const v4f *TW1F4 = reinterpret_cast<const v4f *>(smem_all + TAB_TW1F);
