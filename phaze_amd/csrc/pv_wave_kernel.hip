@@ -662,15 +662,15 @@ __global__ __launch_bounds__(64 * (RESIDENT ? RES_WAVES : WAVES), RESIDENT ? 1 :
     // batch launches: the chains of this instance's class come from the list pv_classify_chains compacted (p.chain_list: [0, nchains) the SPREAD class,
     // [nchains, 2 nchains) the other; p.chain_count[class] entries); a streaming quantum / the tap instance numbers its chains directly
     long chain = (long)blockIdx.x * WGW + wv;
+#ifndef PV_CHAIN_BLOCKED
+    if (!RESIDENT) chain = (long)wv * gridDim.x + blockIdx.x;              // (see below; with or without a list)
+#endif
     bool listed = true;
     if (!RESIDENT && p.chain_list) {
         // The waves of a workgroup take list entries a whole grid apart (wave w of workgroup b: entry w * gridDim.x + b), not twelve neighbours.  Neighbouring
         // chains are neighbouring stretches of a stream and cost alike -- class-B frames come in clusters --, and a launch ends with its slowest chain: next to
         // average chains on its SIMD a slow one inherits their issue slots when they finish; next to its equally slow neighbours it does not
         // (profiles/r05_chain_times.md).
-#ifndef PV_CHAIN_BLOCKED
-        chain = (long)wv * gridDim.x + blockIdx.x;
-#endif
         const long total = (long)p.nch * p.nchunks;
         listed = chain < (long)p.chain_count[SPREAD ? 0 : 1];
         chain = listed ? (long)p.chain_list[(SPREAD ? 0 : total) + chain] : total;
