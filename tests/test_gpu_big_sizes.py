@@ -58,6 +58,32 @@ def test_big_size_streams_through_process():
     assert S.rms(out.astype(np.float64) - yo) < REGRESSION_RMS
 
 
+def test_big_size_taps_match_the_oracle():
+    """The tap instance (pv_debug_frame) at N = 16384: fp64 forward spectrum, peak set and shifted spectrum of one frame against the oracle's."""
+    fft, hop = 16384, 4096
+    x = S.make_signal("tonal", 0, 6 * hop, stream=9)
+    pv = _pv(fft_size=fft, hop_size=hop, max_channels=1, max_hops=1)
+    o = oracle_lib.Oracle(fft, hop, 1)
+    H = fft // 2 + 1
+    for m in range(5):
+        blk = x[m * hop:(m + 1) * hop]
+        got = pv.debug_frame(0, blk, 0.8)
+        o.process([blk], 0.8)
+        ref = o.debug()
+        Xr = ref["X"][0::2] + 1j * ref["X"][1::2]
+        Xg = got["X"][0::2] + 1j * got["X"][1::2]
+        scale = np.max(np.abs(Xr[:H]))
+        assert np.max(np.abs(Xg[:H] - Xr[:H])) < 1e-12 * scale
+        assert np.array_equal(np.nonzero(got["flags"])[0], ref["peaks"])
+        Yr = ref["Y"][0:2 * H:2] + 1j * ref["Y"][1:2 * H:2]
+        Yg = got["Y"][0::2] + 1j * got["Y"][1::2]
+        assert np.max(np.abs(Yg[1:-1] - Yr[1:H - 1])) < 2e-6 * scale
+        out = [[np.zeros(hop, np.float32)]]
+        pv.process([[blk]], out, {"pitchFactor": np.array([0.8], np.float32)})
+    pv.close()
+    o.close()
+
+
 def test_sizes_beyond_the_kernels_are_refused():
     import phaze_amd
     with pytest.raises(phaze_amd.PvError):
