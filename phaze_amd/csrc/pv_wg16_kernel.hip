@@ -472,11 +472,22 @@ __device__ __forceinline__ int digitrev4_16(int v, int nd)
 template <int LOG2N, int R_>
 __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(const float *in, const float *hist, int hist_len, bool sys, long s0, const float *__restrict__ hann,
                                                                                const float2 *__restrict__ tw32, int t, int upper_end, int up_delta, unsigned up_ridx,
-                                                                               double *dbg_X, bool plain)
+                                                                               double *dbg_X, bool plain
+#ifdef PV_WG16_PH
+                                                                               , unsigned *ph_row
+#endif
+                                                                               )
 {
     using C = QC<LOG2N>;
     constexpr int N = C::N, H = C::H, T = C::T, QN = N / 4;
     constexpr bool BASE4 = (LOG2N % 2) == 0;
+#ifdef PV_WG16_PH
+    unsigned ph_prev = W16Clock::now();
+    auto ph_mark = [&](int k) { const unsigned n = W16Clock::now(); if (t == 0 && ph_row) atomicAdd(&ph_row[22 + k], n - ph_prev); ph_prev = n; };
+#define RES_MARK(k) ph_mark(k)
+#else
+#define RES_MARK(k)
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *Y = reinterpret_cast<float2 *>(smem + C::OFF_Y);
     unsigned *CLAIM = reinterpret_cast<unsigned *>(smem + C::OFF_ROUTE);
@@ -518,14 +529,19 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(co
             }
         }
         __syncthreads();
+        RES_MARK(0);
         constexpr int LOG2BASE = BASE4 ? 2 : 1;
+        // (round 5: the block / index split of an item is a shift and a mask instead of a division by a run-time power of two -- a stage is ~1-2 butterflies per thread
+        //  and is bound by the instructions around them, profiles/r05_wg16_phase_clock.md.  Unrolling the stages makes their sizes constants, but the function then needs
+        //  more registers than the kernel that calls it: the kernel's occupancy follows its callees')
+#pragma unroll 1
         for (int log2m = LOG2BASE + 2; log2m <= LOG2N - 2; log2m += 2) {  // block sizes 4 * base .. N/4 inside the quarter
             const int q = (1 << log2m) >> 2, hq = q >> 1;
             const int nblocks = QN >> log2m;
             const int tws = LOG2N - log2m;
             for (int u = t; u < nblocks * (hq + 1); u += T) {
                 int blk, i;
-                if (u < nblocks * hq) { blk = u / hq; i = u - blk * hq; } else { blk = u - nblocks * hq; i = hq; }
+                if (u < nblocks * hq) { blk = u >> (log2m - 3); i = u & (hq - 1); } else { blk = u - nblocks * hq; i = hq; }
                 const int o = blk << log2m;
                 const float2 A = Q[o + i];
                 const float2 w1 = tw32[i << tws];
@@ -544,6 +560,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(co
                 }
             }
             __syncthreads();
+            RES_MARK(1 + (log2m - LOG2BASE - 2) / 2);
         }
         if (dbg_X)
             for (int i = t; i < QN; i += T) if (base + i >= H) { dbg_X[2 * (base + i)] = Q[i].x; dbg_X[2 * (base + i) + 1] = Q[i].y; }
@@ -564,6 +581,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16(co
             claim_rounds_wg16<8, H>(rt, ys, id, Y, CLAIM);
         }
         __syncthreads();
+        RES_MARK(7);
     }
 }
 
@@ -1191,7 +1209,11 @@ resident_top:
                     __syncthreads();
                     const int up_delta = last_shift;
                     residue_scatter_wg16<LOG2N, R>(src.in, src.hist, src.hist_len, src.sys, (long)(m + 1) * HOP - N, p.hann, p.tw32, tq, upper_end, up_delta,
-                                            (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1), dbg ? p.dbg_X : nullptr, pairwise);
+                                            (unsigned)((up_delta & (N - 1)) * tmod) & (N - 1), dbg ? p.dbg_X : nullptr, pairwise
+#ifdef PV_WG16_PH
+                                            , p.stamps ? p.stamps + 32 * ((long)ch * gridDim.x + chunk) : nullptr
+#endif
+                                            );
                 }
             }
         }

@@ -32,3 +32,6 @@ names = ["fwd: window, pack, pass A (radix 16 + 15 twiddles, fp64)", "fwd: excha
 print(f"pv_wg16_kernel {shape} ({fft}/{hop}, {nch} ch x {T} hops), pitch {arg}: {int(ok.sum())} workgroups x {int(fr.max())} frames; shader-clock ticks per frame (wave 0): {a.sum():.0f}")
 for nme, v in zip(names, a):
     if nme: print(f"  {v:8.0f}  {100 * v / a.sum():5.1f} %  {nme}")
+r = (buf[ok, 22:30].astype(np.float64) / fr[ok, None]).mean(0)
+if r.sum() > 0:
+    print("  inside the general residue (ticks per frame, averaged over ALL frames): base blocks + barrier", f"{r[0]:.0f}", "| stages", " ".join(f"{v:.0f}" for v in r[1:7]), "| gather + scatter + barrier", f"{r[7]:.0f}", "| sum", f"{r.sum():.0f}")
