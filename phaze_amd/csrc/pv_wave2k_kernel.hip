@@ -28,7 +28,8 @@
 #include "pv_device_common.h"
 #include "pv_pk_math.h"
 #ifndef PV_PT
-#define PV_PT 1, 0, 1, 2, 2, 2, 2, 2, 0, 0, 0, 2     // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C3 3.76 -> 3.31 ms)
+#define PV_PT 1, 0, 1, 2, 3, 2, 3, 3, 0, 0, 0, 2     // phase priorities of this kernel (pv_wave_fft.h; profiles/r03_priority_sweep.md: C3 3.76 -> 3.31 ms; re-swept in round 5 on the
+                                                     // fp32-first kernel: split arithmetic, scatter and c2r pass at level 3 -- C3 3.024 -> 2.991 ms, 2048/128 at f = 0.8 3.189 -> 3.141)
 #endif
 #include "pv_wave_fft.h"
 #include "pv_guard.h"
