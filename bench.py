@@ -33,8 +33,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
-DTYPE = "f32+f64"           # forward FFT in f32 first, re-run in f64 for the frames where a peak decision is within the f32 transform's error (N = 1024; the other
-                            # sizes: f64 forward); shift / inverse FFT / overlap-add in f32, I/O f32
+DTYPE = "f32+f64"           # forward FFT in f32 first, re-run in f64 for the frames where a peak decision is within the f32 transform's error (N = 1024 and N = 2048:
+                            # pv_wave_kernel_1024, pv_wave2k_kernel; N >= 4096: f64 forward); shift / inverse FFT / overlap-add in f32, I/O f32
+LINE_BUDGET = 7000          # bytes: the driver keeps the last 8 KB of stdout; the ONE line must fit with room to spare (round-5 verdict, item 5).  What the short ids
+                            # ("C3", "C4-share", ...) stand for is spelled out in profiles/bench_workloads.md; the unabridged record of a run goes to bench_detail.json
 
 
 def synth_input(torch, nch, nsamples, device, seed):
@@ -123,16 +125,26 @@ def cpu_baseline(fft, hop, pitch, x_prefix, what, target_seconds=12.0):
 
 
 def other_input(torch, kind, nch, nsamples, device, seed):
-    """The signal classes next to synth_input that bound the fp32-first forward transform from both sides: white noise (nothing falls back) and
-    two clean partials over a -80 dB floor (every frame falls back) -- tools/study_fp32_decisions.py's classes."""
+    """The signal classes next to synth_input that bound the fp32-first forward transform: white noise (nothing falls back), two clean partials over a -80 / -60 dB
+    floor (every / most frames fall back), 16-bit quantised material ("q16": two partials + dither rounded to 1/32768) and digital silence -- tools/flip_count.py's classes."""
     g = torch.Generator(device=device)
     g.manual_seed(4321 + seed)
+    pi2 = 2 * 3.14159265358979
     if kind == "white":
         return (torch.rand((nch, nsamples), device=device, generator=g) - 0.5).float()
+    if kind == "silence":
+        return torch.zeros((nch, nsamples), device=device, dtype=torch.float32)
     i = torch.arange(nsamples, device=device, dtype=torch.float64)[None, :]
-    x = (0.5 * torch.sin(2 * 3.14159265358979 * i * 0.0123) + 0.3 * torch.sin(2 * 3.14159265358979 * i * 0.0931)).float().expand(nch, nsamples).clone()
-    x += (torch.rand((nch, nsamples), device=device, generator=g) * 2 - 1) * 1e-4
-    return x
+    if kind == "q16":
+        x = (0.4 * torch.sin(pi2 * i * 0.031) + 0.2 * torch.sin(pi2 * i * 0.177)).float().expand(nch, nsamples).clone()
+        x += (torch.rand((nch, nsamples), device=device, generator=g) - 0.5) / 32768
+        return torch.round(x * 32768) / 32768
+    if kind.startswith("tonal"):
+        amp = 10.0 ** (-float(kind[5:]) / 20.0)
+        x = (0.5 * torch.sin(pi2 * i * 0.0123) + 0.3 * torch.sin(pi2 * i * 0.0931)).float().expand(nch, nsamples).clone()
+        x += (torch.rand((nch, nsamples), device=device, generator=g) * 2 - 1) * amp
+        return x
+    raise ValueError(kind)
 
 
 def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmup, label, local_rank, frames_per_chunk=0,
@@ -408,6 +420,10 @@ def latency_histogram(phaze_amd, fft, hop, nch, calls, local_rank, sweep, flags=
                        "(one launch per quantum, completion words in pinned memory)"), "realtime_budget_us": hop / fs * 1e6}
 
 
+def r4_(v):
+    return None if v is None else float(f"{v:.4g}")
+
+
 def spawn_ranks(args, n):
     """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run (one process per GPU)."""
     import socket
@@ -543,52 +559,59 @@ def main():
 
     info = head["info"]
     value = shard.aggregate_rate(head["frames_per_step_rank"] * args.steps, world, head["elapsed"])
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            ent = tj.get(f"{fft}/{hop}/ch{nch}/hops{T}")
-            if ent and ent.get("csrc_sha16") == csrc_sha16():
-                traffic = ent["bytes_per_launch"]
-                traffic_src = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, measured on this build of the kernels)"
-            elif ent:
-                traffic_src = "profiles/hbm_traffic.json holds a figure for an OLDER build of the kernels: not reported"
-        except Exception:
-            traffic = None
+    sha = csrc_sha16()
 
-    out = None
+    def stamped(fname, key):
+        """An entry of a profiles/*.json side file, only while it was measured on THIS build of the kernels (csrc_sha16 stamp)."""
+        try:
+            ent = json.load(open(os.path.join(ROOT, "profiles", fname))).get(key)
+            return ent if ent and ent.get("csrc_sha16") == sha else None
+        except Exception:
+            return None
+    shape_key = f"{fft}/{hop}/ch{nch}/hops{T}"
+    tent = stamped("hbm_traffic.json", shape_key)
+    traffic = tent["bytes_per_launch"] if tent else None
+
+    out = detail = None
     if rank == 0:
-        chs = "mono" if nch == 1 else "stereo" if nch == 2 else f"{nch}-ch"
-        is_c1 = (fft, hop, nch) == (1024, 256, 1) and not args.pitch_sweep and abs(args.pitch - 1.5) < 1e-9
+        is_c2 = (fft, hop, nch) == (1024, 256, 1) and not args.pitch_sweep and abs(args.pitch - 1.5) < 1e-9
+        wl = "C2" if is_c2 else f"{nch}ch-{fft}/{hop}-f{args.pitch if not args.pitch_sweep else 'sweep'}"
+        kms = head["regions_kernel_ms"]
+        # the device-copy ceiling of THIS box, measured in this run (SURVEY 8d: "quote the measured copy BW beside" the 8 TB/s peak): a 1 GiB device-to-device
+        # copy kernel (torch copy_), read + write bytes over HIP-event time, best of five
+        copy_gbs = None
+        if world == 1:
+            a = torch.empty(1 << 28, dtype=torch.float32, device=dev); b2 = torch.empty_like(a)
+            b2.copy_(a); torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); b2.copy_(a); e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            copy_gbs = 2 * a.numel() * 4 / (best * 1e-3) / 1e9
+            del a, b2
         out = {
             "metric": "stft_frames_per_sec_1024pt_hop256_48k" if (fft, hop) == (1024, 256) else f"stft_frames_per_sec_{fft}pt_hop{hop}",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": DTYPE,
-            "dtype_note": "N = 1024: forward FFT in packed f32 FIRST, peak decisions on its magnitudes where every comparison lies outside a guard band around the f32 transform's "
-                          "error (10 eps max|X|), else the frame's forward FFT again in f64 (fallback_rate; decisions are the reference's either way: 0 uncaught flips in "
-                          "4.7e7 doubly-computed frames, profiles/r05_flip_count.json); PV_FLAG_FP64_FORWARD = every forward FFT in f64 (the round-4 arithmetic, `configs`); "
-                          "other sizes: f64 forward; shift / inverse FFT / overlap-add in f32, I/O f32",
-            "fallback_rate": head["fallback_rate"],
-            "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: " if is_c1 else "") + f"{chs} 48 kHz FFT={fft} hop={hop} pitchFactor={args.pitch}, throughput mode, "
-                                   f"{nch} resident channel(s) x {T} hops per GPU per step",
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": wl + (": BASELINE configs[1], mono 48 kHz 1024/256 pf 1.5, 1 ch x 2^20 hops resident" if is_c2 and T == 1 << 20 else ""),
                        "fft": fft, "hop": hop, "channels": nch, "hops_per_step": T, "pitch_factor": args.pitch,
-                       "frames_per_chunk": info["frames_per_chunk"], "threads_per_workgroup": info["threads_per_workgroup"],
-                       "lds_bytes_per_workgroup": info["lds_bytes_per_workgroup"], "parallelism": f"streams x{world} (independent, no collective)",
-                       "device": info["device_name"]},
+                       "frames_per_chunk": info["frames_per_chunk"], "parallelism": f"streams x{world}, no collective", "device": info["device_name"][:40]},
             "roofline": {"bound": "hbm", "achieved": head["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["achieved_gbs"] / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": info["kernel_name"], "kernel_ms": head["kernel_ms"],
-                         "algorithmic_bytes_per_launch": head["alg_bytes"], "traffic_source": traffic_src,
-                         "note": "algorithmic bytes = 2*hop*4 B per channel-frame; the kernel is bound by VALU issue, not by HBM (DESIGN.md section 4)"},
-            "parity_rms_vs_oracle": head["parity"],
-            "timed_regions": {"count": len(head["regions_kernel_ms"]), "steps_each": args.steps, "reported": "median region",
-                              "ms_per_step": head["regions_ms_per_step"], "kernel_ms": head["regions_kernel_ms"],
-                              "kernel_ms_min": min(head["regions_kernel_ms"]), "kernel_ms_median": sorted(head["regions_kernel_ms"])[len(head["regions_kernel_ms"]) // 2],
-                              "kernel_ms_max": max(head["regions_kernel_ms"]),
-                              "ms_per_step_min": min(head["regions_ms_per_step"]), "ms_per_step_max": max(head["regions_ms_per_step"])},
+                         "traffic": traffic, "kernel": info["kernel_name"], "kernel_ms": head["kernel_ms"], "kernel_ms_min": min(kms), "kernel_ms_max": max(kms),
+                         "algorithmic_bytes_per_launch": head["alg_bytes"], "copy_gbs_measured": copy_gbs,
+                         "frac_of_measured_copy": (head["achieved_gbs"] / copy_gbs) if copy_gbs else None,
+                         "note": "bound by VALU issue, not HBM: see roofline_valu"},
+            "parity_rms_vs_oracle": head["parity"], "fallback_rate": head["fallback_rate"],
         }
+        # what actually binds (round-5 verdict, item 5c): VALU issue cycles of the dominant kernel over the SIMD cycles of its launch, from the PMC pass of
+        # profiles/run_profile_r06.sh (profiles/valu_issue.json, stamped with the hash of the kernel sources like hbm_traffic.json)
+        vent = stamped("valu_issue.json", shape_key)
+        out["roofline_valu"] = ({"bound": "valu_issue", "frac": vent["frac"], "valu_insts_per_frame": vent["valu_insts_per_frame"], "wait_any_frac": vent.get("wait_any_frac"),
+                                 "src": "profiles/valu_issue.json"} if vent else None)
+        cent = stamped("chain_tail.json", shape_key)          # slowest chain of the launch over the mean chain (stamps build, tools/chain_times.py)
+        out["tail_over_mean"] = cent["max_over_mean"] if cent else None
         distinct = min(world, ndev)                                      # LOCAL_RANK % ndev: more ranks than visible devices share them
         if requested != world or distinct != world:
             out["n_gpus"] = distinct
@@ -597,7 +620,7 @@ def main():
             out["ranks"] = world
             out["note_gpus"] = (f"{max(requested, world)} GPUs requested, {ndev} visible: {distinct} replica(s) measured"
                                 + (f" ({world} ranks share them: `value` is what those devices delivered together, NOT a {world}-GPU rate)" if distinct != world else "")
-                                + "; streams are independent shards with no inter-GPU dependency (SURVEY 8e), nothing is extrapolated; no scaling curve was measured")
+                                + "; independent shards, nothing extrapolated; no scaling curve was measured")
         if os.environ.get("PHAZE_LIB"):
             out["lib_override"] = os.environ["PHAZE_LIB"]
         if sg_ms is not None:
@@ -606,100 +629,95 @@ def main():
                                      "round_trip_intact": sg_ok, "rank0_streams": sg_mine}
         if dist is not None:
             out["dist_backend"] = dist.get_backend()          # "nccl" = RCCL on ROCm: barrier, all_reduce(MAX) of the timing, scatter / gather
+        detail = dict(out)
+        detail["timed_regions"] = {"count": len(kms), "steps_each": args.steps, "reported": "median region", "ms_per_step": head["regions_ms_per_step"], "kernel_ms": kms}
+        detail["csrc_sha16"] = sha
 
     if world == 1 and not args.no_extras:
-        # ---- the other BASELINE configs, each a short measured line (same harness, same timing method) ----
-        extras = []
-        def add(label, workload, f2, h2, c2, T2, pt, steps=8, warm=3, **kw):
-            r = measure(torch, phaze_amd, dev, None, f2, h2, c2, T2, pt, steps, warm, label, local_rank, parity_hops=12, **kw)
-            extras.append({"workload": workload, "value": r["frames_per_step_rank"] * steps / r["elapsed"], "unit": "frames/s", "steps": steps, "warmup": warm,
-                           "ms_per_step": r["elapsed"] / steps * 1e3, "kernel_ms": r["kernel_ms"], "kernel": r["info"]["kernel_name"],
-                           "roofline_frac": r["achieved_gbs"] / HBM_PEAK_GBS, "parity_rms_vs_oracle": r["parity"],
-                           "frames_per_chunk": r["info"]["frames_per_chunk"], "fallback_rate": r["fallback_rate"]})
-        T3 = 1 << 18
-        add("C3", f"BASELINE configs[2]: stereo 48 kHz FFT=2048 hop=512 pitchFactor=f32(0.8), 2 ch x {T3} hops resident", 2048, 512, 2, T3,
-            torch.full((T3,), 0.8, device=dev, dtype=torch.float32))
-        add("C4", "BASELINE configs[3], one GPU's share: 8-ch 48 kHz FFT=4096 hop=1024, 128 streams x 8 ch = 1024 channel slots x 64 hops, pitchFactor=1.25",
-            4096, 1024, 1024, 64, torch.full((64,), 1.25, device=dev, dtype=torch.float32), steps=40, warm=10, ch_per_stream=8)   # 1 ms launches: as many steps as the headline
-        T5 = 1 << 14
-        sweep = (0.5 + 1.5 * (torch.arange(T5, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
-        add("C5", f"BASELINE configs[4]: 8-ch 96 kHz FFT=8192 hop=2048, pitchFactor swept 0.5->2.0 per hop (period 64 hops), 8 ch x {T5} hops resident",
-            8192, 2048, 8, T5, sweep)
-        T8 = 1 << 17
-        add("8ch", f"8-ch 48 kHz FFT=1024 hop=256 pitchFactor=1.5 (the target's phrasing), 8 ch x {T8} hops resident", 1024, 256, 8, T8,
-            torch.full((T8,), 1.5, device=dev, dtype=torch.float32), steps=40, warm=10)   # as many steps as the headline: at 8 steps the fixed cost of a timed region
-                                                                                         # (two synchronizes, two events: ~1 ms of wall clock) read as a 5-8 % "gap" to mono
-                                                                                         # in rounds 3-4; by HIP events the two launches differ by 0.7 % (tools/stride_probe.py)
-        add("native", f"the reference's shipped configuration (phase-vocoder.js:6, ola-processor.js:3): stereo 48 kHz FFT=2048 hop=128 (16 overlaps), "
-            f"pitchFactor=1.0, 2 ch x {T3} hops resident", 2048, 128, 2, T3, torch.full((T3,), 1.0, device=dev, dtype=torch.float32))
-        # the unfavourable half of the reference's parameter range (sliders give f in [0.33, 3], www/index.html:23,28): f < 1 compresses the
-        # regions, the scatter collides (pv:169-170) and the last region reads above Nyquist
-        T2 = 1 << 20
-        add("f0.8", f"headline shape at pitchFactor=f32(0.8): mono 48 kHz FFT=1024 hop=256, 1 ch x {T2} hops resident", 1024, 256, 1, T2,
-            torch.full((T2,), 0.8, device=dev, dtype=torch.float32), steps=24, warm=6)
-        sw = (0.5 + 1.5 * (torch.arange(T2, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
-        add("sweep", f"headline shape with pitchFactor swept 0.5->2.0 per hop (period 64 hops): mono 48 kHz FFT=1024 hop=256, 1 ch x {T2} hops resident",
-            1024, 256, 1, T2, sw, steps=24, warm=6)
-        # ---- the fp32-first forward transform from both sides (round 5): the same launch with every forward FFT in f64 (PV_FLAG_FP64_FORWARD: the round-4 kernels), on white
-        #      noise (no frame falls back) and on two clean partials over a -80 dB floor (EVERY frame falls back: the worst case) ----
-        p15 = torch.full((T2,), 1.5, device=dev, dtype=torch.float32)
-        add("fwd64", f"headline shape with PV_FLAG_FP64_FORWARD (every forward FFT in f64: the round-4 arithmetic): mono 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 1 ch x {T2} hops resident",
-            1024, 256, 1, T2, p15, steps=24, warm=6, flags=phaze_amd.FLAG_FP64_FORWARD)
-        add("white", f"headline shape on WHITE NOISE (uniform, amplitude 0.5): mono 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 1 ch x {T2} hops resident",
-            1024, 256, 1, T2, p15, steps=24, warm=6, signal="white")
-        add("tonal80", f"headline shape on TWO CLEAN PARTIALS over a -80 dB noise floor (worst case of the fp32-first forward transform: every frame re-runs it in f64): "
-            f"mono 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 1 ch x {T2} hops resident", 1024, 256, 1, T2, p15, steps=24, warm=6, signal="tonal80")
-        add("tonal80_fwd64", "the same signal with PV_FLAG_FP64_FORWARD", 1024, 256, 1, T2, p15, steps=24, warm=6, signal="tonal80", flags=phaze_amd.FLAG_FP64_FORWARD)
-        # ---- the reference-width flavour of the headline kernel (never the product; build/exp/libphaze_fp64.so, `make -C phaze_amd/csrc fp64`): shifted spectrum,
-        #      scatter, residue, c2r pass and inverse FFT in fp64 like the reference's JS doubles.  A library is chosen at import time, so it runs in a child ----
+        # ---- the other configurations, each a short measured entry (same harness, same timing method).  Ids: profiles/bench_workloads.md.
+        #      BASELINE's product configurations first, then the unfavourable parameter range, then flavours / signal classes ----
+        extras, extras_full = [], []
+        r4 = lambda v: None if v is None else float(f"{v:.4g}")
+        def add(cid, f2, h2, c2, T2, pt, steps=8, warm=3, **kw):
+            r = measure(torch, phaze_amd, dev, None, f2, h2, c2, T2, pt, steps, warm, cid, local_rank, parity_hops=12, **kw)
+            e = {"id": cid, "v": r4(r["frames_per_step_rank"] * steps / r["elapsed"]), "frac": r4(r["achieved_gbs"] / HBM_PEAK_GBS), "ms": r4(r["kernel_ms"]), "par": r4(r["parity"])}
+            if r["fallback_rate"] is not None:
+                e["fb"] = r4(r["fallback_rate"])
+            extras.append(e)
+            extras_full.append(dict(e, kernel=r["info"]["kernel_name"], steps=steps, warmup=warm, ms_per_step=r["elapsed"] / steps * 1e3, frames_per_chunk=r["info"]["frames_per_chunk"],
+                                    fft=f2, hop=h2, channels=c2, hops=T2))
+        full = lambda n, v: torch.full((n,), v, device=dev, dtype=torch.float32)
+        swp = lambda n: (0.5 + 1.5 * (torch.arange(n, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
+        T3, T5, T8, T2 = 1 << 18, 1 << 14, 1 << 17, 1 << 20
+        add("C3", 2048, 512, 2, T3, full(T3, 0.8))
+        add("C4-share", 4096, 1024, 1024, 64, full(64, 1.25), steps=40, warm=10, ch_per_stream=8)   # 1 ms launches: as many steps as the headline
+        add("C5-sweep", 8192, 2048, 8, T5, swp(T5))
+        add("C5-f1.5", 8192, 2048, 8, T5, full(T5, 1.5))
+        add("8ch-1024", 1024, 256, 8, T8, full(T8, 1.5), steps=40, warm=10)    # (as many steps as the headline: the fixed cost of a timed region read as a "gap" to mono in rounds 3-4)
+        add("native", 2048, 128, 2, T3, full(T3, 1.0))
+        add("C2-f0.8", 1024, 256, 1, T2, full(T2, 0.8), steps=24, warm=6)
+        add("C2-sweep", 1024, 256, 1, T2, swp(T2), steps=24, warm=6)
+        add("C3-f1.5", 2048, 512, 2, T3, full(T3, 1.5))
+        add("C5-f0.6", 8192, 2048, 8, T5, full(T5, 0.6))
+        add("N16384", 16384, 4096, 8, 1 << 11, full(1 << 11, 1.5), steps=4, warm=1)     # complete, not tuned (generic kernel with a device-memory scratch): one timing
+        # the fp32-first forward transform from every side: PV_FLAG_FP64_FORWARD (the round-4 arithmetic) and the signal classes that bound it
+        p15 = full(T2, 1.5)
+        add("C2-fwd64", 1024, 256, 1, T2, p15, steps=24, warm=6, flags=phaze_amd.FLAG_FP64_FORWARD)
+        for sig in ("white", "tonal80", "tonal60", "q16", "silence"):
+            add("C2-" + sig, 1024, 256, 1, T2, p15, steps=16, warm=4, signal=sig)
+            if sig != "white":
+                add("C2-" + sig + "-fwd64", 1024, 256, 1, T2, p15, steps=16, warm=4, signal=sig, flags=phaze_amd.FLAG_FP64_FORWARD)
+        add("C3-tonal80", 2048, 512, 2, T3, full(T3, 0.8), signal="tonal80")
+        add("C3-tonal80-fwd64", 2048, 512, 2, T3, full(T3, 0.8), signal="tonal80", flags=phaze_amd.FLAG_FP64_FORWARD)
+        # ---- the reference-width flavour (never the product; build/exp/libphaze_fp64.so, `make -C phaze_amd/csrc fp64`): shifted spectrum, scatter, residue, c2r pass
+        #      and inverse FFT in fp64 like the reference's JS doubles.  A library is chosen at import time, so it runs in a child ----
         flib = os.path.join(ROOT, "build", "exp", "libphaze_fp64.so")
         if os.path.exists(flib) and not os.environ.get("PHAZE_LIB"):
-            # (round 5: pv_wg16_kernel has the flavour too, and the flavour takes N = 2048 as well -- C3's, C4's and C5's shapes in reference-width arithmetic, verdict r04 "missing" 3)
-            for shape, lab, fargs in (("headline shape", "mono 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 1 ch x 1048576 hops resident", ["--pitch", "1.5"]),
-                                      ("headline shape", "mono 48 kHz FFT=1024 hop=256 pitchFactor=f32(0.8), 1 ch x 1048576 hops resident", ["--pitch", "0.8"]),
-                                      ("BASELINE configs[2]'s shape", "stereo 48 kHz FFT=2048 hop=512 pitchFactor=f32(0.8), 2 ch x 262144 hops resident",
-                                       ["--fft", "2048", "--hop", "512", "--channels", "2", "--hops", "262144", "--pitch", "0.8"]),
-                                      ("BASELINE configs[3]'s shape (one GPU's share)", "8-ch 48 kHz FFT=4096 hop=1024 pitchFactor=1.25, 1024 channel slots x 64 hops resident",
-                                       ["--fft", "4096", "--hop", "1024", "--channels", "1024", "--hops", "64", "--pitch", "1.25"]),
-                                      ("BASELINE configs[4]'s shape", "8-ch 96 kHz FFT=8192 hop=2048 pitchFactor swept 0.5->2.0 per hop, 8 ch x 16384 hops resident",
-                                       ["--fft", "8192", "--hop", "2048", "--channels", "8", "--hops", "16384", "--pitch-sweep"]),
-                                      ("BASELINE configs[4]'s shape", "8-ch 96 kHz FFT=8192 hop=2048 pitchFactor=1.5, 8 ch x 16384 hops resident",
-                                       ["--fft", "8192", "--hop", "2048", "--channels", "8", "--hops", "16384", "--pitch", "1.5"])):
+            for cid, fargs in (("C2-f64", ["--pitch", "1.5"]), ("C2-f0.8-f64", ["--pitch", "0.8"]),
+                               ("C3-f64", ["--fft", "2048", "--hop", "512", "--channels", "2", "--hops", "262144", "--pitch", "0.8"]),
+                               ("C4-share-f64", ["--fft", "4096", "--hop", "1024", "--channels", "1024", "--hops", "64", "--pitch", "1.25"]),
+                               ("C5-sweep-f64", ["--fft", "8192", "--hop", "2048", "--channels", "8", "--hops", "16384", "--pitch-sweep"]),
+                               ("C5-f1.5-f64", ["--fft", "8192", "--hop", "2048", "--channels", "8", "--hops", "16384", "--pitch", "1.5"])):
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--allow-lib-override", "--steps", "10", "--warmup", "3",
                                     "--repeats", "3"] + fargs, capture_output=True, text=True, timeout=600, env=dict(os.environ, PHAZE_LIB=flib))
                 try:
                     fj = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-                    extras.append({"workload": f"{shape} in reference-width arithmetic (fp64 end to end: forward FFT, shift, residue, c2r, inverse FFT; fp32 only where the "
-                                               f"reference rounds to Float32Array): {lab} -- the all-fp64 FLAVOUR (build/exp/libphaze_fp64.so), not the product",
-                                   "dtype": "f64", "value": fj["value"], "unit": "frames/s", "steps": fj["steps"], "warmup": fj["warmup"], "ms_per_step": fj["ms_per_step"],
-                                   "kernel_ms": fj["roofline"]["kernel_ms"], "kernel": fj["roofline"]["kernel"], "roofline_frac": fj["roofline"]["frac"],
-                                   "parity_rms_vs_oracle": fj["parity_rms_vs_oracle"], "lib": "build/exp/libphaze_fp64.so"})
-                except Exception as e:
-                    extras.append({"workload": f"{shape} in reference-width arithmetic (fp64 end to end): {lab}", "dtype": "f64", "error": f"{e}: {(r.stderr or r.stdout)[-300:]}"})
+                    e = {"id": cid, "v": r4(fj["value"]), "frac": r4(fj["roofline"]["frac"]), "ms": r4(fj["roofline"]["kernel_ms"]), "par": r4(fj["parity_rms_vs_oracle"])}
+                    extras.append(e)
+                    extras_full.append(dict(e, dtype="f64", kernel=fj["roofline"]["kernel"], lib="build/exp/libphaze_fp64.so", steps=fj["steps"], ms_per_step=fj["ms_per_step"]))
+                except Exception as ex:
+                    extras.append({"id": cid, "err": f"{ex}"[:60]})
+                    extras_full.append({"id": cid, "error": f"{ex}: {(r.stderr or r.stdout)[-300:]}"})
         out["configs"] = extras
-        # ---- the product boundary with HOST pointers (round-3 verdict, Weak 4): what a Node / C caller that owns host memory gets, PCIe included.
-        #      Never `value`; each line carries the fraction of this box's pinned hipMemcpy bandwidth (both directions busy) it reaches. ----
+        detail["configs"] = extras_full
+        # ---- the product boundary with HOST pointers: what a Node / C caller that owns host memory gets, PCIe included.  Never `value`; each entry carries the
+        #      fraction of this box's best pinned hipMemcpy rate it reaches ----
         bw = pcie_bandwidth(torch, dev)
         hb = []
         rows4 = np.stack([np.full(64, 1.25, np.float32) for _ in range(128)])
-        hb.append(host_batch(torch, phaze_amd, dev, 4096, 1024, 1024, 64, 8, rows4, 5, local_rank, bw,
-                             "BASELINE configs[3], one GPU's share through pv_process_batch (host pointers): 128 streams x 8 ch, FFT=4096 hop=1024, 64 hops per call, pitchFactor 1.25"))
-        hb.append(host_batch(torch, phaze_amd, dev, 1024, 256, 8, 1 << 15, 8, np.full((1, 1 << 15), 1.5, np.float32), 5, local_rank, bw,
-                             f"headline shape through pv_process_batch (host pointers): 8-ch 48 kHz FFT=1024 hop=256 pitchFactor=1.5, 8 ch x {1 << 15} hops per call"))
+        hb.append(host_batch(torch, phaze_amd, dev, 4096, 1024, 1024, 64, 8, rows4, 5, local_rank, bw, "C4-share-host"))
+        hb.append(host_batch(torch, phaze_amd, dev, 1024, 256, 8, 1 << 15, 8, np.full((1, 1 << 15), 1.5, np.float32), 5, local_rank, bw, "8ch-1024-host"))
         nl = node_sharded_line(bw, 128, 8, 4096, 1024, 64, 5)
         if nl:
+            nl["workload"] = "C4-share-node"
             hb.append(nl)
-        out["host_buffer_configs"] = hb
-        out["latency_us"] = latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True)
-        out["latency_us_resident"] = latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True, flags=32)   # the same stream on the resident kernel (PV_FLAG_PERSISTENT_STREAM)
-        # the headline shape as a stream: launch per quantum, and on the resident kernel (opt-in flag of the C ABI / `processorOptions.flags` in Node)
-        out["latency_us_headline_shape"] = {"launch": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, fs=48000.0),
-                                            "resident": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, flags=32, fs=48000.0)}
+        detail["host_buffer_configs"] = hb
+        out["host"] = [{"id": h["workload"], "v": r4(h.get("value")), "gbs_each_way": r4(h.get("gbytes_per_s_each_way")), "pcie_frac": r4(h.get("pcie_frac")),
+                        **({"bit_equal": h["bit_equal_to_resident_form"]} if "bit_equal_to_resident_form" in h else {}), **({"err": h["error"][:60]} if "error" in h else {})} for h in hb]
+        out["pcie_pinned_gbs"] = r4(bw["reference"])
+        lat = {"C5-launch": latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True),
+               "C5-resident": latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True, flags=32),   # PV_FLAG_PERSISTENT_STREAM
+               "C2-launch": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, fs=48000.0),
+               "C2-resident": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, flags=32, fs=48000.0)}
+        detail["latency_us"] = lat
+        out["latency_us"] = {k: {"p50": r4(v["p50"]), "p99": r4(v["p99"]), "budget": r4(v["realtime_budget_us"])} for k, v in lat.items()}
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(fft, hop, args.pitch_num, head["x_prefix"],
-                                               f"the bench input (synth_input seed 0: three partials + a -36 dB noise floor, {nch} ch x {T} hops)")
+            cb = cpu_baseline(fft, hop, args.pitch_num, head["x_prefix"], "the bench input")
+            detail["cpu_baseline"] = cb
+            out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": 1, "kind": "port", "sample": cb["sample"][:110], "host_cpus": cb["host_cpus"],
+                                   "cpu_model": cb["cpu_model"][:40], "reference_ratio": r4_(cb.get("reference_ratio")), "reference_frames_per_s_est": r4_(cb.get("reference_frames_per_s_est"))}
         if args.pcie:
             import signals as S
             Tp = min(T, 1 << 14)
@@ -711,7 +729,18 @@ def main():
                 pv2.process_batch(xh, np.full(Tp, args.pitch_num, np.float32))
             out["pcie_inclusive_frames_per_s"] = 3 * nch * Tp / (time.perf_counter() - t1)
             pv2.close()
-        print(json.dumps(out), flush=True)
+        out["legend"] = "profiles/bench_workloads.md"
+        line = json.dumps(out, separators=(",", ":"))
+        while len(line) > LINE_BUDGET and out.get("configs"):            # (never expected: the entries are sized for ~5 KB) drop flavour entries from the end, say so
+            out["configs"].pop(); out["truncated"] = True
+            line = json.dumps(out, separators=(",", ":"))
+        try:                                                              # the unabridged record (workload prose, every region, forms of the latency lines) next to the line
+            ddir = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(ddir, exist_ok=True)
+            json.dump(detail, open(os.path.join(ddir, "bench_detail.json"), "w"), indent=1)
+        except Exception:
+            pass
+        print(line, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

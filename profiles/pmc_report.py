@@ -137,6 +137,37 @@ def main():
                           "WRITE_SIZE_KiB": calib.get("WRITE_SIZE"), "expected_KiB": 1 << 20,
                           "fetch_x2_over_expected": (calib.get("FETCH_SIZE", 0) * 2) / (1 << 20), "write_over_expected": calib.get("WRITE_SIZE", 0) / (1 << 20)}
     json.dump(tj, open(tj_path, "w"), indent=1)
+    # ---- what binds: VALU issue cycles over the SIMD cycles of the launch (bench.py: roofline_valu), per shape, stamped like the traffic ----
+    vj = {}
+    def valu_entry(c, frames):
+        if not c or "SQ_ACTIVE_INST_VALU" not in c or "GRBM_GUI_ACTIVE" not in c:
+            return None
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0                         # summed over the 8 XCDs
+        e = {"frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc), "active_inst_valu_quad_cycles": c["SQ_ACTIVE_INST_VALU"], "launch_cycles": cyc, "simds": 1024,
+             "valu_insts_per_frame": (c.get("SQ_INSTS_VALU", 0.0) / frames) if frames else None,
+             "wait_any_frac": (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c else None, "csrc_sha16": sha,
+             "source": f"profiles/run_profile_r0N.sh {tag}: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), separate --pmc passes"}
+        return e
+    hc, _ = dominant_counters(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"))
+    e = valu_entry(hc, frames)
+    if e:
+        vj["1024/256/ch1/hops1048576"] = e
+    wgshapes = {"c3": (2048, 512, 2, 262144), "c4": (4096, 1024, 1024, 64), "c5": (8192, 2048, 8, 16384), "native": (2048, 128, 2, 262144)}
+    for name, (fft, hop, nch, hops) in wgshapes.items():
+        cc, _k = dominant_counters(os.path.join(d, f"wg_{name}_*", "**", "*counter_collection.csv"))
+        fr = None
+        try:
+            j = json.loads([l for l in open(os.path.join(d, f"wg_{name}_1.log")) if l.startswith("{")][-1])
+            cfg = j["config"]
+            chains = -(-cfg["hops_per_step"] // cfg["frames_per_chunk"])
+            fr = cfg["channels"] * (cfg["hops_per_step"] + (chains - 1) * (cfg["fft"] // cfg["hop"] - 1))
+        except Exception:
+            pass
+        e = valu_entry(cc, fr)
+        if e:
+            vj[f"{fft}/{hop}/ch{nch}/hops{hops}"] = e
+    if vj:
+        json.dump(vj, open(os.path.join(ROOT, "profiles", "valu_issue.json"), "w"), indent=1)
     # ---- workgroup kernel ----
     lines = [f"# {tag}: counters of the other shapes' kernels (pv_wave2k_kernel at N = 2048, pv_wg_kernel above), per computed frame (separate --pmc passes)", ""]
     for name in ("c3", "c3f15", "c3f07", "c4", "c5", "c5f08", "c5sweep", "native", "c2f08"):
