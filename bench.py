@@ -599,7 +599,7 @@ def main():
                        "fft": fft, "hop": hop, "channels": nch, "hops_per_step": T, "pitch_factor": args.pitch,
                        "frames_per_chunk": info["frames_per_chunk"], "parallelism": f"streams x{world}, no collective", "device": info["device_name"][:40]},
             "roofline": {"bound": "hbm", "achieved": head["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["achieved_gbs"] / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": info["kernel_name"], "kernel_ms": head["kernel_ms"], "kernel_ms_min": min(kms), "kernel_ms_max": max(kms),
+                         "traffic": traffic, "kernel": info["kernel_name"], "kernel_ms": head["kernel_ms"], "kernel_ms_min": min(kms), "kernel_ms_max": max(kms), "regions": len(kms),
                          "algorithmic_bytes_per_launch": head["alg_bytes"], "copy_gbs_measured": copy_gbs,
                          "frac_of_measured_copy": (head["achieved_gbs"] / copy_gbs) if copy_gbs else None,
                          "note": "bound by VALU issue, not HBM: see roofline_valu"},

@@ -26,6 +26,9 @@
 #include "pv_kernels.h"
 #include "pv_device_common.h"
 #include "pv_pk_math.h"
+#ifndef PV_WG16_WPS
+#define PV_WG16_WPS 2      // waves per SIMD the product instances are compiled for (measurement builds: 3)
+#endif
 #ifndef PV_PAIRWISE
 #define PV_PAIRWISE 1
 #endif
@@ -671,7 +674,7 @@ __device__ __attribute__((noinline)) PV_NO_DS_MERGE void residue_scatter_wg16_d(
 // S_ROWS = hop / (N / 16) in {2, 4, 8, 16}: the frame advances by whole register rows (N / 16 samples), overlap-add accumulator and input window live in registers.
 // AUX: test-tap instance.  RESIDENT: streaming instance that stays on the GPU (see pv_wg_kernel.hip).
 template <int LOG2N, int S_ROWS, bool AUX, bool RESIDENT = false>
-__global__ __launch_bounds__(QC<LOG2N>::T, (RESIDENT || FP64W) ? 1 : 2) PV_NO_DS_MERGE void pv_wg16_kernel(const PvKernelParams p)
+__global__ __launch_bounds__(QC<LOG2N>::T, (RESIDENT || FP64W) ? 1 : PV_WG16_WPS) PV_NO_DS_MERGE void pv_wg16_kernel(const PvKernelParams p)
 {
     using C = QC<LOG2N>;
     constexpr int N = C::N, M = C::M, H = C::H, T = C::T, K2 = C::K2, NW = C::NW, PR = C::PR, PM = C::PM;

@@ -95,7 +95,7 @@ def test_rccl_branch_runs_on_hardware_at_world_size_one():
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["n_gpus"] == 1 and j["dist_backend"] == "nccl"
     assert np.isfinite(j["scatter_gather_ms"]) and j["scatter_gather_ms"] > 0
-    assert j["parity_rms_vs_oracle"] < 2e-7 and len(j["timed_regions"]["kernel_ms"]) == 5
+    assert j["parity_rms_vs_oracle"] < 2e-7 and j["roofline"]["regions"] == 5
 
 
 def test_two_bench_ranks_on_one_gpu_run_the_multi_rank_line_end_to_end():

@@ -19,7 +19,7 @@ import torch
 import phaze_amd
 
 
-def gen(kind, n, dev, seed):
+def gen(kind, n, dev, seed, fft=1024):
     g = torch.Generator(device=dev); g.manual_seed(9000 + seed)
     i = torch.arange(n, device=dev, dtype=torch.float64)
     rnd = lambda: torch.rand(n, device=dev, generator=g)
@@ -52,20 +52,42 @@ def gen(kind, n, dev, seed):
     if kind == "quantised16":                 # 16-bit material: tonal + dither rounded to 1/32768
         x = 0.4 * torch.sin(2 * np.pi * i * 0.031) + 0.2 * torch.sin(2 * np.pi * i * 0.177)
         return torch.round((x.float() + (rnd() - 0.5) / 32768) * 32768) / 32768
+    # ---- adversarial classes (round 6; built to stress the error law, not drawn from audio) ----
+    if kind == "adv_binpair150":              # one full-scale partial exactly on a bin + a second partial 150 dB down: every other bin is the fp32 samples' rounding noise
+        return (1.0 * torch.sin(2 * np.pi * (i % 16) / 16) + 10 ** (-150 / 20) * torch.sin(2 * np.pi * i * (0.0731 + 1e-4 * seed))).float()
+    if kind == "adv_nyquist":                 # Nyquist alternation +-A with a tiny tone: the largest bin is the LAST one, everything else cancels
+        alt = 1.0 - 2.0 * (i % 2)
+        return (0.9 * alt + 1e-4 * torch.sin(2 * np.pi * i * (0.0417 + 2e-4 * seed))).float()
+    if kind == "adv_click":                   # a single huge sample per ~window in low noise: |X| flat (every comparison a near tie), max|X| = the frame's rms * sqrt(N)
+        x = (rnd() * 2 - 1) * 1e-5
+        idx = torch.arange(137 + 11 * seed, n, 1531, device=dev)
+        x[idx] = 0.95
+        return x
+    if kind == "adv_halfbin":                 # partials half way between two bins, detuned by parts per million: |X|^2 of the two neighbours differ by a few ulp
+        x = torch.zeros(n, device=dev, dtype=torch.float64)
+        for j, (k0, a) in enumerate(((37.5, 0.4), (101.5, 0.3), (222.5, 0.2))):
+            x += a * torch.sin(2 * np.pi * i * ((k0 + (seed - 3.5) * 2e-7 * (j + 1)) / float(fft)) + 0.3 * j)
+        return x.float() + (rnd() * 2 - 1) * 1e-7
     raise SystemExit(kind)
 
 
+ALL_KINDS = ["bench", "white", "tonal60", "tonal80", "tonal100", "fuzz_noise", "fuzz_tonal", "sine32", "impulses", "chirp_am", "quantised16",
+             "adv_binpair150", "adv_nyquist", "adv_click", "adv_halfbin"]
+
+
 def main():
+    # flip_count.py [frames-per-class] [out.json] [fft] [log2 of the frames per run at N = 1024 (default 19)]
     per_class = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2_000_000
     out_path = sys.argv[2] if len(sys.argv) > 2 else ""
     fft = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    log2t = int(sys.argv[4]) if len(sys.argv) > 4 else 19
     dev = torch.device("cuda", 0)
     L = phaze_amd.load_library()
     if not hasattr(L, "pv_exp_flip_stats"):
         raise SystemExit("this library is not the validation build: PHAZE_LIB=build/exp/libphaze_flip.so")
     L.pv_exp_flip_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-    kinds = ["bench", "white", "tonal60", "tonal80", "tonal100", "fuzz_noise", "fuzz_tonal", "sine32", "impulses", "chirp_am", "quantised16"]
-    T = (1 << 19) * 1024 // fft
+    kinds = ALL_KINDS
+    T = (1 << log2t) * 1024 // fft
     rows, tot, tot_cls = [], np.zeros(4, np.uint64), np.zeros(2, np.uint64)
     qmax_all = 0.0
     for kind in kinds:
@@ -74,7 +96,7 @@ def main():
             hop = (fft // 4, fft // 4, fft // 8 if fft == 1024 else 128, fft // 2)[run % 4]
             amp = (1.0, 1.0, 1e-4, 1.0, 30.0, 1.0, 5e-5, 1.0)[run % 8]         # scale invariance: tiny and large signals
             pf = (1.5, 1.0, 2.0, 1.25)[run % 4]
-            x = (gen(kind, T * hop, dev, run) * amp)[None, :].contiguous()
+            x = (gen(kind, T * hop, dev, run, fft) * amp)[None, :].contiguous()
             y = torch.empty_like(x)
             pt = torch.full((T,), pf, device=dev, dtype=torch.float32)
             pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=1, max_hops=1)
