@@ -29,6 +29,9 @@
 #ifndef PV_WG16_WPS
 #define PV_WG16_WPS 2      // waves per SIMD the product instances are compiled for (measurement builds: 3)
 #endif
+#ifndef PV_WG16_WPS
+#define PV_WG16_WPS 2      // waves per SIMD the product instances are compiled for (measurement builds: 3 -> 168 VGPRs, 99 spilled at N = 8192 / hop N/4: tools/experiments/README.md)
+#endif
 #ifndef PV_PAIRWISE
 #define PV_PAIRWISE 1
 #endif
