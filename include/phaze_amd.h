@@ -47,8 +47,9 @@ typedef struct pv_handle pv_handle;
  * 2 = round 3: pv_config carries its own size, unknown pv_config.flags bits are rejected, PV_FLAG_PERSISTENT_STREAM;
  * 3 = round 4: pv_host_alloc / pv_host_free (page-locked host buffers: pv_process_batch pipelines them), PV_FLAG_TEST_NO_HDP_FLUSH,
  *     pv_reset_channels_part + PV_FLAG_HOST_CHANNEL_BOOKKEEPING;
- * 4 = round 5: PV_FLAG_FP64_FORWARD, pv_forward_stats. */
-#define PV_ABI_VERSION 4
+ * 4 = round 5: PV_FLAG_FP64_FORWARD, pv_forward_stats;
+ * 5 = round 6: PV_FLAG_TEST_FAIL_SECOND_PIECE (a test hook); no layout or semantic change of anything that existed. */
+#define PV_ABI_VERSION 5
 
 /* Construction options.  Replaces `new PhaseVocoderProcessor(options)` (phase-vocoder.js:24-43,
  * ola-processor.js:7-34).  The reference hard-codes fft_size 2048 (phase-vocoder.js:6) and hop 128
@@ -102,13 +103,22 @@ enum {
                                   * reference's bookkeeping itself with pv_reset_channels_part -- input and output buffers separately, ola-processor.js:38-52 -- as
                                   * phaze_amd/node/phase-vocoder.js does for hosts whose outputs do not mirror their inputs */
     PV_FLAG_FP64_FORWARD = 256,  /* every frame's forward transform in fp64, as the reference computes it (realTransform on JS doubles, bundle:306-508) and as every
-                                  * round-4 kernel did.  Default since round 5: the forward transform runs in packed fp32 FIRST and the peak decisions
+                                  * round-4 kernel did.  Default since round 5 (N = 1024 and N = 2048): the forward transform runs in packed fp32 FIRST and the peak decisions
                                   * (phase-vocoder.js:95-116) are taken on its magnitudes wherever every comparison they rest on lies outside a guard band around the fp32
                                   * transform's error; a frame with a comparison inside the band re-runs its forward transform in fp64 (pv_forward_stats counts them).
-                                  * Decisions are the reference's either way; the source spectrum of a guarded frame carries the fp32 transform's rounding
+                                  * The band is an EMPIRICALLY VALIDATED law, not an analytic bound: g = 10 eps max|X| against a largest observed discrepancy of 3.3
+                                  * (a rigorous FFT error bound in max|X| terms is ~20x wider).  What backs "the decisions are the fp64 transform's" is a validation
+                                  * build in which every frame computes both transforms and compares the two sets of peak flags: 0 frames whose flags differ without
+                                  * the band asking for the fp64 transform over 4.7e7 + 1.2e7 frames (profiles/r05_flip_count*.json), re-measured on every GPU test run
+                                  * over fifteen signal classes incl. four adversarial ones (tests/test_gpu_flip_count.py, >= 2.9e6 frames, band-shrink margin >= 2
+                                  * asserted, 4.5 measured).  An uncaught flip would misplace one region of one frame (far inside the 1e-4 RMS bar) -- set this flag where
+                                  * decision parity must hold by construction.  The source spectrum of a guarded frame carries the fp32 transform's rounding
                                   * (~1e-7 of the frame's rms instead of a correctly rounded fp64 value).  Which frames fall back depends on their own samples only:
                                   * chunked, call-split, streaming and batch runs of one stream still agree bit for bit */
-    PV_FLAG_ALL = 511            /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
+    PV_FLAG_TEST_FAIL_SECOND_PIECE = 512, /* TEST HOOK, never needed in production: a pipelined host-buffer batch (pv_process_batch on page-locked memory, >= 4 MB) reports
+                                  * PV_ERR_DEVICE behind its second piece, as a failed copy or launch would -- tests/test_gpu_batch_pipeline.py checks that the handle is
+                                  * rolled back to its state before the call (timeCursor, ping-pong half, the state snapshot of a hop-span pipeline) */
+    PV_FLAG_ALL = 1023           /* every bit this build knows: pv_create rejects anything else (PV_ERR_ARGUMENT) */
 };
 
 typedef struct pv_info {
@@ -141,7 +151,9 @@ PV_API int pv_device_count(int32_t *out);
 
 /* Forward-transform statistics since the handle was created (or last reset): frames whose forward transform an fp32-first kernel instance computed, and how many
  * of them re-ran it in fp64 because a peak decision (phase-vocoder.js:95-116) was within the fp32 transform's error (PV_FLAG_FP64_FORWARD).  Frames that run on
- * instances without the fp32-first path are not counted.  Synchronizes the handle's stream.  Either pointer may be NULL; reset != 0 zeroes the counters. */
+ * instances without the fp32-first path are not counted.  Synchronizes the handle's stream -- and, like every call that puts work on that stream, first asks the resident
+ * waves of a PV_FLAG_PERSISTENT_STREAM handle to leave (the next quantum relaunches them: ~20 us once): poll it between streams, not between quanta.  Either pointer may be
+ * NULL; reset != 0 zeroes the counters. */
 PV_API int pv_forward_stats(pv_handle *h, uint64_t *frames, uint64_t *fallbacks, int32_t reset);
 
 /* ---- state ------------------------------------------------------------------------------------- */

@@ -41,13 +41,14 @@ def make_config(fft_size, hop_size, max_channels=1, max_hops=1, device_id=0, fra
     return _Config(C.sizeof(_Config), fft_size, hop_size, max_channels, max_hops, device_id, frames_per_chunk, flags)
 
 
-ABI_VERSION = 4          # PV_ABI_VERSION of include/phaze_amd.h this binding was written against (checked at load time)
+ABI_VERSION = 5          # PV_ABI_VERSION of include/phaze_amd.h this binding was written against (checked at load time)
 
 
 # pv_config.flags (include/phaze_amd.h): explicit A/B switches; the library reads no environment variables
 FLAG_GENERIC_KERNEL, FLAG_STREAM_COPY, FLAG_WORKGROUP_KERNEL, FLAG_STREAM_EVENT_WAIT, FLAG_STREAM_PINNED_INPUT, FLAG_PERSISTENT_STREAM = 1, 2, 4, 8, 16, 32
 FLAG_TEST_NO_HDP_FLUSH = 64      # test hook (tests/test_gpu_stream_forms.py)
 FLAG_HOST_CHANNEL_BOOKKEEPING = 128
+FLAG_TEST_FAIL_SECOND_PIECE = 512   # test hook (tests/test_gpu_batch_pipeline.py): a pipelined host-buffer batch fails behind its second piece
 FLAG_FP64_FORWARD = 256          # every forward transform in fp64 (the round-4 kernels); default: fp32 first, fp64 only where a peak decision is in doubt
 STATE_HISTORY, STATE_ACCUMULATOR = 1, 2
 

@@ -82,6 +82,7 @@ struct pv_handle {
     int pending_cur, pending_active_nch;         // ... and what to restore if that wait fails
     int64_t pending_time_cursor;
     bool host_channels;                          // PV_FLAG_HOST_CHANNEL_BOOKKEEPING: a changed nch resets nothing here
+    bool test_fail_piece = false;      // PV_FLAG_TEST_FAIL_SECOND_PIECE: the second piece of a pipelined host-buffer batch reports a device error (exercises the roll-back)
     bool use_wave;                               // N = 1024: wave-per-frame kernel (pv_wave_kernel.hip)
     bool use_wg;                                 // N = 2048..8192, R <= 8: register-resident workgroup kernel (pv_wg_kernel.hip)
     bool use_wave2k;                             // N = 2048, hop 128..2048: one wave per frame (pv_wave2k_kernel.hip)
@@ -259,11 +260,31 @@ bool host_pinned(const void *ptr)
     if (hipPointerGetAttributes(&a, ptr) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
 }
-// ... the whole range [ptr, ptr + bytes): a buffer that is only partly registered (hipHostRegister on a sub-range, a view that runs past its registration) must not
-// take the asynchronous DMA path
+// ... the whole range [ptr, ptr + bytes): a buffer that is only partly registered (hipHostRegister on a sub-range, a view that runs past its registration, two
+// registrations with a pageable gap between them) must not take the asynchronous DMA path.  Both ends must be page-locked AND belong to the SAME allocation / registration
+// (hipMemGetAddressRange on the device-side alias of the two ends: same base); where the runtime cannot name the allocation, the span is probed at up to 2048 evenly
+// spaced points in between (every page of a span of up to 8 MB; coarser above -- a gap smaller than the probe stride inside two separately registered regions is then
+// not seen, which costs such a caller a synchronous staging copy inside the runtime, never a wrong result).
 bool host_pinned_range(const void *ptr, size_t bytes)
 {
-    return host_pinned(ptr) && (bytes == 0 || host_pinned(static_cast<const char *>(ptr) + bytes - 1));
+    if (bytes == 0) return host_pinned(ptr);
+    const char *lo = static_cast<const char *>(ptr), *hi = lo + bytes - 1;
+    hipPointerAttribute_t a0, a1;
+    memset(&a0, 0, sizeof a0); memset(&a1, 0, sizeof a1);
+    if (hipPointerGetAttributes(&a0, lo) != hipSuccess || hipPointerGetAttributes(&a1, hi) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a0.type != hipMemoryTypeHost || a1.type != hipMemoryTypeHost) return false;
+    if (a0.devicePointer && a1.devicePointer) {
+        hipDeviceptr_t b0 = nullptr, b1 = nullptr;
+        size_t s0 = 0, s1 = 0;
+        if (hipMemGetAddressRange(&b0, &s0, a0.devicePointer) == hipSuccess && hipMemGetAddressRange(&b1, &s1, a1.devicePointer) == hipSuccess)
+            return b0 == b1 && s0 == s1;                                     // one allocation / one registration covers both ends, hence everything between them
+        (void)hipGetLastError();
+    }
+    const size_t page = 4096, pages = (bytes + page - 1) / page;
+    const size_t probes = pages < 2048 ? pages : 2048;
+    for (size_t i = 1; i + 1 < probes; i++)
+        if (!host_pinned(lo + (size_t)((double)i / (double)(probes - 1) * (double)(bytes - 1)))) return false;
+    return true;
 }
 
 // ---- resident streaming kernel (PV_FLAG_PERSISTENT_STREAM) ----
@@ -396,6 +417,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     h->active_nch = -1;
     h->host_channels = (cfg->flags & PV_FLAG_HOST_CHANNEL_BOOKKEEPING) != 0;
     h->fwd64 = (cfg->flags & PV_FLAG_FP64_FORWARD) != 0;
+    h->test_fail_piece = (cfg->flags & PV_FLAG_TEST_FAIL_SECOND_PIECE) != 0;
     {
         // the resident waves leave after ~50 ms without work, measured on the device's constant-rate clock (wall_clock64): the host stops and restarts them by ITS
         // wall clock after 20 ms (pv_process_begin), so the device-side figure must never come out below that -- a poll COUNT did, depending on where the control block lives
@@ -992,6 +1014,7 @@ int pv_process_batch(pv_handle *h, const float *in, float *out, int32_t nch, int
             const int rc = by_channel ? launch_chain(h, h->d_stage_in + doff, h->d_stage_out + doff, c0, cn, mn, (long)row, pp, pitch_stride ? nhops : 0, cps, true, -1, 0)
                                       : run_chain(h, h->d_stage_in + doff, h->d_stage_out + doff, nch, mn, (long)row, pp, pitch_stride ? nhops : 0, cps, true, -1);
             if (rc != PV_OK) return rc;
+            if (k == 1 && h->test_fail_piece) return fail(h, PV_ERR_DEVICE, "pv_process_batch: injected failure behind the second piece (PV_FLAG_TEST_FAIL_SECOND_PIECE)");
             HIPCHK(h, hipEventRecord(h->ev_k[k], h->stream));
             HIPCHK(h, hipStreamWaitEvent(h->s_out, h->ev_k[k], 0));
             HIPCHK(h, hipMemcpy2DAsync(out + hoff, (size_t)ch_stride * sizeof(float), h->d_stage_out + doff, row_bytes, w, cn, hipMemcpyDeviceToHost, h->s_out));

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "pv_signal.h"
+#include "pv_mul_rounded.h"
 
 // Measured on gfx950 (tools/lds_microbench.hip): ds_read2_b64 / ds_read2st64_b64 / ds_read2_b32 occupy the LDS pipe for 8 cycles, twice
 // the cost of the two single reads they replace (2 + 2); ds_write2_b64 is neutral.  The SI load/store optimizer forms them wherever
@@ -80,16 +81,7 @@ __device__ __forceinline__ typename v2t<T>::type mul_w16(typename v2t<T>::type o
     return cmul(o, w);
 }
 
-// a * b ROUNDED to fp32, as an operation of its own.  hipcc contracts a plain product into a following add or subtract (v_fma_f32 / v_pk_fma_f32) -- also `__fmul_rn`, which
-// this toolchain defines as `x * y` --: one rounding less than the reference, whose windowed samples and windowed frames are Float32Array elements (pv:55,67).  An asm
-// multiply is opaque to that (pure, not volatile: free to be scheduled or dropped).  Found by the reference-width flavour of pv_wg16_kernel in round 5: the fused form differs
-// from the reference by one ulp in ~40 % of the output samples (4e-9 RMS), which the product's own fp32 inverse (6e-9) had covered.
-__device__ __forceinline__ float mul_rounded(float a, float b)
-{
-    float d;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
+// mul_rounded (a * b rounded to fp32 as an operation of its own, pv:55,67): pv_mul_rounded.h
 
 struct WaveSrc {
     const float *in;

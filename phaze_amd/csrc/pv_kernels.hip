@@ -20,6 +20,7 @@
 
 #include "pv_kernels.h"
 #include "pv_signal.h"
+#include "pv_mul_rounded.h"
 
 namespace {
 
@@ -37,15 +38,7 @@ template <typename T2> __device__ __forceinline__ T2 cconj(T2 a) { return T2{a.x
 // multiply by -j (forward) / +j (inverse)
 template <bool INV, typename T2> __device__ __forceinline__ T2 cmul_mj(T2 a) { return INV ? T2{-a.y, a.x} : T2{a.y, -a.x}; }
 
-// a * b rounded to fp32 as an operation of its own: a plain product (also `__fmul_rn`) is contracted into a following add -- one rounding less than the reference's
-// Float32Array elements (pv:55,67); see pv_device_common.h
-__device__ __forceinline__ float mul_rounded(float a, float b)
-{
-    float d;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-
+// mul_rounded (a * b rounded to fp32 as an operation of its own, pv:55,67): pv_mul_rounded.h, shared with the register kernels
 __device__ __forceinline__ int bitrev(int v, int bits) { return bits == 0 ? 0 : (int)(__brev((unsigned)v) >> (32 - bits)); }
 // base-4 digit reversal over nd digits
 __device__ __forceinline__ int digitrev4(int v, int nd)
@@ -191,6 +184,10 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
     const int ch = blockIdx.y, chunk = blockIdx.x;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // GM != 0 (N >= 16384): B, the overlap-add ring, the claim words (and at GM == 2 the fp64 buffer) live in a per-workgroup slice of DEVICE memory and are ordered by
+    // __syncthreads() alone, agent-scope atomicMin next to plain loads and stores.  That is sound because a workgroup's waves share ONE vector L1 (the default CU mode):
+    // under -mtgsplit (threadgroup-split mode: the waves of a workgroup may sit on different CUs with different L1s) it would need workgroup-scope atomics / fences
+    // around every exchange.  The build never uses that mode (the compiler defines no macro for it: the Makefile refuses the flag).
     unsigned char *gm = GM ? p.gscratch + ((size_t)ch * gridDim.x + chunk) * p.gscratch_stride : nullptr;
     unsigned char *abase = (GM == 2) ? gm : smem;                          // where the fp64 buffer lives
     unsigned char *bbase = (GM == 2) ? gm + 16 * (M + 1) : (GM == 1) ? gm : smem + 16 * (M + 1);

@@ -60,7 +60,7 @@ def test_errors_without_device():
     cfg = capi.make_config(1024, 256)
     cfg.struct_size -= 4                                           # what a caller compiled against the round-2 header (no struct_size, 28 bytes) would pass
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_ARGUMENT and "struct_size" in L.pv_last_error(None).decode()
-    cfg = capi.make_config(1024, 256, flags=0x200)
+    cfg = capi.make_config(1024, 256, flags=0x400)
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_ARGUMENT and "flags" in L.pv_last_error(None).decode()
     try:
         import torch
@@ -103,7 +103,7 @@ def test_flag_constants_match_the_header():
     hdr = open(os.path.join(ROOT, "include", "phaze_amd.h")).read()
     vals = dict(re.findall(r"(PV_FLAG_[A-Z0-9_]+)\s*=\s*(\d+)", hdr))
     assert vals == {"PV_FLAG_GENERIC_KERNEL": "1", "PV_FLAG_STREAM_COPY": "2", "PV_FLAG_WORKGROUP_KERNEL": "4", "PV_FLAG_STREAM_EVENT_WAIT": "8", "PV_FLAG_STREAM_PINNED_INPUT": "16",
-                    "PV_FLAG_PERSISTENT_STREAM": "32", "PV_FLAG_TEST_NO_HDP_FLUSH": "64", "PV_FLAG_HOST_CHANNEL_BOOKKEEPING": "128", "PV_FLAG_FP64_FORWARD": "256", "PV_FLAG_ALL": "511"}
+                    "PV_FLAG_PERSISTENT_STREAM": "32", "PV_FLAG_TEST_NO_HDP_FLUSH": "64", "PV_FLAG_HOST_CHANNEL_BOOKKEEPING": "128", "PV_FLAG_FP64_FORWARD": "256", "PV_FLAG_TEST_FAIL_SECOND_PIECE": "512", "PV_FLAG_ALL": "1023"}
     import phaze_amd
     assert (phaze_amd.FLAG_GENERIC_KERNEL, phaze_amd.FLAG_STREAM_COPY, phaze_amd.FLAG_WORKGROUP_KERNEL, phaze_amd.FLAG_STREAM_EVENT_WAIT,
             phaze_amd.FLAG_STREAM_PINNED_INPUT) == (1, 2, 4, 8, 16)

@@ -69,8 +69,7 @@ def test_pinned_batch_is_pipelined_and_bit_identical(fft, hop, nch, T, cps, pf):
 
 def test_pinned_batch_keeps_other_slots_and_a_mixed_buffer_pair_takes_the_plain_path():
     """A pipelined call over nch < used_channels slots carries the other slots' state across the flip(s); a mixed pinned / pageable pair of
-    buffers takes the unpipelined path with the same bits.  (The roll-back of a pipelined call that fails in a later piece -- the state snapshot in pv_process_batch --
-    has no test: nothing short of a device fault makes a piece fail.)"""
+    buffers takes the unpipelined path with the same bits.  (The roll-back of a pipelined call that fails in a later piece: test_failed_piece_rolls_the_handle_back below.)"""
     import phaze_amd
     fft, hop, T = 1024, 256, 8192
     x = _x(3, T * hop, 5)
@@ -90,3 +89,38 @@ def test_pinned_batch_keeps_other_slots_and_a_mixed_buffer_pair_takes_the_plain_
     y3 = pv.process_batch(xin, p)                                  # pinned in, pageable out: unpipelined
     assert np.array_equal(y3.view(np.uint32), r3.view(np.uint32))
     pv.close()
+
+
+@pytest.mark.parametrize("fft,hop,nch,T,cps", [
+    (1024, 256, 1, 16384, 1),             # spans of hops: the pieces commit the state ping-pong one by one -> the snapshot taken before the first piece is put back
+    (1024, 256, 96, 192, 2),              # groups of whole streams: nothing is committed before the last piece
+])
+def test_failed_piece_rolls_the_handle_back(fft, hop, nch, T, cps):
+    """PV_FLAG_TEST_FAIL_SECOND_PIECE (a test hook of the C ABI, round 6; advisor r05): a pipelined batch reports PV_ERR_DEVICE behind its second piece, with piece 0 already
+    through the kernel (hop spans: state committed, both ping-pong halves about to be overwritten).  The call must fail, leave timeCursor and the channel state exactly as they
+    were, and the handle must go on as if the call had never been made: the same batch again == a handle that never saw the failure, bit for bit."""
+    import phaze_amd
+    n = T * hop
+    x = _x(nch, n, 77 + nch)
+    pitch = np.full(T, 0.9, np.float32)
+    ref_pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T)
+    r1 = ref_pv.process_batch(x, pitch, channels_per_stream=cps)
+    r2 = ref_pv.process_batch(x, pitch, channels_per_stream=cps)
+    ref_pv.close()
+    xin, yout = phaze_amd.pinned_empty((nch, n)), phaze_amd.pinned_empty((nch, n))
+    xin[:] = x
+    # one handle WITH the hook: first a clean call through the plain path (pageable output), so that there is state to roll back to
+    pv = phaze_amd.PhaseVocoder(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T, flags=phaze_amd.FLAG_TEST_FAIL_SECOND_PIECE)
+    y1 = pv.process_batch(xin, pitch, channels_per_stream=cps)
+    assert np.array_equal(y1.view(np.uint32), r1.view(np.uint32))
+    cur0 = pv.time_cursor
+    hist0, acc0, _ = pv.export_state(0)
+    with pytest.raises(phaze_amd.PvError) as ei:
+        pv.process_batch(xin, pitch, channels_per_stream=cps, out=yout)           # pinned in AND out, >= 4 MB: pipelined -> the injected failure
+    assert "injected failure" in str(ei.value)
+    assert pv.time_cursor == cur0
+    hist1, acc1, _ = pv.export_state(0)
+    assert np.array_equal(hist0.view(np.uint32), hist1.view(np.uint32)) and np.array_equal(acc0.view(np.uint32), acc1.view(np.uint32))
+    y2 = pv.process_batch(xin, pitch, channels_per_stream=cps)                    # (pageable output: the plain path, no hook) continues from the restored state
+    pv.close()
+    assert np.array_equal(y2.view(np.uint32), r2.view(np.uint32))
