@@ -79,7 +79,8 @@ int pv_wave_threads();
 bool pv_wave_supported(int log2n, int hop);
 // spread: > 0 every frame of the launch has pitchFactor >= 1 (the host knows: streaming quantum), 0 it does not, < 0 unknown: classify the chains on the device
 // (list = 2 * nch * nchunks + 2 words of device memory owned by the caller) and run each class on its instance
-hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st, int spread, unsigned *list);
+// list_next: the list the NEXT classified launch of this handle will use; its two counters are zeroed by this launch's classification (no memset per launch)
+hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st, int spread, unsigned *list, unsigned *list_next = nullptr);
 // resident form of the same kernel for streaming quanta (p.ctl != null): one wave per channel slot, nslots of them, polling p.ctl until ctl[4] (stop) or ~50 ms idle
 hipError_t pv_launch_wave_resident(const PvKernelParams &p, int nslots, hipStream_t st);
 hipError_t pv_launch_wave2k_resident(const PvKernelParams &p, int nslots, hipStream_t st);

@@ -1545,8 +1545,9 @@ resident_top:
 // whatever the atomics make it: chains are independent, the results do not depend on it.  list = {count[2], class 0 [nchains], class 1 [nchains]}.
 constexpr int CLS_WAVES = 16;
 template <int S_ROWS>
-__global__ __launch_bounds__(64 * CLS_WAVES) void pv_classify_chains(const PvKernelParams p, unsigned *list)
+__global__ __launch_bounds__(64 * CLS_WAVES) void pv_classify_chains(const PvKernelParams p, unsigned *list, unsigned *list_next)
 {
+    if (list_next && blockIdx.x == 0 && threadIdx.x < 2) list_next[threadIdx.x] = 0u;     // the counters of the handle's NEXT launch (its previous user is behind us in stream order)
     constexpr int HOP = 128 * S_ROWS, R = 1024 / HOP;
     __shared__ unsigned cls_of[CLS_WAVES], base[2];
     const long nchains = (long)p.nch * p.nchunks;
@@ -1582,7 +1583,7 @@ __global__ __launch_bounds__(64 * CLS_WAVES) void pv_classify_chains(const PvKer
 }
 
 template <int S_ROWS, bool AUX>
-hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st, int spread, unsigned *list)
+hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st, int spread, unsigned *list, unsigned *list_next)
 {
     static std::atomic<bool> attr_done[16], attr_done_s[16];
     static std::atomic<bool> attr_done_f[16], attr_done_g[16];
@@ -1610,9 +1611,11 @@ hipError_t launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_
         if (!AUX) hipLaunchKernelGGL(ks, grid, block, pv_wave_lds_bytes(), st, q);
     } else {
         // classify on the device, then both instances over the whole grid: a workgroup beyond its class's count leaves at once
-        hipError_t e = hipMemsetAsync(list, 0, 2 * sizeof(unsigned), st);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(pv_classify_chains<S_ROWS>, dim3((unsigned)((chains + CLS_WAVES - 1) / CLS_WAVES), 1, 1), dim3(64 * CLS_WAVES, 1, 1), 0, st, q, list);
+        if (!list_next) {                                                  // (a caller without a second list: the counters are zeroed here, one more operation per launch)
+            hipError_t e = hipMemsetAsync(list, 0, 2 * sizeof(unsigned), st);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(pv_classify_chains<S_ROWS>, dim3((unsigned)((chains + CLS_WAVES - 1) / CLS_WAVES), 1, 1), dim3(64 * CLS_WAVES, 1, 1), 0, st, q, list, list_next);
         q.chain_count = list;
         q.chain_list = list + 2;
         if (!AUX) hipLaunchKernelGGL(ks, grid, block, pv_wave_lds_bytes(), st, q);
@@ -1659,14 +1662,14 @@ hipError_t pv_launch_wave_resident(const PvKernelParams &p, int nslots, hipStrea
     }
 }
 
-hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st, int spread, unsigned *list)
+hipError_t pv_launch_wave(const PvKernelParams &p, int nch, int nchunks, hipStream_t st, int spread, unsigned *list, unsigned *list_next)
 {
     const bool aux = (p.dbg_mag != nullptr);
     switch (p.hop) {
-    case 128: return aux ? launch_wave<1, true>(p, nch, nchunks, st, 0, nullptr) : launch_wave<1, false>(p, nch, nchunks, st, spread, list);
-    case 256: return aux ? launch_wave<2, true>(p, nch, nchunks, st, 0, nullptr) : launch_wave<2, false>(p, nch, nchunks, st, spread, list);
-    case 512: return aux ? launch_wave<4, true>(p, nch, nchunks, st, 0, nullptr) : launch_wave<4, false>(p, nch, nchunks, st, spread, list);
-    case 1024: return aux ? launch_wave<8, true>(p, nch, nchunks, st, 0, nullptr) : launch_wave<8, false>(p, nch, nchunks, st, spread, list);
+    case 128: return aux ? launch_wave<1, true>(p, nch, nchunks, st, 0, nullptr, nullptr) : launch_wave<1, false>(p, nch, nchunks, st, spread, list, list_next);
+    case 256: return aux ? launch_wave<2, true>(p, nch, nchunks, st, 0, nullptr, nullptr) : launch_wave<2, false>(p, nch, nchunks, st, spread, list, list_next);
+    case 512: return aux ? launch_wave<4, true>(p, nch, nchunks, st, 0, nullptr, nullptr) : launch_wave<4, false>(p, nch, nchunks, st, spread, list, list_next);
+    case 1024: return aux ? launch_wave<8, true>(p, nch, nchunks, st, 0, nullptr, nullptr) : launch_wave<8, false>(p, nch, nchunks, st, spread, list, list_next);
     default: return hipErrorInvalidValue;
     }
 }
