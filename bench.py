@@ -535,6 +535,89 @@ def main():
         args.pitch_num, args.pitch = 1.0, "swept 0.5->2.0 per hop (period 64 hops)"    # (CPU baseline / PCIe legs of a swept run use f = 1.0)
     else:
         args.pitch_num = args.pitch
+    # The other configurations are measured FIRST and the headline LAST (round 6): a freshly leased box spends its first seconds below its sustained clocks -- on some boxes the
+    # first five or six workloads of a process read 3-5 % slow (the headline 1.78 ms where the same box gives 1.69 once it has been busy for ten seconds), whatever their own
+    # warm-up steps -- and `value` is the steady-state rate.  Nothing about the headline's own measurement changes: W untimed steps, then regions of exactly K timed steps.
+    xo, xd = {}, {}
+    if world == 1 and not args.no_extras:
+        # ---- the other configurations, each a short measured entry (same harness, same timing method).  Ids: profiles/bench_workloads.md.
+        #      BASELINE's product configurations first, then the unfavourable parameter range, then flavours / signal classes ----
+        extras, extras_full = [], []
+        r4 = lambda v: None if v is None else float(f"{v:.4g}")
+        def add(cid, f2, h2, c2, T2, pt, steps=8, warm=3, **kw):
+            r = measure(torch, phaze_amd, dev, None, f2, h2, c2, T2, pt, steps, warm, cid, local_rank, parity_hops=12, **kw)
+            e = {"id": cid, "v": r4(r["frames_per_step_rank"] * steps / r["elapsed"]), "frac": r4(r["achieved_gbs"] / HBM_PEAK_GBS), "ms": r4(r["kernel_ms"]), "par": r4(r["parity"])}
+            if r["fallback_rate"] is not None:
+                e["fb"] = r4(r["fallback_rate"])
+            extras.append(e)
+            extras_full.append(dict(e, kernel=r["info"]["kernel_name"], steps=steps, warmup=warm, ms_per_step=r["elapsed"] / steps * 1e3, frames_per_chunk=r["info"]["frames_per_chunk"],
+                                    fft=f2, hop=h2, channels=c2, hops=T2))
+        full = lambda n, v: torch.full((n,), v, device=dev, dtype=torch.float32)
+        swp = lambda n: (0.5 + 1.5 * (torch.arange(n, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
+        T3, T5, T8, T2 = 1 << 18, 1 << 14, 1 << 17, 1 << 20
+        add("C3", 2048, 512, 2, T3, full(T3, 0.8))
+        add("C4-share", 4096, 1024, 1024, 64, full(64, 1.25), steps=40, warm=10, ch_per_stream=8)   # 1 ms launches: as many steps as the headline
+        add("C5-sweep", 8192, 2048, 8, T5, swp(T5))
+        add("C5-f1.5", 8192, 2048, 8, T5, full(T5, 1.5))
+        add("8ch-1024", 1024, 256, 8, T8, full(T8, 1.5), steps=40, warm=10)    # (as many steps as the headline: the fixed cost of a timed region read as a "gap" to mono in rounds 3-4)
+        add("native", 2048, 128, 2, T3, full(T3, 1.0))
+        add("C2-f0.8", 1024, 256, 1, T2, full(T2, 0.8), steps=24, warm=6)
+        add("C2-sweep", 1024, 256, 1, T2, swp(T2), steps=24, warm=6)
+        add("C3-f1.5", 2048, 512, 2, T3, full(T3, 1.5))
+        add("C5-f0.6", 8192, 2048, 8, T5, full(T5, 0.6))
+        add("N16384", 16384, 4096, 8, 1 << 11, full(1 << 11, 1.5), steps=4, warm=1)     # complete, not tuned (generic kernel with a device-memory scratch): one timing
+        # the fp32-first forward transform from every side: PV_FLAG_FP64_FORWARD (the round-4 arithmetic) and the signal classes that bound it
+        p15 = full(T2, 1.5)
+        add("C2-fwd64", 1024, 256, 1, T2, p15, steps=24, warm=6, flags=phaze_amd.FLAG_FP64_FORWARD)
+        for sig in ("white", "tonal80", "tonal60", "q16", "silence"):
+            add("C2-" + sig, 1024, 256, 1, T2, p15, steps=16, warm=4, signal=sig)
+            if sig != "white":
+                add("C2-" + sig + "-fwd64", 1024, 256, 1, T2, p15, steps=16, warm=4, signal=sig, flags=phaze_amd.FLAG_FP64_FORWARD)
+        add("C3-tonal80", 2048, 512, 2, T3, full(T3, 0.8), signal="tonal80")
+        add("C3-tonal80-fwd64", 2048, 512, 2, T3, full(T3, 0.8), signal="tonal80", flags=phaze_amd.FLAG_FP64_FORWARD)
+        # ---- the reference-width flavour (never the product; build/exp/libphaze_fp64.so, `make -C phaze_amd/csrc fp64`): shifted spectrum, scatter, residue, c2r pass
+        #      and inverse FFT in fp64 like the reference's JS doubles.  A library is chosen at import time, so it runs in a child ----
+        flib = os.path.join(ROOT, "build", "exp", "libphaze_fp64.so")
+        if os.path.exists(flib) and not os.environ.get("PHAZE_LIB"):
+            for cid, fargs in (("C2-f64", ["--pitch", "1.5"]), ("C2-f0.8-f64", ["--pitch", "0.8"]),
+                               ("C3-f64", ["--fft", "2048", "--hop", "512", "--channels", "2", "--hops", "262144", "--pitch", "0.8"]),
+                               ("C4-share-f64", ["--fft", "4096", "--hop", "1024", "--channels", "1024", "--hops", "64", "--pitch", "1.25"]),
+                               ("C5-sweep-f64", ["--fft", "8192", "--hop", "2048", "--channels", "8", "--hops", "16384", "--pitch-sweep"]),
+                               ("C5-f1.5-f64", ["--fft", "8192", "--hop", "2048", "--channels", "8", "--hops", "16384", "--pitch", "1.5"])):
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--allow-lib-override", "--steps", "10", "--warmup", "3",
+                                    "--repeats", "3"] + fargs, capture_output=True, text=True, timeout=600, env=dict(os.environ, PHAZE_LIB=flib))
+                try:
+                    fj = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                    e = {"id": cid, "v": r4(fj["value"]), "frac": r4(fj["roofline"]["frac"]), "ms": r4(fj["roofline"]["kernel_ms"]), "par": r4(fj["parity_rms_vs_oracle"])}
+                    extras.append(e)
+                    extras_full.append(dict(e, dtype="f64", kernel=fj["roofline"]["kernel"], lib="build/exp/libphaze_fp64.so", steps=fj["steps"], ms_per_step=fj["ms_per_step"]))
+                except Exception as ex:
+                    extras.append({"id": cid, "err": f"{ex}"[:60]})
+                    extras_full.append({"id": cid, "error": f"{ex}: {(r.stderr or r.stdout)[-300:]}"})
+        xo["configs"] = extras
+        xd["configs"] = extras_full
+        # ---- the product boundary with HOST pointers: what a Node / C caller that owns host memory gets, PCIe included.  Never `value`; each entry carries the
+        #      fraction of this box's best pinned hipMemcpy rate it reaches ----
+        bw = pcie_bandwidth(torch, dev)
+        hb = []
+        rows4 = np.stack([np.full(64, 1.25, np.float32) for _ in range(128)])
+        hb.append(host_batch(torch, phaze_amd, dev, 4096, 1024, 1024, 64, 8, rows4, 5, local_rank, bw, "C4-share-host"))
+        hb.append(host_batch(torch, phaze_amd, dev, 1024, 256, 8, 1 << 15, 8, np.full((1, 1 << 15), 1.5, np.float32), 5, local_rank, bw, "8ch-1024-host"))
+        nl = node_sharded_line(bw, 128, 8, 4096, 1024, 64, 5)
+        if nl:
+            nl["workload"] = "C4-share-node"
+            hb.append(nl)
+        xd["host_buffer_configs"] = hb
+        xo["host"] = [{"id": h["workload"], "v": r4(h.get("value")), "gbs_each_way": r4(h.get("gbytes_per_s_each_way")), "pcie_frac": r4(h.get("pcie_frac")),
+                        **({"bit_equal": h["bit_equal_to_resident_form"]} if "bit_equal_to_resident_form" in h else {}), **({"err": h["error"][:60]} if "error" in h else {})} for h in hb]
+        xo["pcie_pinned_gbs"] = r4(bw["reference"])
+        lat = {"C5-launch": latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True),
+               "C5-resident": latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True, flags=32),   # PV_FLAG_PERSISTENT_STREAM
+               "C2-launch": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, fs=48000.0),
+               "C2-resident": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, flags=32, fs=48000.0)}
+        xd["latency_us"] = lat
+        xo["latency_us"] = {k: {"p50": r4(v["p50"]), "p99": r4(v["p99"]), "budget": r4(v["realtime_budget_us"])} for k, v in lat.items()}
+
     head = measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch, args.steps, args.warmup, "headline", local_rank,
                    frames_per_chunk=args.frames_per_chunk, parity_hops=96 if rank == 0 else 0, seed=rank, repeats=args.repeats,
                    keep_prefix_hops=(1 << 19) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else 0)
@@ -629,88 +712,12 @@ def main():
                                      "round_trip_intact": sg_ok, "rank0_streams": sg_mine}
         if dist is not None:
             out["dist_backend"] = dist.get_backend()          # "nccl" = RCCL on ROCm: barrier, all_reduce(MAX) of the timing, scatter / gather
+        out.update(xo)
         detail = dict(out)
+        detail.update(xd)
+        detail["measured_last"] = bool(xo)
         detail["timed_regions"] = {"count": len(kms), "steps_each": args.steps, "reported": "median region", "ms_per_step": head["regions_ms_per_step"], "kernel_ms": kms}
         detail["csrc_sha16"] = sha
-
-    if world == 1 and not args.no_extras:
-        # ---- the other configurations, each a short measured entry (same harness, same timing method).  Ids: profiles/bench_workloads.md.
-        #      BASELINE's product configurations first, then the unfavourable parameter range, then flavours / signal classes ----
-        extras, extras_full = [], []
-        r4 = lambda v: None if v is None else float(f"{v:.4g}")
-        def add(cid, f2, h2, c2, T2, pt, steps=8, warm=3, **kw):
-            r = measure(torch, phaze_amd, dev, None, f2, h2, c2, T2, pt, steps, warm, cid, local_rank, parity_hops=12, **kw)
-            e = {"id": cid, "v": r4(r["frames_per_step_rank"] * steps / r["elapsed"]), "frac": r4(r["achieved_gbs"] / HBM_PEAK_GBS), "ms": r4(r["kernel_ms"]), "par": r4(r["parity"])}
-            if r["fallback_rate"] is not None:
-                e["fb"] = r4(r["fallback_rate"])
-            extras.append(e)
-            extras_full.append(dict(e, kernel=r["info"]["kernel_name"], steps=steps, warmup=warm, ms_per_step=r["elapsed"] / steps * 1e3, frames_per_chunk=r["info"]["frames_per_chunk"],
-                                    fft=f2, hop=h2, channels=c2, hops=T2))
-        full = lambda n, v: torch.full((n,), v, device=dev, dtype=torch.float32)
-        swp = lambda n: (0.5 + 1.5 * (torch.arange(n, device=dev) % 64).to(torch.float32) / 63.0).to(torch.float32)
-        T3, T5, T8, T2 = 1 << 18, 1 << 14, 1 << 17, 1 << 20
-        add("C3", 2048, 512, 2, T3, full(T3, 0.8))
-        add("C4-share", 4096, 1024, 1024, 64, full(64, 1.25), steps=40, warm=10, ch_per_stream=8)   # 1 ms launches: as many steps as the headline
-        add("C5-sweep", 8192, 2048, 8, T5, swp(T5))
-        add("C5-f1.5", 8192, 2048, 8, T5, full(T5, 1.5))
-        add("8ch-1024", 1024, 256, 8, T8, full(T8, 1.5), steps=40, warm=10)    # (as many steps as the headline: the fixed cost of a timed region read as a "gap" to mono in rounds 3-4)
-        add("native", 2048, 128, 2, T3, full(T3, 1.0))
-        add("C2-f0.8", 1024, 256, 1, T2, full(T2, 0.8), steps=24, warm=6)
-        add("C2-sweep", 1024, 256, 1, T2, swp(T2), steps=24, warm=6)
-        add("C3-f1.5", 2048, 512, 2, T3, full(T3, 1.5))
-        add("C5-f0.6", 8192, 2048, 8, T5, full(T5, 0.6))
-        add("N16384", 16384, 4096, 8, 1 << 11, full(1 << 11, 1.5), steps=4, warm=1)     # complete, not tuned (generic kernel with a device-memory scratch): one timing
-        # the fp32-first forward transform from every side: PV_FLAG_FP64_FORWARD (the round-4 arithmetic) and the signal classes that bound it
-        p15 = full(T2, 1.5)
-        add("C2-fwd64", 1024, 256, 1, T2, p15, steps=24, warm=6, flags=phaze_amd.FLAG_FP64_FORWARD)
-        for sig in ("white", "tonal80", "tonal60", "q16", "silence"):
-            add("C2-" + sig, 1024, 256, 1, T2, p15, steps=16, warm=4, signal=sig)
-            if sig != "white":
-                add("C2-" + sig + "-fwd64", 1024, 256, 1, T2, p15, steps=16, warm=4, signal=sig, flags=phaze_amd.FLAG_FP64_FORWARD)
-        add("C3-tonal80", 2048, 512, 2, T3, full(T3, 0.8), signal="tonal80")
-        add("C3-tonal80-fwd64", 2048, 512, 2, T3, full(T3, 0.8), signal="tonal80", flags=phaze_amd.FLAG_FP64_FORWARD)
-        # ---- the reference-width flavour (never the product; build/exp/libphaze_fp64.so, `make -C phaze_amd/csrc fp64`): shifted spectrum, scatter, residue, c2r pass
-        #      and inverse FFT in fp64 like the reference's JS doubles.  A library is chosen at import time, so it runs in a child ----
-        flib = os.path.join(ROOT, "build", "exp", "libphaze_fp64.so")
-        if os.path.exists(flib) and not os.environ.get("PHAZE_LIB"):
-            for cid, fargs in (("C2-f64", ["--pitch", "1.5"]), ("C2-f0.8-f64", ["--pitch", "0.8"]),
-                               ("C3-f64", ["--fft", "2048", "--hop", "512", "--channels", "2", "--hops", "262144", "--pitch", "0.8"]),
-                               ("C4-share-f64", ["--fft", "4096", "--hop", "1024", "--channels", "1024", "--hops", "64", "--pitch", "1.25"]),
-                               ("C5-sweep-f64", ["--fft", "8192", "--hop", "2048", "--channels", "8", "--hops", "16384", "--pitch-sweep"]),
-                               ("C5-f1.5-f64", ["--fft", "8192", "--hop", "2048", "--channels", "8", "--hops", "16384", "--pitch", "1.5"])):
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--allow-lib-override", "--steps", "10", "--warmup", "3",
-                                    "--repeats", "3"] + fargs, capture_output=True, text=True, timeout=600, env=dict(os.environ, PHAZE_LIB=flib))
-                try:
-                    fj = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-                    e = {"id": cid, "v": r4(fj["value"]), "frac": r4(fj["roofline"]["frac"]), "ms": r4(fj["roofline"]["kernel_ms"]), "par": r4(fj["parity_rms_vs_oracle"])}
-                    extras.append(e)
-                    extras_full.append(dict(e, dtype="f64", kernel=fj["roofline"]["kernel"], lib="build/exp/libphaze_fp64.so", steps=fj["steps"], ms_per_step=fj["ms_per_step"]))
-                except Exception as ex:
-                    extras.append({"id": cid, "err": f"{ex}"[:60]})
-                    extras_full.append({"id": cid, "error": f"{ex}: {(r.stderr or r.stdout)[-300:]}"})
-        out["configs"] = extras
-        detail["configs"] = extras_full
-        # ---- the product boundary with HOST pointers: what a Node / C caller that owns host memory gets, PCIe included.  Never `value`; each entry carries the
-        #      fraction of this box's best pinned hipMemcpy rate it reaches ----
-        bw = pcie_bandwidth(torch, dev)
-        hb = []
-        rows4 = np.stack([np.full(64, 1.25, np.float32) for _ in range(128)])
-        hb.append(host_batch(torch, phaze_amd, dev, 4096, 1024, 1024, 64, 8, rows4, 5, local_rank, bw, "C4-share-host"))
-        hb.append(host_batch(torch, phaze_amd, dev, 1024, 256, 8, 1 << 15, 8, np.full((1, 1 << 15), 1.5, np.float32), 5, local_rank, bw, "8ch-1024-host"))
-        nl = node_sharded_line(bw, 128, 8, 4096, 1024, 64, 5)
-        if nl:
-            nl["workload"] = "C4-share-node"
-            hb.append(nl)
-        detail["host_buffer_configs"] = hb
-        out["host"] = [{"id": h["workload"], "v": r4(h.get("value")), "gbs_each_way": r4(h.get("gbytes_per_s_each_way")), "pcie_frac": r4(h.get("pcie_frac")),
-                        **({"bit_equal": h["bit_equal_to_resident_form"]} if "bit_equal_to_resident_form" in h else {}), **({"err": h["error"][:60]} if "error" in h else {})} for h in hb]
-        out["pcie_pinned_gbs"] = r4(bw["reference"])
-        lat = {"C5-launch": latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True),
-               "C5-resident": latency_histogram(phaze_amd, 8192, 2048, 8, 300, local_rank, sweep=True, flags=32),   # PV_FLAG_PERSISTENT_STREAM
-               "C2-launch": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, fs=48000.0),
-               "C2-resident": latency_histogram(phaze_amd, 1024, 256, 1, 1000, local_rank, sweep=False, flags=32, fs=48000.0)}
-        detail["latency_us"] = lat
-        out["latency_us"] = {k: {"p50": r4(v["p50"]), "p99": r4(v["p99"]), "budget": r4(v["realtime_budget_us"])} for k, v in lat.items()}
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
