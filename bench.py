@@ -148,7 +148,7 @@ def other_input(torch, kind, nch, nsamples, device, seed):
 
 
 def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmup, label, local_rank, frames_per_chunk=0,
-            pitch_stride=0, ch_per_stream=1, parity_hops=0, seed=0, repeats=1, keep_prefix_hops=0, flags=0, signal="bench"):
+            pitch_stride=0, ch_per_stream=1, parity_hops=0, seed=0, repeats=1, keep_prefix_hops=0, flags=0, signal="bench", preheat_s=0.0):
     """One workload: resident input, `warmup` + `steps` launches bracketed by HIP events on the launch stream.  Returns a dict."""
     import numpy as np
     from phaze_amd import shard
@@ -186,6 +186,12 @@ def measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch_t, steps, warmu
     pv.forward_stats(reset=True)
     regions = []
     with torch.cuda.stream(stream):
+        if preheat_s > 0:                         # (see --preheat-seconds: the same workload, untimed, until the box has been busy that long)
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < preheat_s:
+                for _ in range(16):
+                    step()
+                torch.cuda.synchronize()
         for _ in range(warmup):
             step()
         for _ in range(max(1, repeats)):          # every region: EXACTLY `steps` launches between barrier + synchronize on both sides
@@ -451,6 +457,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend under torch.distributed.run.  nccl (= RCCL) is what the driver runs; gloo exists for ONE test that puts two ranks on one "
                          "GPU (RCCL refuses that) to execute the multi-rank code paths end to end (tests/test_gpu_multirank.py)")
+    ap.add_argument("--preheat-seconds", type=float, default=-1.0,
+                    help="untimed launches of the headline workload in front of its --warmup steps, until the GPU has been busy this long.  Default: 0 when the other "
+                         "configurations run first (N = 1: they already keep the box busy for ~20 s) and with --no-extras (profiling runs); 8 for N > 1, where the headline is "
+                         "all a rank runs: a freshly leased box spends its first seconds below its sustained clocks, and the per-N values must be measured in the same state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-config lines and the latency histogram (profiling runs)")
     ap.add_argument("--allow-lib-override", action="store_true", help="accept PHAZE_LIB (A/B builds of the same ABI); recorded in the line")
@@ -618,9 +628,10 @@ def main():
         xd["latency_us"] = lat
         xo["latency_us"] = {k: {"p50": r4(v["p50"]), "p99": r4(v["p99"]), "budget": r4(v["realtime_budget_us"])} for k, v in lat.items()}
 
+    preheat = args.preheat_seconds if args.preheat_seconds >= 0 else (8.0 if world > 1 else 0.0)
     head = measure(torch, phaze_amd, dev, dist, fft, hop, nch, T, pitch, args.steps, args.warmup, "headline", local_rank,
                    frames_per_chunk=args.frames_per_chunk, parity_hops=96 if rank == 0 else 0, seed=rank, repeats=args.repeats,
-                   keep_prefix_hops=(1 << 19) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else 0)
+                   keep_prefix_hops=(1 << 19) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else 0, preheat_s=preheat)
 
     sg_ms = None
     if args.scatter_gather and dist is not None:             # also at world size 1 under torchrun: the collectives still run through RCCL
@@ -687,6 +698,7 @@ def main():
                          "frac_of_measured_copy": (head["achieved_gbs"] / copy_gbs) if copy_gbs else None,
                          "note": "bound by VALU issue, not HBM: see roofline_valu"},
             "parity_rms_vs_oracle": head["parity"], "fallback_rate": head["fallback_rate"],
+            "busy_before_headline": ("other configs (~20 s)" if xo else f"preheat {preheat:g} s" if preheat > 0 else "none"),
         }
         # what actually binds (round-5 verdict, item 5c): VALU issue cycles of the dominant kernel over the SIMD cycles of its launch, from the PMC pass of
         # profiles/run_profile_r06.sh (profiles/valu_issue.json, stamped with the hash of the kernel sources like hbm_traffic.json)
