@@ -35,7 +35,7 @@ enum {
     PV_OK = 0,
     PV_ERR_FFT_SIZE = 1,     /* 'FFT size must be a power of two and bigger than 1' (bundle:6-7)        */
     PV_ERR_ARGUMENT = 2,     /* NULL pointer, negative count, hop does not divide fft_size, ...          */
-    PV_ERR_UNSUPPORTED = 3,  /* valid for the reference but outside this build's kernel range (64..32768) */
+    PV_ERR_UNSUPPORTED = 3,  /* valid for the reference but outside this build's kernel range (2..1048576)  */
     PV_ERR_CAPACITY = 4,     /* more channels / hops than the handle was created for                     */
     PV_ERR_DEVICE = 5,       /* HIP runtime error (no GPU, launch failure, out of memory)                */
     PV_ERR_DESTROYED = 6     /* handle already destroyed                                                  */
@@ -57,7 +57,7 @@ typedef struct pv_handle pv_handle;
 typedef struct pv_config {
     int32_t struct_size;     /* sizeof(pv_config) as the CALLER compiled it (PV_CONFIG_INIT sets it).  pv_create rejects any other value with
                               * PV_ERR_ARGUMENT: a caller built against another layout would otherwise have trailing fields (flags!) read as garbage */
-    int32_t fft_size;        /* N, power of two > 1 (else PV_ERR_FFT_SIZE); kernels cover 64..32768       */
+    int32_t fft_size;        /* N, power of two > 1 (else PV_ERR_FFT_SIZE); kernels cover 2..1048576      */
     int32_t hop_size;        /* h >= 2, divides N.  nbOverlaps R = N / h (ola-processor.js:17)           */
     int32_t max_channels;    /* channel slots owned by this handle (streams x channels); 0 => 2.  One launch
                               * takes any count for N = 1024 (hops 128..1024) and up to 65535 otherwise (PV_ERR_CAPACITY) */

@@ -399,7 +399,7 @@ int pv_create(const pv_config *cfg, pv_handle **out)
     if (hop <= 0 || N % hop != 0) return fail(nullptr, PV_ERR_ARGUMENT, "hop_size must be positive and divide fft_size");
     int log2n = 0;
     while ((1 << log2n) < N) log2n++;
-    if (log2n < 6 || log2n > 15) return fail(nullptr, PV_ERR_UNSUPPORTED, "fft_size must be within 64..32768 for the gfx950 kernels");
+    if (log2n > 20) return fail(nullptr, PV_ERR_UNSUPPORTED, "fft_size must be within 2..1048576 for the gfx950 kernels");
     if (hop < 2) return fail(nullptr, PV_ERR_UNSUPPORTED, "hop_size must be >= 2");
     {
         const bool generic = (cfg->flags & PV_FLAG_GENERIC_KERNEL) != 0;

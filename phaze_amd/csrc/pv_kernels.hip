@@ -348,7 +348,8 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
         }
         for (int bt = 0; bt < NBATCH; bt++) {
         float2 ys[SPT];
-        unsigned short tg[SPT];
+        using tgt_t = typename std::conditional<(LOG2N > 16), unsigned, unsigned short>::type;   // target bin < H (N = 131072: 17 bits)
+        tgt_t tg[SPT];
         unsigned pend = 0;
 #pragma unroll
         for (int i = 0; i < SPT; i++) {
@@ -378,11 +379,11 @@ __global__ __launch_bounds__(THREADS) void pv_chain_kernel(const PvKernelParams 
             const int delta = (int)psh - owner;
             const int tgt = b + delta;
             if (tgt < 0 || tgt >= H) continue;                             // pv:150-152; negative index: named property
-            const int ridx = ((delta & (N - 1)) * tmod) & (N - 1);         // (delta * t) mod N  (pv:155-157)
+            const int ridx = (int)(((unsigned)(delta & (N - 1)) * (unsigned)tmod) & (unsigned)(N - 1));   // (delta * t) mod N  (pv:155-157); unsigned: the product wraps at N >= 65536
             const float2 rot = cconj(p.tw32[ridx]);                        // exp(+2 pi j ridx / N)
             const float2 v = (b < H) ? Af[b] : B[b];
             ys[i] = cmul(v, rot);
-            tg[i] = (unsigned short)tgt;
+            tg[i] = (tgt_t)tgt;
             if (disjoint) B[tgt] = ys[i];                                  // f >= 1: delta_i non-decreasing => shifted regions never overlap
             else pend |= 1u << i;
         }
@@ -504,6 +505,11 @@ hipError_t pv_launch_chain(int log2n, const PvKernelParams &p, int nch, int nchu
 {
     const size_t lds = pv_kernel_lds_bytes(log2n, p.hop);
     switch (log2n) {
+    case 1: return launch_one<1, 64>(p, nch, nchunks, lds, st);
+    case 2: return launch_one<2, 64>(p, nch, nchunks, lds, st);
+    case 3: return launch_one<3, 64>(p, nch, nchunks, lds, st);
+    case 4: return launch_one<4, 64>(p, nch, nchunks, lds, st);
+    case 5: return launch_one<5, 64>(p, nch, nchunks, lds, st);
     case 6: return launch_one<6, 64>(p, nch, nchunks, lds, st);
     case 7: return launch_one<7, 64>(p, nch, nchunks, lds, st);
     case 8: return launch_one<8, 64>(p, nch, nchunks, lds, st);
@@ -514,6 +520,11 @@ hipError_t pv_launch_chain(int log2n, const PvKernelParams &p, int nch, int nchu
     case 13: return launch_one<13, 256>(p, nch, nchunks, lds, st);
     case 14: return launch_one<14, 512, 1>(p, nch, nchunks, lds, st);
     case 15: return launch_one<15, 512, 2>(p, nch, nchunks, lds, st);
+    case 16: return launch_one<16, 512, 2>(p, nch, nchunks, lds, st);
+    case 17: return launch_one<17, 512, 2>(p, nch, nchunks, lds, st);
+    case 18: return launch_one<18, 512, 2>(p, nch, nchunks, lds, st);
+    case 19: return launch_one<19, 512, 2>(p, nch, nchunks, lds, st);
+    case 20: return launch_one<20, 512, 2>(p, nch, nchunks, lds, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -52,7 +52,7 @@ def test_errors_without_device():
     assert L.pv_last_error(None).decode() == "FFT size must be a power of two and bigger than 1"     # bundle:6-7
     cfg = capi.make_config(1024, 300)
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_ARGUMENT
-    cfg = capi.make_config(65536, 16384)
+    cfg = capi.make_config(2097152, 524288)
     assert L.pv_create(C.byref(cfg), C.byref(h)) == capi.PV_ERR_UNSUPPORTED
     assert L.pv_status_string(capi.PV_ERR_DEVICE).decode() == "HIP device error"
     # ABI guards (round 3): a config of another layout, or flag bits this build does not know, are refused before any device is touched

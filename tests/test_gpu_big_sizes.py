@@ -1,4 +1,4 @@
-"""N = 16384 and 32768 (round 5; verdict r04 "missing" 2): `new FFT(n)` takes any power of two (bundle:4-8), and beyond 8192 a frame no longer fits the LDS of a CU --
+"""N = 16384 ... 1048576 (round 5: 16384 and 32768; round 6: 65536 ... 1048576, and 2 ... 32 below; verdict r04 "missing" 2, r05 "missing" 5): `new FFT(n)` takes any power of two (bundle:4-8), and beyond 8192 a frame no longer fits the LDS of a CU --
 pv_chain_kernel's global-scratch instances keep the fp32 buffer and the overlap-add ring (N = 32768: the fp64 buffer too) in a slice of device memory per workgroup.
 Against the oracle at the bar of every other size (2e-7 RMS; measured ~1e-8); chunked = unchunked = call-split bit for bit; the streaming entry point."""
 import numpy as np
@@ -17,7 +17,9 @@ def _pv(**kw):
 
 
 @pytest.mark.parametrize("fft,hop,T,pf", [(16384, 4096, 12, 1.5), (16384, 4096, 12, 0.8), (16384, 2048, 20, 0.6), (16384, 16384, 4, 1.25), (16384, 128, 140, 1.5),
-                                          (32768, 8192, 10, 1.5), (32768, 8192, 10, 0.7), (32768, 4096, 18, "sweep"), (32768, 32768, 3, 0.9)])
+                                          (32768, 8192, 10, 1.5), (32768, 8192, 10, 0.7), (32768, 4096, 18, "sweep"), (32768, 32768, 3, 0.9),
+                                          (65536, 16384, 8, 1.5), (65536, 16384, 8, 0.7), (65536, 8192, 12, "sweep"), (131072, 32768, 7, 1.25), (131072, 32768, 7, 0.8),
+                                          (262144, 65536, 6, 1.5), (262144, 32768, 9, 0.75), (1048576, 262144, 5, 1.25), (1048576, 262144, 5, 0.8)])
 def test_big_sizes_match_the_oracle(fft, hop, T, pf):
     nch = 2
     x = np.stack([S.make_signal(["tonal", "noise"][c], c, T * hop, stream=fft + hop) for c in range(nch)])
@@ -87,4 +89,33 @@ def test_big_size_taps_match_the_oracle():
 def test_sizes_beyond_the_kernels_are_refused():
     import phaze_amd
     with pytest.raises(phaze_amd.PvError):
-        _pv(fft_size=65536, hop_size=16384)
+        _pv(fft_size=2097152, hop_size=524288)
+
+
+@pytest.mark.parametrize("fft,hop,T,pf", [(32, 8, 200, 1.5), (32, 8, 200, 0.7), (32, 32, 40, 1.25), (32, 2, 300, "sweep"), (16, 4, 300, 1.5), (16, 4, 300, 0.6), (16, 8, 100, "sweep"),
+                                          (8, 2, 400, 1.5), (8, 2, 400, 0.8), (8, 4, 200, "sweep"), (4, 2, 300, 1.5), (4, 4, 100, 0.7), (2, 2, 300, 1.25)])
+def test_small_sizes_match_the_oracle(fft, hop, T, pf):
+    """N = 8, 16, 32 (round 6; verdict r05 "missing" 5): `new FFT(n)` takes any power of two > 1 (bundle:4-8).  Nothing below 64 fills a wavefront -- the generic kernel runs them
+    with idle lanes --, and the reference's own processor has no meaning there at its fixed 128-sample quantum; the path is still the path: against the oracle at the bar of every
+    other size, chunked = unchunked = call-split bit for bit."""
+    nch = 2
+    x = np.stack([S.make_signal(["tonal", "noise"][c], c, T * hop, stream=fft + hop) for c in range(nch)])
+    p = (0.5 + 1.5 * (np.arange(T) % 16) / 15.0 if pf == "sweep" else np.full(T, pf)).astype(np.float32)
+    pv = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T)
+    assert pv.info()["kernel_name"] == "pv_chain_kernel"
+    y = pv.process_batch(x, p)
+    pv.close()
+    yo = oracle_lib.Oracle(fft, hop, nch).process_planar(x, p)
+    assert np.all(np.isfinite(y))
+    err = S.rms(y.astype(np.float64) - yo)
+    print(fft, hop, pf, "rms vs oracle", err, "rms(out)", S.rms(yo))
+    assert err < REGRESSION_RMS, err
+    pv = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T, frames_per_chunk=7)
+    y2 = pv.process_batch(x, p)
+    pv.close()
+    assert np.array_equal(y, y2)
+    pv = _pv(fft_size=fft, hop_size=hop, max_channels=nch, max_hops=T)
+    k = T // 3
+    y3 = np.concatenate([pv.process_batch(x[:, :k * hop], p[:k]), pv.process_batch(x[:, k * hop:], p[k:])], axis=1)
+    pv.close()
+    assert np.array_equal(y, y3)
