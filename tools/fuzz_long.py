@@ -11,7 +11,7 @@ worst, t0, kern = 0.0, time.time(), {}
 for i in range(n):
     N, hop, nch, T, kind, p = _case(rng)
     if pin:
-        N = 1 << pin; hop = N >> int(rng.integers(0, 5)); nch = int(rng.integers(1, 5)); T = len(p)
+        N = 1 << pin; hop = max(2, N >> int(rng.integers(0, 5))); nch = int(rng.integers(1, 5)); T = len(p)
     x = np.stack([S.make_signal(kind, c, T * hop, stream=i) for c in range(nch)])
     fpc = int(rng.choice([0, 0, 1, 3, 7, 16]))
     pv = phaze_amd.PhaseVocoder(fft_size=N, hop_size=hop, max_channels=nch, max_hops=T, frames_per_chunk=fpc)
